@@ -1,0 +1,155 @@
+/*
+ * r2hip.h -- C ABI of libr2hip.so, the MI355X (gfx950) implementation of the R2-Gaussian hot path:
+ * differentiable X-ray rasterizer, 3D voxelizer and simple-knn.
+ *
+ * Every entry point replaces one function of the reference's native layer L0/L1
+ * (paths relative to r2_gaussian/submodules/xray-gaussian-rasterization-voxelization/ = SUB):
+ *
+ *   r2_raster_forward     <- CudaRasterizer::Rasterizer::forward      SUB/cuda_rasterizer/rasterizer.h:36-56,  rasterizer_impl.cu:196-331
+ *   r2_raster_backward    <- CudaRasterizer::Rasterizer::backward     SUB/cuda_rasterizer/rasterizer.h:58-85,  rasterizer_impl.cu:335-421
+ *   r2_mark_visible       <- CudaRasterizer::Rasterizer::markVisible  SUB/cuda_rasterizer/rasterizer.h:29-34,  rasterizer_impl.cu:141-153
+ *   r2_voxel_forward      <- CudaVoxelizer::Voxelizer::forward        SUB/cuda_voxelizer/voxelizer.h:28-47,    voxelizer_impl.cu:171-302
+ *   r2_voxel_backward     <- CudaVoxelizer::Voxelizer::backward       SUB/cuda_voxelizer/voxelizer.h:49-72,    voxelizer_impl.cu:307-389
+ *   r2_knn_dist2          <- simple_knn._C.distCUDA2 (un-vendored submodule; call site r2_gaussian/gaussian/gaussian_model.py:145-150)
+ *
+ * Conventions (identical to the reference's L0):
+ *   - all data pointers are DEVICE pointers to contiguous float32 / int32 arrays owned by the caller;
+ *   - "absent" optional inputs (scales/rotations vs cov3D_precomp) are passed as NULL;
+ *   - 4x4 matrices are 16 floats indexed m[col*4+row] (== row-major memory of the transposed
+ *     matrices torch hands over: world_view_transform, full_proj_transform);
+ *   - the library never allocates result/state memory: it asks the caller for bytes through the
+ *     three r2_alloc_fn callbacks, the C form of the reference's std::function<char*(size_t)>
+ *     (SUB/utility.h:7-13).  The layout inside those buffers is private to the library;
+ *   - gradient outputs of the backward calls must be ZERO-INITIALISED by the caller, as the
+ *     reference's torch boundary does (SUB/rasterize_points.cu:124-131, SUB/voxelize_points.cu:130-136);
+ *   - `stream` is a hipStream_t (NULL = the null stream).  Work is enqueued on it; the forward
+ *     calls synchronise that stream once to learn num_rendered (the reference's cudaMemcpy D2H,
+ *     rasterizer_impl.cu:279), the backward calls do not synchronise;
+ *   - return value: >= 0 on success (forward: num_rendered), < 0 = -(hipError_t) or R2_ERR_*;
+ *     r2_last_error() gives a message.  With debug != 0 the stream is synchronised and checked after
+ *     every stage (the reference's CHECK_CUDA, SUB/cuda_rasterizer/auxiliary.h:170-177).
+ */
+#ifndef R2HIP_H
+#define R2HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define R2_API __attribute__((visibility("default")))
+#else
+#define R2_API
+#endif
+
+#define R2_ABI_VERSION 1
+#define R2_ERR_INVALID (-10001) /* bad argument (NULL where data is required, negative size ...) */
+#define R2_ERR_ALLOC   (-10002) /* an r2_alloc_fn callback returned NULL */
+
+/* Returns a device pointer to at least `bytes` bytes (128-byte aligned), valid until the matching
+ * backward call has been enqueued.  `user` is passed through untouched. */
+typedef char *(*r2_alloc_fn)(size_t bytes, void *user);
+
+R2_API int r2_abi_version(void);
+R2_API const char *r2_last_error(void);
+
+/* ---- rasterizer ------------------------------------------------------------------------------ */
+R2_API int r2_raster_forward(
+    r2_alloc_fn geometryBuffer, void *geometry_user,
+    r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user,
+    int P, int width, int height,
+    const float *means3D,      /* [P,3] */
+    const float *opacities,    /* [P]   activated density */
+    const float *scales,       /* [P,3] or NULL */
+    float scale_modifier,
+    const float *rotations,    /* [P,4] (r,x,y,z) or NULL */
+    const float *cov3D_precomp,/* [P,6] or NULL */
+    const float *viewmatrix,   /* [16] */
+    const float *projmatrix,   /* [16] */
+    const float *cam_pos,      /* [3], unused by the X-ray path (kept for signature parity) */
+    float tan_fovx, float tan_fovy,
+    int prefiltered,
+    int mode,                  /* 0 parallel beam, 1 cone beam */
+    float *out_color,          /* [1,H,W] */
+    int *radii,                /* [P] */
+    int debug,
+    void *stream);
+
+R2_API int r2_raster_backward(
+    int P, int R, int width, int height,
+    const float *means3D, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *campos,
+    float tan_fovx, float tan_fovy,
+    const int *radii,
+    char *geom_buffer, char *binning_buffer, char *img_buffer,
+    const float *dL_dpix,      /* [1,H,W] */
+    float *dL_dmean2D,         /* [P,3] (z stays 0) */
+    float *dL_dconic,          /* [P,2,2] (slots 0,1,3) */
+    float *dL_dopacity,        /* [P,1] */
+    float *dL_dmu,             /* [P,1] */
+    float *dL_dmean3D,         /* [P,3] */
+    float *dL_dcov3D,          /* [P,6] */
+    float *dL_dscale,          /* [P,3] */
+    float *dL_drot,            /* [P,4] */
+    int mode, int debug, void *stream);
+
+R2_API int r2_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                    uint8_t *present /* [P] bool */, void *stream);
+
+/* ---- voxelizer ------------------------------------------------------------------------------- */
+R2_API int r2_voxel_forward(
+    r2_alloc_fn geometryBuffer, void *geometry_user,
+    r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user,
+    int P,
+    int nVoxel_x, int nVoxel_y, int nVoxel_z,
+    float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z,
+    const float *means3D, const float *opacities, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp,
+    int prefiltered,
+    float *out_volume,         /* [nx,ny,nz] */
+    int *radii_x, int *radii_y, int *radii_z, /* [P] each */
+    int debug, void *stream);
+
+R2_API int r2_voxel_backward(
+    int P, int R,
+    int nVoxel_x, int nVoxel_y, int nVoxel_z,
+    float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z,
+    const float *means3D, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp,
+    const int *radii_x, const int *radii_y, const int *radii_z,
+    char *geom_buffer, char *binning_buffer, char *img_buffer,
+    const float *dL_dvol,      /* [nx,ny,nz] */
+    float *dL_dmean3D_norm,    /* [P,3] */
+    float *dL_dconic3D,        /* [P,6] */
+    float *dL_dopacity,        /* [P,1] */
+    float *dL_dmean3D,         /* [P,3] */
+    float *dL_dcov3D,          /* [P,6] */
+    float *dL_dscale,          /* [P,3] */
+    float *dL_drot,            /* [P,4] */
+    int debug, void *stream);
+
+/* ---- simple-knn ------------------------------------------------------------------------------ */
+/* mean of the 3 smallest squared distances to the other points; out[P].  No workspace needed. */
+R2_API int r2_knn_dist2(int P, const float *points /* [P,3] */, float *out /* [P] */, void *stream);
+
+/* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
+/* Byte offsets of the private arrays inside the state buffers of the LAST forward call with the
+ * given sizes; lets tests read radii/offsets/keys/point_list/ranges back without fixing the layout
+ * in the ABI.  which: 0 tiles_touched u32[P], 1 point_offsets u32[P], 2 keys_unsorted u64[R],
+ * 3 values_unsorted u32[R], 4 keys_sorted u64[R], 5 point_list u32[R], 6 ranges uint2[T],
+ * 7 cov3D f32[6P], 8 n_contrib u32[N] (only filled when forward ran with debug != 0).
+ * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
+R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);
+R2_API long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R2HIP_H */

@@ -1,0 +1,221 @@
+"""Python mirror of the reference's pybind module ``xray_gaussian_rasterization_voxelization._C``
+(SUB/ext.cpp:17-23): the same five functions with the same argument lists and return tuples, implemented on
+top of the C ABI of libr2hip.so.  This file plays the role of the torch boundary
+SUB/rasterize_points.cu / SUB/voxelize_points.cu: it owns tensor allocation (outputs, zeroed gradient
+buffers, the three opaque uint8 state tensors handed to the kernels through allocation callbacks) and passes
+raw device pointers + the current HIP stream down.
+"""
+import torch
+
+from . import _lib
+
+_F32 = torch.float32
+
+
+def _ptr(t):
+    """Device pointer of a contiguous float32/int32 tensor; empty tensors become NULL (the reference passes
+    ``torch.Tensor([])`` for absent inputs, whose data pointer is null)."""
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _dev_f32(t, like):
+    """Contiguous float32 view on the kernel's device (SUB/rasterize_points.cu:79-93 ``.contiguous()``)."""
+    if t is None or t.numel() == 0:
+        return None
+    if t.dtype != _F32:
+        t = t.to(_F32)
+    if t.device != like.device:
+        t = t.to(like.device)
+    return t.contiguous()
+
+
+def _require_gpu(t, name):
+    if not t.is_cuda:
+        raise _lib.R2HipError("%s must be a GPU tensor: the MI355X kernels have no CPU fallback" % name)
+
+
+class _State:
+    """Three growable byte tensors + the ctypes callbacks that resize them (SUB/utility.h:7-13)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.bufs = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.cbs = [_lib.ALLOC_FN(self._make(i)) for i in range(3)]
+
+    def _make(self, i):
+        def alloc(nbytes, _user):
+            try:
+                self.bufs[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                return self.bufs[i].data_ptr()
+            except Exception:   # out of memory etc.: report NULL, the C side turns it into R2_ERR_ALLOC
+                return None
+        return alloc
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def rasterize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                        projmatrix, tan_fovx, tan_fovy, image_height, image_width, campos, prefiltered, mode,
+                        debug):
+    """-> (num_rendered, out_color[1,H,W], radii[P] i32, geomBuffer u8, binningBuffer u8, imgBuffer u8)
+    (SUB/rasterize_points.cu:28-97)."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P, H, W = means3D.shape[0], int(image_height), int(image_width)
+    out_color = torch.zeros((1, H, W), dtype=_F32, device=dev)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    st = _State(dev)
+    rendered = 0
+    if P != 0:
+        m3 = _dev_f32(means3D, means3D)
+        op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
+        vm, pm, cam = (_dev_f32(t, means3D) for t in (viewmatrix, projmatrix, campos))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_raster_forward(
+                st.cbs[0], None, st.cbs[1], None, st.cbs[2], None, P, W, H, _ptr(m3), _ptr(op), _ptr(sc),
+                float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm), _ptr(cam), float(tan_fovx),
+                float(tan_fovy), int(bool(prefiltered)), int(mode), out_color.data_ptr(), radii.data_ptr(),
+                int(bool(debug)), _stream(dev))
+        rendered = _lib.check(rc, "r2_raster_forward")
+    return rendered, out_color, radii, st.bufs[0], st.bufs[1], st.bufs[2]
+
+
+def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
+                                 projmatrix, tan_fovx, tan_fovy, dL_dout_color, campos, geomBuffer, R,
+                                 binningBuffer, imageBuffer, mode, debug):
+    """-> (dL_dmeans2D[P,3], dL_dopacity[P,1], dL_dmu[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dscales[P,3],
+    dL_drotations[P,4])  (SUB/rasterize_points.cu:99-164)."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
+    # one zero-fill for all eight gradient arrays (25 floats per Gaussian); 16-byte rows first
+    flat = torch.zeros(25 * P, dtype=_F32, device=dev)
+    cuts = [4, 4, 3, 3, 1, 1, 6, 3]
+    views, o = [], 0
+    for c in cuts:
+        views.append(flat[o:o + c * P])
+        o += c * P
+    dL_dconic = views[0].view(P, 2, 2)
+    dL_drot = views[1].view(P, 4)
+    dL_dmeans3D = views[2].view(P, 3)
+    dL_dmeans2D = views[3].view(P, 3)
+    dL_dopacity = views[4].view(P, 1)
+    dL_dmu = views[5].view(P, 1)
+    dL_dcov3D = views[6].view(P, 6)
+    dL_dscales = views[7].view(P, 3)
+    if P != 0:
+        m3 = _dev_f32(means3D, means3D)
+        sc, ro, cp = (_dev_f32(t, means3D) for t in (scales, rotations, cov3D_precomp))
+        vm, pm, cam = (_dev_f32(t, means3D) for t in (viewmatrix, projmatrix, campos))
+        g = _dev_f32(dL_dout_color, means3D)
+        rad = radii.contiguous()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_raster_backward(
+                P, int(R), W, H, _ptr(m3), _ptr(sc), float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm),
+                _ptr(cam), float(tan_fovx), float(tan_fovy), rad.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
+                _ptr(imageBuffer), _ptr(g), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(),
+                dL_dmu.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dscales.data_ptr(),
+                dL_drot.data_ptr(), int(mode), int(bool(debug)), _stream(dev))
+        _lib.check(rc, "r2_raster_backward")
+    return dL_dmeans2D, dL_dopacity, dL_dmu, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drot
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """-> bool[P], ``z_view > 0.2``  (SUB/rasterize_points.cu:166-185)."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    present = torch.zeros((P,), dtype=torch.bool, device=dev)
+    if P != 0:
+        m3, vm, pm = (_dev_f32(t, means3D) for t in (means3D, viewmatrix, projmatrix))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), present.data_ptr(), _stream(dev))
+        _lib.check(rc, "r2_mark_visible")
+    return present
+
+
+def voxelize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, nVoxel_x, nVoxel_y,
+                       nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, prefiltered, debug):
+    """-> (num_rendered, out_volume[nx,ny,nz], radii_x, radii_y, radii_z, geomBuffer, binningBuffer, imgBuffer)
+    (SUB/voxelize_points.cu:29-98)."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    nx, ny, nz = int(nVoxel_x), int(nVoxel_y), int(nVoxel_z)
+    out = torch.zeros((nx, ny, nz), dtype=_F32, device=dev)
+    radii = torch.zeros((3, P), dtype=torch.int32, device=dev)
+    st = _State(dev)
+    rendered = 0
+    if P != 0:
+        m3 = _dev_f32(means3D, means3D)
+        op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_voxel_forward(
+                st.cbs[0], None, st.cbs[1], None, st.cbs[2], None, P, nx, ny, nz, float(sVoxel_x), float(sVoxel_y),
+                float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(op), _ptr(sc),
+                float(scale_modifier), _ptr(ro), _ptr(cp), int(bool(prefiltered)), out.data_ptr(),
+                radii[0].data_ptr(), radii[1].data_ptr(), radii[2].data_ptr(), int(bool(debug)), _stream(dev))
+        rendered = _lib.check(rc, "r2_voxel_forward")
+    return rendered, out, radii[0], radii[1], radii[2], st.bufs[0], st.bufs[1], st.bufs[2]
+
+
+def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rotations, scale_modifier,
+                                cov3D_precomp, dL_dout_color, geomBuffer, R, binningBuffer, imageBuffer, nVoxel_x,
+                                nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z,
+                                debug):
+    """-> (dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dscales[P,3], dL_drotations[P,4])
+    (SUB/voxelize_points.cu:102-167)."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P = means3D.shape[0]
+    flat = torch.zeros(26 * P, dtype=_F32, device=dev)
+    cuts = [4, 3, 3, 6, 1, 6, 3]
+    views, o = [], 0
+    for c in cuts:
+        views.append(flat[o:o + c * P])
+        o += c * P
+    dL_drot = views[0].view(P, 4)
+    dL_dmeans3D = views[1].view(P, 3)
+    dL_dmeans3D_norm = views[2].view(P, 3)
+    dL_dconic3D = views[3].view(P, 6)
+    dL_dopacity = views[4].view(P, 1)
+    dL_dcov3D = views[5].view(P, 6)
+    dL_dscales = views[6].view(P, 3)
+    if P != 0:
+        m3 = _dev_f32(means3D, means3D)
+        sc, ro, cp = (_dev_f32(t, means3D) for t in (scales, rotations, cov3D_precomp))
+        g = _dev_f32(dL_dout_color, means3D)
+        rx, ry, rz = radii_x.contiguous(), radii_y.contiguous(), radii_z.contiguous()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_voxel_backward(
+                P, int(R), int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y),
+                float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(sc),
+                float(scale_modifier), _ptr(ro), _ptr(cp), rx.data_ptr(), ry.data_ptr(), rz.data_ptr(),
+                _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(g), dL_dmeans3D_norm.data_ptr(),
+                dL_dconic3D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
+                dL_dscales.data_ptr(), dL_drot.data_ptr(), int(bool(debug)), _stream(dev))
+        _lib.check(rc, "r2_voxel_backward")
+    return dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drot
+
+
+def distCUDA2(points):
+    """simple_knn._C.distCUDA2: mean squared distance to the 3 nearest neighbours, [P] f32."""
+    _require_gpu(points, "points")
+    dev = points.device
+    pts = _dev_f32(points, points)
+    P = points.shape[0]
+    out = torch.zeros((P,), dtype=_F32, device=dev)
+    if P != 0:
+        with torch.cuda.device(dev):
+            rc = _lib.lib().r2_knn_dist2(P, _ptr(pts), out.data_ptr(), _stream(dev))
+        _lib.check(rc, "r2_knn_dist2")
+    return out

@@ -1,0 +1,71 @@
+"""ctypes binding of libr2hip.so (the C ABI declared in include/r2hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the ops
+raises.  Build it with ``python -m r2_gaussian_amd.build`` (or ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libr2hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
+
+R2_ABI_VERSION = 1
+R2_ERR_INVALID = -10001
+R2_ERR_ALLOC = -10002
+
+_f, _i, _p, _fp = C.c_float, C.c_int, C.c_void_p, C.c_void_p
+
+_SIGNATURES = {
+    "r2_abi_version": (C.c_int, []),
+    "r2_last_error": (C.c_char_p, []),
+    "r2_raster_forward": (C.c_int, [ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _fp, _fp, _fp, _f, _fp, _fp,
+                                    _fp, _fp, _fp, _f, _f, _i, _i, _fp, _p, _i, _p]),
+    "r2_raster_backward": (C.c_int, [_i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp, _fp, _fp, _f, _f, _p, _p, _p, _p,
+                                     _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _p]),
+    "r2_mark_visible": (C.c_int, [_i, _fp, _fp, _fp, _p, _p]),
+    "r2_voxel_forward": (C.c_int, [ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
+                                   _fp, _fp, _fp, _f, _fp, _fp, _i, _fp, _p, _p, _p, _i, _p]),
+    "r2_voxel_backward": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _fp, _f, _fp, _fp, _p, _p, _p,
+                                    _p, _p, _p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _p]),
+    "r2_knn_dist2": (C.c_int, [_i, _fp, _fp, _p]),
+    "r2_raster_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, C.POINTER(C.c_int)]),
+    "r2_voxel_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, _i, C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+class R2HipError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libr2hip.so once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise R2HipError(
+                "libr2hip.so not found at %s -- the HIP extension is required (no fallback). "
+                "Run `python -m r2_gaussian_amd.build`." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        if L.r2_abi_version() != R2_ABI_VERSION:
+            raise R2HipError("libr2hip.so ABI %d != expected %d" % (L.r2_abi_version(), R2_ABI_VERSION))
+        _lib = L
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what):
+    if rc < 0:
+        msg = lib().r2_last_error()
+        raise R2HipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))
+    return rc

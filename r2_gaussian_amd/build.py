@@ -1,0 +1,86 @@
+"""Builds r2_gaussian_amd/libr2hip.so from csrc/*.hip with plain hipcc for gfx950 (in-tree, no JIT cache).
+
+    python -m r2_gaussian_amd.build [--force]
+
+Geometry translation units (``*_geom.hip``, ``knn.hip``) are compiled with ``-ffp-contract=off``: every
+float that can feed an integer decision (radius, tile rectangle, sort key) is a separately rounded
+IEEE-754 op, which is what makes tile / sort indices bit-exact against the CPU oracle.  The render
+kernels keep FMA contraction (they are VALU-bound and tolerance-checked).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "csrc", "build")
+LIB = os.path.join(HERE, "libr2hip.so")
+
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function"]
+EXACT = ["-ffp-contract=off"]
+FAST = ["-ffp-contract=fast"]
+
+SOURCES = {
+    "binning.hip": FAST,
+    "raster_geom.hip": EXACT,
+    "raster_render.hip": FAST,
+    "raster_api.hip": FAST,
+    "voxel_geom.hip": EXACT,
+    "voxel_render.hip": FAST,
+    "voxel_api.hip": FAST,
+    "knn.hip": EXACT,
+}
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _deps_mtime():
+    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    hdrs.append(os.path.join(HERE, "..", "include", "r2hip.h"))
+    hdrs.append(os.path.abspath(__file__))
+    return max(os.path.getmtime(h) for h in hdrs)
+
+
+def _compile(src, flags, force, hdr_mtime):
+    s = os.path.join(CSRC, src)
+    o = os.path.join(OBJ, src.replace(".hip", ".o"))
+    if not force and os.path.exists(o) and os.path.getmtime(o) >= max(os.path.getmtime(s), hdr_mtime):
+        return o, False
+    cmd = [_hipcc()] + COMMON + flags + ["-c", s, "-o", o]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr[-8000:]))
+    if r.stderr.strip():
+        sys.stderr.write(r.stderr)
+    return o, True
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    present = {k: v for k, v in SOURCES.items() if os.path.exists(os.path.join(CSRC, k))}
+    missing = sorted(set(SOURCES) - set(present))
+    if missing:
+        raise RuntimeError("missing kernel sources: %s" % missing)
+    hdr_mtime = _deps_mtime()
+    with ThreadPoolExecutor(max_workers=min(8, len(present))) as ex:
+        res = list(ex.map(lambda kv: _compile(kv[0], kv[1], force, hdr_mtime), present.items()))
+    objs = [o for o, _ in res]
+    if force or any(c for _, c in res) or not os.path.exists(LIB):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+        if verbose:
+            print("linked", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

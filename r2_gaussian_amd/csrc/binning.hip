@@ -1,0 +1,94 @@
+// binning.hip -- prefix sum, stable radix sort and tile-range detection shared by the rasterizer
+// and the voxelizer.  Replaces cub::DeviceScan::InclusiveSum / cub::DeviceRadixSort::SortPairs /
+// identifyTileRanges of the reference (RAS/rasterizer_impl.cu:116-138,275,301-316).
+#include "r2_common.hpp"
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <stdarg.h>
+
+namespace r2 {
+
+static thread_local char g_err[512] = "";
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char *get_error() { return g_err; }
+
+uint32_t higher_msb(uint32_t n)
+{
+    // smallest b with (n >> b) == 0, i.e. bit length of n (same value as the reference's
+    // getHigherMsb binary search, RAS/rasterizer_impl.cu:35-50, for every n >= 1)
+    uint32_t msb = 16, step = 16;
+    while (step > 1) {
+        step >>= 1;
+        msb = (n >> msb) ? msb + step : msb - step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+size_t scan_temp_bytes(int P)
+{
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P,
+                                  rocprim::plus<uint32_t>());
+    return bytes;
+}
+
+int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s)
+{
+    R2_HIP_TRY(rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)P, rocprim::plus<uint32_t>(), s));
+    return 0;
+}
+
+size_t sort_temp_bytes(size_t R)
+{
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, R, 0, 64);
+    return bytes;
+}
+
+int sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
+                       uint32_t *vout, size_t R, int end_bit, hipStream_t s)
+{
+    R2_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, R, 0u, (unsigned)end_bit, s));
+    return 0;
+}
+
+// One thread per sorted instance; a tile boundary writes the end of the previous tile's range and the
+// start of the next one.  ranges must be zeroed first (tiles with no instance keep (0,0)).
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t L,
+                                                          uint2 *__restrict__ ranges)
+{
+    const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) {
+            ranges[prev].y = idx;
+            ranges[cur].x = idx;
+        }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+int tile_ranges(const uint64_t *keys_sorted, size_t R, uint2 *ranges, size_t T, hipStream_t s)
+{
+    R2_HIP_TRY(hipMemsetAsync(ranges, 0, T * sizeof(uint2), s));
+    if (R > 0)
+        tile_ranges_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(keys_sorted, (uint32_t)R, ranges);
+    return 0;
+}
+
+}  // namespace r2
+
+extern "C" const char *r2_last_error(void) { return r2::get_error(); }
+extern "C" int r2_abi_version(void) { return R2_ABI_VERSION; }

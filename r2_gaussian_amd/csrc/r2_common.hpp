@@ -1,0 +1,74 @@
+// r2_common.hpp -- shared host/device helpers for libr2hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include "../../include/r2hip.h"
+
+namespace r2 {
+
+constexpr int TILE2D = 16;       // 16x16 pixel tiles  (reference BLOCK_X/BLOCK_Y, RAS/config.h:16-17)
+constexpr int TILE3D = 8;        // 8x8x8 voxel tiles  (reference BLOCK3D_*, VOX/config.h:16-18)
+constexpr int WAVE = 64;         // CDNA4 wavefront
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+void set_error(const char *fmt, ...);
+
+#define R2_HIP_TRY(expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess) {                                                                   \
+            r2::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return -(int)_e;                                                                      \
+        }                                                                                         \
+    } while (0)
+
+// the reference's CHECK_CUDA(A, debug): sync + check after a stage, only in debug mode
+#define R2_STAGE_CHECK(debug, stream, what)                                                      \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e == hipSuccess && (debug)) _e = hipStreamSynchronize(stream);                       \
+        if (_e != hipSuccess) {                                                                   \
+            r2::set_error("stage '%s' failed: %s", what, hipGetErrorString(_e));                  \
+            return -(int)_e;                                                                      \
+        }                                                                                         \
+    } while (0)
+
+// 128-byte aligned bump allocation inside a caller-provided chunk (reference: obtain(), RAS/rasterizer_impl.h:21-31)
+struct Bump {
+    char *base;
+    size_t off;
+    explicit Bump(char *b) : base(b), off(0) {}
+    template <typename T>
+    T *take(size_t count)
+    {
+        off = (off + 127) & ~size_t(127);
+        T *p = base ? reinterpret_cast<T *>(base + off) : nullptr;
+        off += count * sizeof(T);
+        return p;
+    }
+    size_t offset_of_next() const { return (off + 127) & ~size_t(127); }
+    size_t total() const { return off + 128; }
+};
+
+// ---- binning.hip: scan / stable radix sort / tile ranges (shared by rasterizer and voxelizer)
+size_t scan_temp_bytes(int P);
+int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s);
+size_t sort_temp_bytes(size_t R);
+int sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
+                       uint32_t *vout, size_t R, int end_bit, hipStream_t s);
+int tile_ranges(const uint64_t *keys_sorted, size_t R, uint2 *ranges, size_t T, hipStream_t s);
+uint32_t higher_msb(uint32_t n);
+
+// XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,
+// which share Gaussian records) stay on one XCD's L2 instead of being dealt round-robin over 8.
+__device__ __forceinline__ uint32_t xcd_remap(uint32_t b, uint32_t n)
+{
+    const uint32_t per = (n + 7u) >> 3;
+    const uint32_t w = (b & 7u) * per + (b >> 3);
+    return w;   // may be >= n for the ragged tail: caller checks
+}
+
+}  // namespace r2

@@ -1,0 +1,156 @@
+// raster_api.hip -- extern "C" entry points of the rasterizer (see include/r2hip.h).
+// Host orchestration of Rasterizer::forward / backward (RAS/rasterizer_impl.cu:196-421).
+#include "raster_state.hpp"
+
+using namespace r2;
+
+extern "C" int r2_raster_forward(
+    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height, const float *means3D,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered, int mode, float *out_color, int *radii, int debug, void *stream)
+{
+    (void)cam_pos;
+    (void)prefiltered;   // the reference only uses it to trap on an impossible state (RAS/auxiliary.h:160-164)
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0 || !geometryBuffer || !binningBuffer || !imageBuffer || !out_color) {
+        set_error("r2_raster_forward: invalid argument");
+        return R2_ERR_INVALID;
+    }
+    const size_t N = (size_t)width * height;
+    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
+    const size_t T = (size_t)gx * gy;
+    if (P == 0) {   // the torch boundary skips the call (SUB/rasterize_points.cu:70); out_color is pre-zeroed
+        R2_HIP_TRY(hipMemsetAsync(out_color, 0, N * sizeof(float), s));
+        return 0;
+    }
+    if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii ||
+        (!cov3D_precomp && (!scales || !rotations))) {
+        set_error("r2_raster_forward: NULL input (need means3D, opacities, matrices, radii and scales+rotations or cov3D_precomp)");
+        return R2_ERR_INVALID;
+    }
+    if (mode != 0 && mode != 1) {
+        set_error("r2_raster_forward: unsupported mode %d", mode);
+        return R2_ERR_INVALID;
+    }
+
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P).bytes, geometry_user);
+    char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N).bytes, image_user);
+    if (!gchunk || !ichunk) {
+        set_error("r2_raster_forward: state allocation callback returned NULL");
+        return R2_ERR_ALLOC;
+    }
+    const RasterGeom geom = RasterGeom::carve(gchunk, P);
+    const RasterImage img = RasterImage::carve(ichunk, T, N);
+
+    launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
+                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, s);
+    R2_STAGE_CHECK(debug, s, "preprocess");
+    int rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s);
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "scan");
+
+    // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, :279)
+    uint32_t num_rendered = 0;
+    R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipStreamSynchronize(s));
+    const size_t R = num_rendered;
+
+    char *bchunk = binningBuffer(RasterBinning::carve(nullptr, R).bytes, binning_user);
+    if (!bchunk) {
+        set_error("r2_raster_forward: binning allocation callback returned NULL");
+        return R2_ERR_ALLOC;
+    }
+    const RasterBinning bin = RasterBinning::carve(bchunk, R);
+
+    if (R > 0) {
+        launch_raster_duplicate(geom, bin, P, radii, width, height, s);
+        R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
+        const int bit = (int)higher_msb((uint32_t)T);
+        rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
+                                bin.point_list, R, 32 + bit, s);
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "sort");
+    }
+    rc = tile_ranges(bin.keys, R, img.ranges, T, s);
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "identifyTileRanges");
+    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, s);
+    R2_STAGE_CHECK(debug, s, "render");
+    return (int)num_rendered;
+}
+
+extern "C" int r2_raster_backward(
+    int P, int R, int width, int height, const float *means3D, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+    const float *campos, float tan_fovx, float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+    char *img_buffer, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dmu,
+    float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, void *stream)
+{
+    (void)campos;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (P < 0 || R < 0 || !means3D || !radii || !geom_buffer || !img_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
+        !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmu || !dL_dmean3D || !dL_dcov3D ||
+        (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
+        set_error("r2_raster_backward: invalid argument");
+        return R2_ERR_INVALID;
+    }
+    const size_t N = (size_t)width * height;
+    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
+    const RasterGeom geom = RasterGeom::carve(geom_buffer, P);
+    const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
+    const RasterImage img = RasterImage::carve(img_buffer, (size_t)gx * gy, N);
+
+    launch_raster_render_backward(geom, bin, img, width, height, (size_t)R, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity,
+                                  dL_dmu, s);
+    R2_STAGE_CHECK(debug, s, "render backward");
+    const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    launch_raster_geom_backward(P, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
+                                tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dmean3D, dL_dcov3D,
+                                dL_dscale, dL_drot, mode, s);
+    R2_STAGE_CHECK(debug, s, "geometry backward");
+    return 0;
+}
+
+extern "C" int r2_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                               uint8_t *present, void *stream)
+{
+    (void)projmatrix;
+    if (P == 0) return 0;
+    if (P < 0 || !means3D || !viewmatrix || !present) {
+        set_error("r2_mark_visible: invalid argument");
+        return R2_ERR_INVALID;
+    }
+    launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream);
+    R2_STAGE_CHECK(0, (hipStream_t)stream, "markVisible");
+    return 0;
+}
+
+extern "C" long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id)
+{
+    char *const base = reinterpret_cast<char *>(uintptr_t(1) << 40);   // fake base: only differences are used
+    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
+    const RasterGeom g = RasterGeom::carve(base, P);
+    const RasterBinning b = RasterBinning::carve(base, (size_t)R);
+    const RasterImage im = RasterImage::carve(base, (size_t)gx * gy, (size_t)width * height);
+    const char *p = nullptr;
+    int buf = -1;
+    switch (which) {
+    case 0: p = (char *)g.tiles_touched; buf = 0; break;
+    case 1: p = (char *)g.offsets; buf = 0; break;
+    case 2: p = (char *)b.keys_unsorted; buf = 1; break;
+    case 3: p = (char *)b.vals_unsorted; buf = 1; break;
+    case 4: p = (char *)b.keys; buf = 1; break;
+    case 5: p = (char *)b.point_list; buf = 1; break;
+    case 6: p = (char *)im.ranges; buf = 2; break;
+    case 7: p = (char *)g.cov3D; buf = 0; break;
+    case 8: p = (char *)im.n_contrib; buf = 2; break;
+    case 9: p = (char *)g.rec; buf = 0; break;
+    case 10: p = (char *)g.depths; buf = 0; break;
+    default: return -1;
+    }
+    if (buffer_id) *buffer_id = buf;
+    return (long long)(p - base);
+}

@@ -1,0 +1,367 @@
+// raster_geom.hip -- per-Gaussian kernels of the X-ray rasterizer (HBM-bound streams, one lane per
+// Gaussian): projection + ray-space covariance + tile rectangle (forward), key/value emission, and the
+// fused geometry backward.  Compiled with -ffp-contract=off (see r2_math.hpp).
+//
+// Reference: RAS/forward.cu:77-289, RAS/auxiliary.h:45-60,143-168, RAS/rasterizer_impl.cu:54-111,
+//            RAS/backward.cu:145-444.
+#include "r2_math.hpp"
+#include "raster_state.hpp"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace r2 {
+
+// pixel coordinate of an NDC coordinate, evaluated in double like the reference (RAS/auxiliary.h:45-48)
+__device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
+
+// tile rectangle of a square of half-width `rad` around p (RAS/auxiliary.h:50-60); float->int truncation
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
+{
+    x0 = min(gx, max(0, (int)((px - rad) / TILE2D)));
+    y0 = min(gy, max(0, (int)((py - rad) / TILE2D)));
+    x1 = min(gx, max(0, (int)((px + rad + TILE2D - 1) / TILE2D)));
+    y1 = min(gy, max(0, (int)((py + rad + TILE2D - 1) / TILE2D)));
+}
+
+struct Cov2D {
+    float tx, ty, tz;
+    float xmul, ymul;
+    M3 J, W, M, cov;
+};
+
+// t (clamped), J, W, M = W*J, cov = M^T Vrk^T M -- forward RAS/forward.cu:77-131, backward RAS/backward.cu:165-219
+__device__ __forceinline__ void cov2d_common(float3 mean, float fx, float fy, float tan_fovx, float tan_fovy,
+                                             const float *cov3D, const float *__restrict__ view, int mode, Cov2D &c)
+{
+    float3 t = xform4x3(mean, view);
+    if (mode == 0) {
+        const float limx = 1.3f, limy = 1.3f;
+        t.x = fminf(limx, fmaxf(-limx, t.x));
+        t.y = fminf(limx, fmaxf(-limx, t.y));
+        c.xmul = (t.x < -limx || t.x > limx) ? 0.f : 1.f;
+        c.ymul = (t.y < -limy || t.y > limy) ? 0.f : 1.f;
+        c.J = m3(fx, 0.0f, 0.0f, 0.0f, fy, 0.0f, 0.0f, 0.0f, 1.0f);
+    } else {
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float txtz = t.x / t.z, tytz = t.y / t.z;
+        t.x = fminf(limx, fmaxf(-limx, txtz)) * t.z;
+        t.y = fminf(limy, fmaxf(-limy, tytz)) * t.z;
+        c.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        c.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        const float l = sqrtf(t.x * t.x + t.y * t.y + t.z * t.z);
+        c.J = m3(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z), 0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z), t.x / l, t.y / l,
+                 t.z / l);
+    }
+    c.tx = t.x; c.ty = t.y; c.tz = t.z;
+    c.W = m3(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    c.M = mul(c.W, c.J);
+    const M3 Vrk = m3(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    c.cov = mul(mul(tr(c.M), tr(Vrk)), c.M);
+}
+
+__device__ __forceinline__ float mu_of(float circ, float diamond)
+{
+    // 2*M_PI is a double in the reference: the quotient is formed in double, narrowed afterwards
+    const double q = 2 * M_PI * (double)circ / (double)diamond;
+    float mu = 0.0f;
+    if ((float)q > 0.0f) mu = (float)sqrt(q);
+    return mu;
+}
+
+// ------------------------------------------------------------------ forward: one lane per Gaussian
+__global__ void __launch_bounds__(256) raster_preprocess_kernel(
+    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
+    float focal_x, float focal_y, int mode, int gx, int gy,
+    int *__restrict__ radii, float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ cov3Ds,
+    uint32_t *__restrict__ tiles_touched)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    radii[idx] = 0;
+    tiles_touched[idx] = 0;
+
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p_view = xform4x3(p, view);
+    if (p_view.z <= 0.2f) return;   // near cull (RAS/auxiliary.h:158)
+    const float4 p_hom = xform4x4(p, proj);
+    const float p_w = 1.0f / (p_hom.w + 0.0000001f);
+    const float projx = p_hom.x * p_w, projy = p_hom.y * p_w;
+
+    float cov3D[6];
+    if (cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3D[k] = cov3D_precomp[6 * idx + k];
+    } else {
+        const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+        cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q, cov3D);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];   // written even if rejected below (Q12)
+    }
+
+    Cov2D c;
+    cov2d_common(p, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, view, mode, c);
+    const float a = c.cov.m[0][0], b = c.cov.m[0][1], cc = c.cov.m[0][2];
+    const float d = c.cov.m[1][1], e = c.cov.m[1][2], f = c.cov.m[2][2];
+    const float diamond = a * d - b * b;
+    const float circ = a * d * f + 2 * b * cc * e - a * e * e - f * b * b - d * cc * cc;
+    const float mu = mu_of(circ, diamond);
+
+    const float det = (a * d - b * b);
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    const float conA = d * det_inv, conB = -b * det_inv, conC = a * det_inv;
+
+    const float mid = 0.5f * (a + d);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float px = ndc2pix(projx, W), py = ndc2pix(projy, H);
+    int x0, y0, x1, y1;
+    tile_rect(px, py, (int)my_radius, gx, gy, x0, y0, x1, y1);
+    if ((uint32_t)(x1 - x0) * (uint32_t)(y1 - y0) == 0) return;
+
+    depths[idx] = p_view.z;
+    radii[idx] = (int)my_radius;
+    tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+    // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
+    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), then opacity*mu and the two factors.
+    const float op = opacities[idx];
+    rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
+    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, op, mu);
+}
+
+// z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
+__global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means3D,
+                                                           const float *__restrict__ view, uint8_t *__restrict__ present)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    present[idx] = xform4x3(p, view).z <= 0.2f ? 0 : 1;
+}
+
+// (tile | depth) keys + Gaussian ids, emitted y-major/x-minor per Gaussian (RAS/rasterizer_impl.cu:70-111).
+// One WAVE serves 64 consecutive Gaussians: the 64 output runs are contiguous in the key array, so the
+// wave walks that span 64 instances at a time (coalesced 8-byte/4-byte stores) and each lane finds its
+// owner with a 6-step search over the lanes' exclusive offsets (ds_bpermute), instead of every lane
+// dribbling out its own run.
+__global__ void __launch_bounds__(256) raster_duplicate_kernel(
+    int P, const float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
+    const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave_first = idx - lane;
+    if (wave_first >= P) return;
+    const bool live = idx < P && radii[idx] > 0;
+    // exclusive offset of this lane's run; dead lanes get the running offset so the search stays monotone
+    uint32_t excl = 0, incl = 0;
+    if (idx < P) {
+        incl = offsets[idx];
+        excl = idx == 0 ? 0u : offsets[idx - 1];
+    } else {
+        incl = excl = offsets[P - 1];
+    }
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    uint32_t dbits = 0;
+    if (live) {
+        const float4 r0 = rec[2 * idx];
+        tile_rect(r0.x, r0.y, radii[idx], gx, gy, x0, y0, x1, y1);
+        dbits = __float_as_uint(depths[idx]);
+    }
+    const uint32_t wbeg = __shfl(excl, 0);
+    const int last_lane = min(63, P - 1 - wave_first);
+    const uint32_t wend = __shfl(incl, last_lane);
+    const int rw = x1 - x0;
+    for (uint32_t base = wbeg; base < wend; base += 64) {
+        const uint32_t k = base + lane;
+        // owner = last lane whose exclusive offset is <= k  (binary search over 64 lanes)
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int probe = lo + step;
+            const uint32_t e = __shfl(excl, probe & 63);
+            if (probe <= last_lane && e <= k) lo = probe;
+        }
+        const uint32_t o_excl = __shfl(excl, lo);
+        const int o_x0 = __shfl(x0, lo), o_y0 = __shfl(y0, lo), o_rw = __shfl(rw, lo);
+        const uint32_t o_d = __shfl(dbits, lo);
+        if (k < wend) {
+            const uint32_t local = k - o_excl;
+            const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
+            const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
+            keys[k] = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | o_d;
+            vals[k] = (uint32_t)(wave_first + lo);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ backward: fused geometry gradient
+// computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA (RAS/backward.cu:402-444) in one pass:
+// the per-Gaussian accumulators of the render backward are read once, all four output rows written once.
+// Outputs are ASSIGNED; the caller's zero-initialisation covers the rows of culled Gaussians.
+__global__ void __launch_bounds__(256) raster_geom_backward_kernel(
+    int P, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
+    const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
+    float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
+    const float *__restrict__ proj, const float *__restrict__ dL_dconics, const float *__restrict__ dL_dmus,
+    const float *__restrict__ dL_dmean2D, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
+    float *__restrict__ dL_dscale, float *__restrict__ dL_drot, int mode)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii[idx] > 0)) return;
+
+    float cov3D[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
+    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float4 gcon = reinterpret_cast<const float4 *>(dL_dconics)[idx];
+    const float gx_ = gcon.x, gy_ = gcon.y, gz_ = gcon.w;
+    const float dL_dmu = dL_dmus[idx];
+
+    Cov2D c;
+    cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, mode, c);
+    const M3 &M = c.M;
+    const M3 &Wm = c.W;
+    const float hata = c.cov.m[0][0], hatb = c.cov.m[0][1], hatc = c.cov.m[0][2];
+    const float hatd = c.cov.m[1][1], hate = c.cov.m[1][2], hatf = c.cov.m[2][2];
+
+    float da = 0, db = 0, dc = 0, dd = 0, de = 0, df = 0;
+    const float denom = hata * hatd - hatb * hatb;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    const float diamond = hata * hatd - hatb * hatb;
+    const float circ = hata * hatd * hatf + 2 * hatb * hatc * hate - hata * hate * hate - hatf * hatb * hatb - hatd * hatc * hatc;
+    const float mu = mu_of(circ, diamond);
+    const float pi_mu = (float)(M_PI / (double)(mu + 0.0000001f));
+    const float circ_diamond = circ / diamond;
+
+    float o[6] = { 0, 0, 0, 0, 0, 0 };
+    if (denom2inv != 0.0f && mu != 0.0f) {
+        da = denom2inv * (-hatd * hatd * gx_ + hatb * hatd * gy_ + (denom - hata * hatd) * gz_);
+        dd = denom2inv * (-hata * hata * gz_ + hata * hatb * gy_ + (denom - hata * hatd) * gx_);
+        db = denom2inv * (2 * hatb * hatd * gx_ - (denom + 2 * hatb * hatb) * gy_ + 2 * hata * hatb * gz_);
+
+        da += pi_mu * ((hatd * hatf - hate * hate) / diamond - hatd * circ_diamond / diamond) * dL_dmu;
+        db += pi_mu * ((2 * hatc * hate - 2 * hatf * hatb) / diamond + 2 * hatb * circ_diamond / diamond) * dL_dmu;
+        dc += pi_mu * ((2 * hatb * hate - 2 * hatd * hatc) / diamond) * dL_dmu;
+        dd += pi_mu * ((hata * hatf - hatc * hatc) / diamond - hata * circ_diamond / diamond) * dL_dmu;
+        de += pi_mu * ((2 * hatb * hatc - 2 * hata * hate) / diamond) * dL_dmu;
+        df += pi_mu * ((hata * hatd - hatb * hatb) / diamond) * dL_dmu;
+        dcov_from_dhat(M, da, db, dc, dd, de, df, o);
+    }
+    // else: all six stay 0 (Q8)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = o[k];
+
+    float3 gmean = make_float3(0.f, 0.f, 0.f);
+    if (mode == 1) {
+#define MM(c_, r_) (M.m[c_][r_])
+#define WW(c_, r_) (Wm.m[c_][r_])
+        const float a = cov3D[0], b = cov3D[1], cc = cov3D[2], d = cov3D[3], e = cov3D[4], f = cov3D[5];
+        const float dM00 = 2*(MM(0,0)*a+MM(0,1)*b + MM(0,2)*cc)*da + (MM(1,0)*a+MM(1,1)*b+MM(1,2)*cc)*db + (MM(2,0)*a+MM(2,1)*b+MM(2,2)*cc)*dc;
+        const float dM01 = 2*(MM(0,0)*b+MM(0,1)*d + MM(0,2)*e)*da + (MM(1,0)*b+MM(1,1)*d+MM(1,2)*e)*db + (MM(2,0)*b+MM(2,1)*d+MM(2,2)*e)*dc;
+        const float dM02 = 2*(MM(0,0)*cc+MM(0,1)*e + MM(0,2)*f)*da + (MM(1,0)*cc+MM(1,1)*e+MM(1,2)*f)*db + (MM(2,0)*cc+MM(2,1)*e+MM(2,2)*f)*dc;
+        const float dM10 = (MM(0,0)*a+MM(0,1)*b+MM(0,2)*cc)*db + 2*(MM(1,0)*a+MM(1,1)*b+MM(1,2)*cc)*dd + (MM(2,0)*a+MM(2,1)*b+MM(2,2)*cc)*de;
+        const float dM11 = (MM(0,0)*b+MM(0,1)*d+MM(0,2)*e)*db + 2*(MM(1,0)*b+MM(1,1)*d+MM(1,2)*e)*dd + (MM(2,0)*b+MM(2,1)*d+MM(2,2)*e)*de;
+        const float dM12 = (MM(0,0)*cc+MM(0,1)*e+MM(0,2)*f)*db + 2*(MM(1,0)*cc+MM(1,1)*e+MM(1,2)*f)*dd + (MM(2,0)*cc+MM(2,1)*e+MM(2,2)*f)*de;
+        const float dM20 = (MM(0,0)*a+MM(0,1)*b+MM(0,2)*cc)*dc + (MM(1,0)*a+MM(1,1)*b+MM(1,2)*cc)*de + 2*(MM(2,0)*a+MM(2,1)*b+MM(2,2)*cc)*df;
+        const float dM21 = (MM(0,0)*b+MM(0,1)*d+MM(0,2)*e)*dc + (MM(1,0)*b+MM(1,1)*d+MM(1,2)*e)*de + 2*(MM(2,0)*b+MM(2,1)*d+MM(2,2)*e)*df;
+        const float dM22 = (MM(0,0)*cc+MM(0,1)*e+MM(0,2)*f)*dc + (MM(1,0)*cc+MM(1,1)*e+MM(1,2)*f)*de + 2*(MM(2,0)*cc+MM(2,1)*e+MM(2,2)*f)*df;
+
+        const float dJ00 = WW(0,0)*dM00 + WW(0,1)*dM01 + WW(0,2)*dM02;
+        const float dJ02 = WW(2,0)*dM00 + WW(2,1)*dM01 + WW(2,2)*dM02;
+        const float dJ11 = WW(1,0)*dM10 + WW(1,1)*dM11 + WW(1,2)*dM12;
+        const float dJ12 = WW(2,0)*dM10 + WW(2,1)*dM11 + WW(2,2)*dM12;
+        const float dJ20 = WW(0,0)*dM20 + WW(0,1)*dM21 + WW(0,2)*dM22;
+        const float dJ21 = WW(1,0)*dM20 + WW(1,1)*dM21 + WW(1,2)*dM22;
+        const float dJ22 = WW(2,0)*dM20 + WW(2,1)*dM21 + WW(2,2)*dM22;
+#undef MM
+#undef WW
+        const float tx = c.tx, ty = c.ty, tz = c.tz;
+        const float inv_tz = 1.f / tz;
+        const float inv_tz2 = inv_tz * inv_tz;
+        const float inv_tz3 = inv_tz2 * inv_tz;
+        const float cc0 = sqrtf(tx * tx + ty * ty + tz * tz);
+        const float icc3 = 1 / (cc0 * cc0 * cc0);
+        const float dtx = c.xmul * (-h_x*inv_tz2*dJ02 + (1/cc0 - tx*tx*icc3)*dJ20 - tx*ty*icc3*dJ21 - tx*tz*icc3*dJ22);
+        const float dty = c.ymul * (-h_y*inv_tz2*dJ12 - tx*ty*icc3*dJ20 + (1/cc0 - ty*ty*icc3)*dJ21 - ty*tz*icc3*dJ22);
+        const float dtz = -h_x*inv_tz2*dJ00 + 2*h_x*tx*inv_tz3*dJ02 - h_y*inv_tz2*dJ11 + 2*h_y*ty*inv_tz3*dJ12 - tx*tz*icc3*dJ20 - ty*tz*icc3*dJ21 + (1/cc0-tz*tz*icc3)*dJ22;
+        gmean.x = view[0] * dtx + view[1] * dty + view[2] * dtz;
+        gmean.y = view[4] * dtx + view[5] * dty + view[6] * dtz;
+        gmean.z = view[8] * dtx + view[9] * dty + view[10] * dtz;
+    }
+
+    // mean gradient through the perspective divide (RAS/backward.cu:419-437)
+    const float4 m_hom = xform4x4(mean, proj);
+    const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+    const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+    const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+    const float g0 = dL_dmean2D[3 * idx], g1 = dL_dmean2D[3 * idx + 1];
+    const float ddx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
+    const float ddy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
+    const float ddz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
+    dL_dmeans[3 * idx + 0] = gmean.x + ddx;
+    dL_dmeans[3 * idx + 1] = gmean.y + ddy;
+    dL_dmeans[3 * idx + 2] = gmean.z + ddz;
+
+    if (scales != nullptr) {
+        float ds[3];
+        float4 dq;
+        cov3d_backward(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier,
+                       reinterpret_cast<const float4 *>(rotations)[idx], o, ds, &dq);
+        dL_dscale[3 * idx + 0] = ds[0];
+        dL_dscale[3 * idx + 1] = ds[1];
+        dL_dscale[3 * idx + 2] = ds[2];
+        reinterpret_cast<float4 *>(dL_drot)[idx] = dq;
+    }
+}
+
+// ------------------------------------------------------------------ host launchers
+int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
+                             const float *rotations, const float *opacities, const float *cov3D_precomp,
+                             const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
+                             int mode, int *radii, hipStream_t s)
+{
+    const float focal_y = H / (2.0f * tan_fovy);
+    const float focal_x = W / (2.0f * tan_fovx);
+    const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
+    raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depths, g.cov3D, g.tiles_touched);
+    return 0;
+}
+
+int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
+                            hipStream_t s)
+{
+    const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
+    raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.depths, g.offsets, radii, gx, gy,
+                                                                        b.keys_unsorted, b.vals_unsorted);
+    return 0;
+}
+
+int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s)
+{
+    mark_visible_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, view, present);
+    return 0;
+}
+
+int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,
+                                const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
+                                float tan_fovy, const float *view, const float *proj, const float *dL_dconic,
+                                const float *dL_dmu, const float *dL_dmean2D, float *dL_dmean3D, float *dL_dcov3D,
+                                float *dL_dscale, float *dL_drot, int mode, hipStream_t s)
+{
+    const float h_y = H / (2.0f * tan_fovy);
+    const float h_x = W / (2.0f * tan_fovx);
+    raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, dL_dconic,
+        dL_dmu, dL_dmean2D, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
+    return 0;
+}
+
+}  // namespace r2

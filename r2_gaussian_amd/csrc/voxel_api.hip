@@ -1,0 +1,146 @@
+// voxel_api.hip -- extern "C" entry points of the voxelizer (see include/r2hip.h).
+// Host orchestration of Voxelizer::forward / backward (VOX/voxelizer_impl.cu:171-389).
+#include "voxel_state.hpp"
+
+using namespace r2;
+
+static VoxelGrid make_grid(int nx, int ny, int nz, float sx, float sy, float sz, float cx, float cy, float cz)
+{
+    VoxelGrid v;
+    v.nx = nx; v.ny = ny; v.nz = nz;
+    v.sx = sx; v.sy = sy; v.sz = sz;
+    v.cx = cx; v.cy = cy; v.cz = cz;
+    v.gx = (nx + TILE3D - 1) / TILE3D;
+    v.gy = (ny + TILE3D - 1) / TILE3D;
+    v.gz = (nz + TILE3D - 1) / TILE3D;
+    return v;
+}
+
+extern "C" int r2_voxel_forward(
+    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int nVoxel_x, int nVoxel_y, int nVoxel_z, float sVoxel_x,
+    float sVoxel_y, float sVoxel_z, float center_x, float center_y, float center_z, const float *means3D,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, int prefiltered, float *out_volume, int *radii_x, int *radii_y, int *radii_z,
+    int debug, void *stream)
+{
+    (void)prefiltered;
+    hipStream_t s = (hipStream_t)stream;
+    if (P < 0 || nVoxel_x <= 0 || nVoxel_y <= 0 || nVoxel_z <= 0 || !geometryBuffer || !binningBuffer ||
+        !imageBuffer || !out_volume) {
+        set_error("r2_voxel_forward: invalid argument");
+        return R2_ERR_INVALID;
+    }
+    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
+    const size_t V = (size_t)nVoxel_x * nVoxel_y * nVoxel_z;
+    const size_t T = (size_t)v.gx * v.gy * v.gz;
+    if (P == 0) {
+        R2_HIP_TRY(hipMemsetAsync(out_volume, 0, V * sizeof(float), s));
+        return 0;
+    }
+    // The voxel radius is derived from the raw scales even when a precomputed covariance is given
+    // (VOX/forward.cu:137-143): the reference dereferences an empty tensor there; we refuse instead.
+    if (!means3D || !opacities || !radii_x || !radii_y || !radii_z || !scales || (!cov3D_precomp && !rotations)) {
+        set_error("r2_voxel_forward: NULL input (scales are required even with cov3D_precomp)");
+        return R2_ERR_INVALID;
+    }
+    char *gchunk = geometryBuffer(VoxelGeom::carve(nullptr, P).bytes, geometry_user);
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, debug != 0).bytes, image_user);
+    if (!gchunk || !ichunk) {
+        set_error("r2_voxel_forward: state allocation callback returned NULL");
+        return R2_ERR_ALLOC;
+    }
+    const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, debug != 0);
+
+    launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
+                            radii_y, radii_z, s);
+    R2_STAGE_CHECK(debug, s, "preprocess");
+    int rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s);
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "scan");
+    uint32_t num_rendered = 0;
+    R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipStreamSynchronize(s));
+    const size_t R = num_rendered;
+
+    char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
+    if (!bchunk) {
+        set_error("r2_voxel_forward: binning allocation callback returned NULL");
+        return R2_ERR_ALLOC;
+    }
+    const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
+    if (R > 0) {
+        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s);
+        R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
+        const int bit = (int)higher_msb((uint32_t)T);
+        rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
+                                bin.point_list, R, 32 + bit, s);
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "sort");
+    }
+    rc = tile_ranges(bin.keys, R, img.ranges, T, s);
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "identifyTileRanges");
+    launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s);
+    R2_STAGE_CHECK(debug, s, "render");
+    return (int)num_rendered;
+}
+
+extern "C" int r2_voxel_backward(
+    int P, int R, int nVoxel_x, int nVoxel_y, int nVoxel_z, float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z, const float *means3D, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp, const int *radii_x, const int *radii_y, const int *radii_z,
+    char *geom_buffer, char *binning_buffer, char *img_buffer, const float *dL_dvol, float *dL_dmean3D_norm,
+    float *dL_dconic3D, float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
+    int debug, void *stream)
+{
+    (void)means3D;
+    (void)img_buffer;
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 0) return 0;
+    if (P < 0 || R < 0 || !radii_x || !radii_y || !radii_z || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dvol ||
+        !dL_dmean3D_norm || !dL_dconic3D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D ||
+        (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
+        set_error("r2_voxel_backward: invalid argument");
+        return R2_ERR_INVALID;
+    }
+    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
+    const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
+    const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
+    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, dL_dmean3D_norm, dL_dconic3D, dL_dopacity, s);
+    R2_STAGE_CHECK(debug, s, "render backward");
+    const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    launch_voxel_geom_backward(v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
+                               cov3D_precomp ? nullptr : rotations, scale_modifier, dL_dconic3D, dL_dmean3D_norm,
+                               dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s);
+    R2_STAGE_CHECK(debug, s, "geometry backward");
+    return 0;
+}
+
+extern "C" long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id)
+{
+    char *const base = reinterpret_cast<char *>(uintptr_t(1) << 40);
+    const VoxelGrid v = make_grid(nx, ny, nz, 1, 1, 1, 0, 0, 0);
+    const VoxelGeom g = VoxelGeom::carve(base, P);
+    const VoxelBinning b = VoxelBinning::carve(base, (size_t)R);
+    const VoxelImage im = VoxelImage::carve(base, (size_t)v.gx * v.gy * v.gz, (size_t)nx * ny * nz, true);
+    const char *p = nullptr;
+    int buf = -1;
+    switch (which) {
+    case 0: p = (char *)g.tiles_touched; buf = 0; break;
+    case 1: p = (char *)g.offsets; buf = 0; break;
+    case 2: p = (char *)b.keys_unsorted; buf = 1; break;
+    case 3: p = (char *)b.vals_unsorted; buf = 1; break;
+    case 4: p = (char *)b.keys; buf = 1; break;
+    case 5: p = (char *)b.point_list; buf = 1; break;
+    case 6: p = (char *)im.ranges; buf = 2; break;
+    case 7: p = (char *)g.cov3D; buf = 0; break;
+    case 8: p = (char *)im.n_contrib; buf = 2; break;
+    case 9: p = (char *)g.rec; buf = 0; break;
+    case 10: p = (char *)g.depths; buf = 0; break;
+    default: return -1;
+    }
+    if (buffer_id) *buffer_id = buf;
+    return (long long)(p - base);
+}

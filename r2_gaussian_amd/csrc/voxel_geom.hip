@@ -1,0 +1,242 @@
+// voxel_geom.hip -- per-Gaussian kernels of the 3D voxelizer: voxel-space inverse covariance + tile cube
+// (forward), key/value emission, fused geometry backward.  Compiled with -ffp-contract=off (r2_math.hpp).
+//
+// Reference: VOX/forward.cu:58-178, VOX/auxiliary.h:27-39, VOX/voxelizer_impl.cu:54-101,
+//            VOX/backward.cu:86-213.
+#include "r2_math.hpp"
+#include "voxel_state.hpp"
+
+namespace r2 {
+
+// tile cube of a box of half-widths rad around p (VOX/auxiliary.h:27-39), float->int truncation
+__device__ __forceinline__ void tile_cube(float3 p, float3 rad, int gx, int gy, int gz, int3 &lo, int3 &hi)
+{
+    lo.x = min(gx, max(0, (int)((p.x - rad.x) / TILE3D)));
+    lo.y = min(gy, max(0, (int)((p.y - rad.y) / TILE3D)));
+    lo.z = min(gz, max(0, (int)((p.z - rad.z) / TILE3D)));
+    hi.x = min(gx, max(0, (int)((p.x + rad.x + TILE3D - 1) / TILE3D)));
+    hi.y = min(gy, max(0, (int)((p.y + rad.y + TILE3D - 1) / TILE3D)));
+    hi.z = min(gz, max(0, (int)((p.z + rad.z + TILE3D - 1) / TILE3D)));
+}
+
+// cov = M^T Vrk^T M with M = diag(1/dVoxel)  (VOX/forward.cu:110-118)
+__device__ __forceinline__ void voxel_cov(const float *cov3D, float dvx, float dvy, float dvz, M3 &M, float *h)
+{
+    const M3 Vrk = m3(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    M = m3(1.f / dvx, 0.0f, 0.0f, 0.0f, 1.f / dvy, 0.0f, 0.0f, 0.0f, 1.f / dvz);
+    const M3 cov = mul(mul(tr(M), tr(Vrk)), M);
+    h[0] = cov.m[0][0]; h[1] = cov.m[0][1]; h[2] = cov.m[0][2];
+    h[3] = cov.m[1][1]; h[4] = cov.m[1][2]; h[5] = cov.m[2][2];
+}
+
+__global__ void __launch_bounds__(256) voxel_preprocess_kernel(
+    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
+    float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ cov3Ds,
+    uint32_t *__restrict__ tiles_touched)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P) return;
+    radii_x[idx] = 0;
+    radii_y[idx] = 0;
+    radii_z[idx] = 0;
+    tiles_touched[idx] = 0;
+    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+
+    float cov3D[6];
+    if (cov3D_precomp != nullptr) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3D[k] = cov3D_precomp[6 * idx + k];
+    } else {
+        const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
+        cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q, cov3D);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];
+    }
+    M3 M;
+    float h[6];
+    voxel_cov(cov3D, dvx, dvy, dvz, M, h);
+    const float a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
+    const float det = a * d * f + 2 * b * c * e - a * e * e - f * b * b - d * c * c;
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    const float inv_a = (d * f - e * e) * det_inv;
+    const float inv_b = (c * e - b * f) * det_inv;
+    const float inv_c = (b * e - c * d) * det_inv;
+    const float inv_d = (a * f - c * c) * det_inv;
+    const float inv_e = (b * c - a * e) * det_inv;
+    const float inv_f = (a * d - b * b) * det_inv;
+
+    // radius from the RAW scales, no scale_modifier (reference quirk Q5, VOX/forward.cu:137-143)
+    const float max_scale = fmaxf(fmaxf(scales[3 * idx], scales[3 * idx + 1]), scales[3 * idx + 2]);
+    const float3 rad = make_float3(ceilf((3.f * max_scale) / dvx), ceilf((3.f * max_scale) / dvy),
+                                   ceilf((3.f * max_scale) / dvz));
+    const float3 pv = make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy,
+                                  (p.z - v.cz + v.sz / 2) / dvz);
+    if (pv.x + rad.x < 0 || pv.y + rad.y < 0 || pv.z + rad.z < 0 || pv.x - rad.x > (float)v.nx ||
+        pv.y - rad.y > (float)v.ny || pv.z - rad.z > (float)v.nz)
+        return;
+    int3 lo, hi;
+    tile_cube(pv, rad, v.gx, v.gy, v.gz, lo, hi);
+    const uint32_t n = (uint32_t)(hi.x - lo.x) * (uint32_t)(hi.y - lo.y) * (uint32_t)(hi.z - lo.z);
+    if (n == 0) return;
+
+    radii_x[idx] = (int)rad.x;
+    radii_y[idx] = (int)rad.y;
+    radii_z[idx] = (int)rad.z;
+    tiles_touched[idx] = n;
+    depths[idx] = p.z;
+    rec[3 * idx] = make_float4(pv.x, pv.y, pv.z, opacities[idx]);
+    rec[3 * idx + 1] = make_float4((-0.5f * LOG2E) * inv_a, (-LOG2E) * inv_b, (-LOG2E) * inv_c, (-0.5f * LOG2E) * inv_d);
+    rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, 0.f, 0.f);
+}
+
+// (tile | depth) keys, z-major / y / x-minor per Gaussian (VOX/voxelizer_impl.cu:54-101); one wave serves
+// 64 consecutive Gaussians and walks their contiguous output span with coalesced stores (see raster_geom.hip).
+__global__ void __launch_bounds__(256) voxel_duplicate_kernel(
+    int P, const float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
+    const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
+    int gz, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave_first = idx - lane;
+    if (wave_first >= P) return;
+    const bool live = idx < P && radii_x[idx] > 0 && radii_y[idx] > 0 && radii_z[idx] > 0;
+    uint32_t excl, incl;
+    if (idx < P) {
+        incl = offsets[idx];
+        excl = idx == 0 ? 0u : offsets[idx - 1];
+    } else {
+        incl = excl = offsets[P - 1];
+    }
+    int3 lo = make_int3(0, 0, 0), hi = lo;
+    uint32_t dbits = 0;
+    if (live) {
+        const float4 r0 = rec[3 * idx];
+        tile_cube(make_float3(r0.x, r0.y, r0.z),
+                  make_float3((float)radii_x[idx], (float)radii_y[idx], (float)radii_z[idx]), gx, gy, gz, lo, hi);
+        dbits = __float_as_uint(depths[idx]);
+    }
+    const uint32_t wbeg = __shfl(excl, 0);
+    const int last_lane = min(63, P - 1 - wave_first);
+    const uint32_t wend = __shfl(incl, last_lane);
+    const int rw = hi.x - lo.x, rh = hi.y - lo.y;
+    for (uint32_t base = wbeg; base < wend; base += 64) {
+        const uint32_t k = base + lane;
+        int own = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int probe = own + step;
+            const uint32_t e = __shfl(excl, probe & 63);
+            if (probe <= last_lane && e <= k) own = probe;
+        }
+        const uint32_t o_excl = __shfl(excl, own);
+        const int ox = __shfl(lo.x, own), oy = __shfl(lo.y, own), oz = __shfl(lo.z, own);
+        const int orw = __shfl(rw, own), orh = __shfl(rh, own);
+        const uint32_t o_d = __shfl(dbits, own);
+        if (k < wend) {
+            const uint32_t local = k - o_excl;
+            const uint32_t xy = (uint32_t)orw * (uint32_t)orh;
+            const int z = oz + (int)(local / xy);
+            const uint32_t rem = local % xy;
+            const int y = oy + (int)(rem / (uint32_t)orw);
+            const int x = ox + (int)(rem % (uint32_t)orw);
+            keys[k] = ((uint64_t)(uint32_t)(z * gy * gx + y * gx + x) << 32) | o_d;
+            vals[k] = (uint32_t)(wave_first + own);
+        }
+    }
+}
+
+// computeCov3DCUDA (VOX/backward.cu:86-177) + preprocessCUDA backward (VOX/backward.cu:180-213), fused.
+__global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
+    int P, const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
+    const float *__restrict__ cov3Ds, const float *__restrict__ scales, const float *__restrict__ rotations,
+    float scale_modifier, VoxelGrid v, const float *__restrict__ dL_dconic3D, const float *__restrict__ dL_dmean3D_norm,
+    float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov, float *__restrict__ dL_dscale,
+    float *__restrict__ dL_drot)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || !(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) return;
+    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    float cov3D[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
+    const float ga = dL_dconic3D[6 * idx + 0], gb = dL_dconic3D[6 * idx + 1], gc = dL_dconic3D[6 * idx + 2];
+    const float gd = dL_dconic3D[6 * idx + 3], ge = dL_dconic3D[6 * idx + 4], gf = dL_dconic3D[6 * idx + 5];
+    M3 M;
+    float h[6];
+    voxel_cov(cov3D, dvx, dvy, dvz, M, h);
+    const float hata = h[0], hatb = h[1], hatc = h[2], hatd = h[3], hate = h[4], hatf = h[5];
+    const float denom = hata * hatd * hatf + 2 * hatb * hatc * hate - hata * hate * hate - hatf * hatb * hatb - hatd * hatc * hatc;
+    const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+    float o[6] = { 0, 0, 0, 0, 0, 0 };
+    if (denom2inv != 0) {
+        const float denom_da = hatd * hatf - hate * hate;
+        const float denom_db = 2 * hatc * hate - 2 * hatf * hatb;
+        const float denom_dc = 2 * hatb * hate - 2 * hatd * hatc;
+        const float denom_dd = hata * hatf - hatc * hatc;
+        const float denom_de = 2 * hatb * hatc - 2 * hata * hate;
+        const float denom_df = hata * hatd - hatb * hatb;
+        const float ce_bf = hatc * hate - hatb * hatf;
+        const float be_cd = hatb * hate - hatc * hatd;
+        const float bc_ae = hatb * hatc - hata * hate;
+        const float da = denom2inv * (-denom_da*denom_da*ga - ce_bf*denom_da*gb - be_cd*denom_da*gc + (hatf*denom-denom_dd*denom_da)*gd + (-hate*denom-bc_ae*denom_da)*ge + (hatd*denom-denom_df*denom_da)*gf);
+        const float db = denom2inv * (-denom_da*denom_db*ga + (-hatf*denom-ce_bf*denom_db)*gb + (hate*denom-be_cd*denom_db)*gc - denom_dd*denom_db*gd + (hatc*denom-bc_ae*denom_db)*ge + (-2*hatb*denom-denom_df*denom_db)*gf);
+        const float dc = denom2inv * (-denom_da*denom_dc*ga + (hate*denom-ce_bf*denom_dc)*gb + (-hatd*denom-be_cd*denom_dc)*gc + (-2*hatc*denom-denom_dd*denom_dc)*gd + (hatb*denom-bc_ae*denom_dc)*ge - denom_df*denom_dc*gf);
+        const float dd = denom2inv * ((hatf*denom-denom_da*denom_dd)*ga - ce_bf*denom_dd*gb +(-hatc*denom-be_cd*denom_dd)*gc - denom_dd*denom_dd*gd - bc_ae*denom_dd*ge + (hata*denom-denom_df*denom_dd)*gf);
+        const float de = denom2inv * ((-2*hate*denom-denom_da*denom_de)*ga + (hatc*denom-ce_bf*denom_de)*gb + (hatb*denom-be_cd*denom_de)*gc - denom_dd*denom_de*gd + (-hata*denom-bc_ae*denom_de)*ge + -denom_df*denom_de*gf);
+        const float df = denom2inv * ((hatd*denom-denom_da*denom_df)*ga + (-hatb*denom-ce_bf*denom_df)*gb - be_cd*denom_df*gc + (hata*denom-denom_dd*denom_df)*gd - bc_ae*denom_df*ge - denom_df*denom_df*gf);
+        dcov_from_dhat(M, da, db, dc, dd, de, df, o);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = o[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) dL_dmeans[3 * idx + k] = dL_dmean3D_norm[3 * idx + k];   // zero-init + "+=" in the reference
+    if (scales != nullptr && rotations != nullptr) {
+        float ds[3];
+        float4 dq;
+        cov3d_backward(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier,
+                       reinterpret_cast<const float4 *>(rotations)[idx], o, ds, &dq);
+        dL_dscale[3 * idx + 0] = ds[0];
+        dL_dscale[3 * idx + 1] = ds[1];
+        dL_dscale[3 * idx + 2] = ds[2];
+        reinterpret_cast<float4 *>(dL_drot)[idx] = dq;
+    }
+}
+
+int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
+                            float scale_modifier, const float *rotations, const float *opacities,
+                            const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, hipStream_t s)
+{
+    voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
+                                                                        opacities, cov3D_precomp, v, radii_x, radii_y,
+                                                                        radii_z, g.rec, g.depths, g.cov3D,
+                                                                        g.tiles_touched);
+    return 0;
+}
+
+int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
+                           const int *radii_y, const int *radii_z, hipStream_t s)
+{
+    voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.depths, g.offsets, radii_x, radii_y,
+                                                                       radii_z, v.gx, v.gy, v.gz, b.keys_unsorted,
+                                                                       b.vals_unsorted);
+    return 0;
+}
+
+int launch_voxel_geom_backward(const VoxelGrid &v, int P, const int *radii_x, const int *radii_y, const int *radii_z,
+                               const float *cov3D, const float *scales, const float *rotations, float scale_modifier,
+                               const float *dL_dconic3D, const float *dL_dmean3D_norm, float *dL_dmean3D,
+                               float *dL_dcov3D, float *dL_dscale, float *dL_drot, hipStream_t s)
+{
+    voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, radii_x, radii_y, radii_z, cov3D, scales,
+                                                                           rotations, scale_modifier, v, dL_dconic3D,
+                                                                           dL_dmean3D_norm, dL_dmean3D, dL_dcov3D,
+                                                                           dL_dscale, dL_drot);
+    return 0;
+}
+
+}  // namespace r2

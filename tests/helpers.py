@@ -1,0 +1,167 @@
+"""Shared scenario builders and state readers for the parity tests."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from r2_gaussian_amd import scene as S
+
+LOG2E = 1.4426950408889634
+
+
+def np_view(v):
+    return v.world_view_transform.numpy(), v.full_proj_transform.numpy()
+
+
+def cloud_np(c):
+    return c.xyz.numpy(), c.density.numpy(), c.scales.numpy(), c.rotations.numpy()
+
+
+def oracle_raster(O, c, v, cov3D_precomp=None, scale_modifier=1.0, render=True):
+    xyz, rho, sc, q = cloud_np(c)
+    vm, pm = np_view(v)
+    if cov3D_precomp is not None:
+        sc, q = None, None
+    return O.raster_forward(xyz, rho, sc, q, scale_modifier, cov3D_precomp, vm, pm, v.tanfovx, v.tanfovy,
+                            v.image_height, v.image_width, v.mode, render=render)
+
+
+def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
+    """Run the HIP forward through the `_C` mirror and read every private intermediate back."""
+    from r2_gaussian_amd import _C, _lib
+    e = torch.empty(0)
+    sc, q = (c.scales.to(dev), c.rotations.to(dev)) if cov3D_precomp is None else (e, e)
+    cp = e if cov3D_precomp is None else torch.as_tensor(cov3D_precomp).to(dev)
+    args = (c.xyz.to(dev), c.density.to(dev), sc, q, scale_modifier, cp, v.world_view_transform.to(dev),
+            v.full_proj_transform.to(dev), v.tanfovx, v.tanfovy, v.image_height, v.image_width,
+            v.camera_center.to(dev), False, v.mode, debug)
+    R, color, radii, geom, binning, img = _C.rasterize_gaussians(*args)
+    torch.cuda.synchronize()
+    P, H, W = c.xyz.shape[0], v.image_height, v.image_width
+    out = dict(num_rendered=R, color=color.cpu().numpy(), radii=radii.cpu().numpy(), bufs=(geom, binning, img),
+               args=args)
+    if P == 0:
+        return out
+    bufs = [geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()]
+    L = _lib.lib()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def read(which, dtype, count):
+        bid = C.c_int(-1)
+        off = L.r2_raster_state_offset(which, P, R, W, H, C.byref(bid))
+        assert off >= 0
+        nbytes = np.dtype(dtype).itemsize * count
+        return bufs[bid.value][off:off + nbytes].view(dtype).copy()
+
+    out["tiles_touched"] = read(0, np.uint32, P)
+    out["offsets"] = read(1, np.uint32, P)
+    out["keys_unsorted"] = read(2, np.uint64, R)
+    out["vals_unsorted"] = read(3, np.uint32, R)
+    out["keys"] = read(4, np.uint64, R)
+    out["point_list"] = read(5, np.uint32, R)
+    out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
+    out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
+    if debug:
+        out["n_contrib"] = read(8, np.uint32, H * W)
+    rec = read(9, np.float32, 8 * P).reshape(P, 8)
+    out["rec"] = rec
+    out["depths"] = read(10, np.float32, P)
+    # decode the packed render record back to the reference's quantities
+    out["means2D"] = rec[:, 0:2]
+    out["conic"] = np.stack([rec[:, 2] / (-0.5 * LOG2E), rec[:, 3] / (-LOG2E), rec[:, 4] / (-0.5 * LOG2E)], 1)
+    out["mus"] = rec[:, 7]
+    out["opacity"] = rec[:, 6]
+    return out
+
+
+def hip_raster_backward(h, c, v, dL, dev):
+    from r2_gaussian_amd import _C
+    a = h["args"]
+    geom, binning, img = h["bufs"]
+    radii = torch.as_tensor(h["radii"]).to(dev)
+    res = _C.rasterize_gaussians_backward(a[0], radii, a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9],
+                                          torch.as_tensor(dL).to(dev), a[12], geom, h["num_rendered"], binning, img,
+                                          v.mode, False)
+    torch.cuda.synchronize()
+    names = ["dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"]
+    return {n: t.cpu().numpy() for n, t in zip(names, res)}
+
+
+def oracle_voxel(O, c, nVoxel, sVoxel, center, scale_modifier=1.0, render=True):
+    xyz, rho, sc, q = cloud_np(c)
+    return O.voxel_forward(xyz, rho, sc, q, scale_modifier, None, nVoxel, sVoxel, center, render=render)
+
+
+def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
+    from r2_gaussian_amd import _C, _lib
+    e = torch.empty(0)
+    args = (c.xyz.to(dev), c.density.to(dev), c.scales.to(dev), c.rotations.to(dev), scale_modifier, e,
+            nVoxel[0], nVoxel[1], nVoxel[2], sVoxel[0], sVoxel[1], sVoxel[2], center[0], center[1], center[2],
+            False, debug)
+    R, vol, rx, ry, rz, geom, binning, img = _C.voxelize_gaussians(*args)
+    torch.cuda.synchronize()
+    P = c.xyz.shape[0]
+    nx, ny, nz = nVoxel
+    out = dict(num_rendered=R, vol=vol.cpu().numpy(), radii_x=rx.cpu().numpy(), radii_y=ry.cpu().numpy(),
+               radii_z=rz.cpu().numpy(), bufs=(geom, binning, img), args=args, radii_t=(rx, ry, rz))
+    if P == 0:
+        return out
+    bufs = [geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()]
+    L = _lib.lib()
+    T = ((nx + 7) // 8) * ((ny + 7) // 8) * ((nz + 7) // 8)
+
+    def read(which, dtype, count):
+        bid = C.c_int(-1)
+        off = L.r2_voxel_state_offset(which, P, R, nx, ny, nz, C.byref(bid))
+        assert off >= 0
+        nbytes = np.dtype(dtype).itemsize * count
+        return bufs[bid.value][off:off + nbytes].view(dtype).copy()
+
+    out["tiles_touched"] = read(0, np.uint32, P)
+    out["offsets"] = read(1, np.uint32, P)
+    out["keys_unsorted"] = read(2, np.uint64, R)
+    out["vals_unsorted"] = read(3, np.uint32, R)
+    out["keys"] = read(4, np.uint64, R)
+    out["point_list"] = read(5, np.uint32, R)
+    out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
+    out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
+    if debug:
+        out["n_contrib"] = read(8, np.uint32, nx * ny * nz)
+    rec = read(9, np.float32, 12 * P).reshape(P, 12)
+    out["rec"] = rec
+    out["means3D_norm"] = rec[:, 0:3]
+    sc = np.array([-0.5 * LOG2E, -LOG2E, -LOG2E, -0.5 * LOG2E, -LOG2E, -0.5 * LOG2E], np.float32)
+    out["conic"] = rec[:, 4:10] / sc
+    return out
+
+
+def hip_voxel_backward(h, c, nVoxel, sVoxel, center, dL, dev):
+    from r2_gaussian_amd import _C
+    a = h["args"]
+    geom, binning, img = h["bufs"]
+    rx, ry, rz = h["radii_t"]
+    res = _C.voxelize_gaussians_backward(a[0], rx, ry, rz, a[2], a[3], a[4], a[5], torch.as_tensor(dL).to(dev),
+                                         geom, h["num_rendered"], binning, img, nVoxel[0], nVoxel[1], nVoxel[2],
+                                         sVoxel[0], sVoxel[1], sVoxel[2], center[0], center[1], center[2], False)
+    torch.cuda.synchronize()
+    names = ["dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"]
+    return {n: t.cpu().numpy() for n, t in zip(names, res)}
+
+
+def assert_close_scaled(a, b, rtol, name, atol_frac=1e-6):
+    """|a-b| <= rtol*|b| + atol_frac*max|b| elementwise; reports the worst offender."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (name, a.shape, b.shape)
+    scale = np.abs(b).max() if b.size else 0.0
+    err = np.abs(a - b)
+    tol = rtol * np.abs(b) + atol_frac * scale
+    bad = err > tol
+    if bad.any():
+        i = np.argmax(err - tol)
+        raise AssertionError("%s: %d/%d out of tolerance; worst |a-b|=%.3e at %s (a=%.6e b=%.6e, scale=%.3e)" % (
+            name, bad.sum(), bad.size, err.flat[i], np.unravel_index(i, a.shape), a.flat[i], b.flat[i], scale))
+
+
+def ellipsoid_cloud(P, seed=0, scale_mult=1.0):
+    return S.make_cloud(P, seed=seed, scale_mult=scale_mult)

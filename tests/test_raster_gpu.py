@@ -1,0 +1,192 @@
+"""GPU parity of the rasterizer: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bar (BASELINE.json north_star): tile / sort indices bit-exact; rendered projections within 1e-4 relative;
+gradients compared against the oracle's double-accumulated sums (the reference itself accumulates with
+order-nondeterministic float atomics).
+"""
+import numpy as np
+import pytest
+import torch
+
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+# (P, H, W, scanner, angle, scale_mult)
+CASES = [
+    (5000, 64, 64, S.CONE_BEAM, 0.3, 1.0),          # BASELINE config A geometry
+    (3000, 50, 70, S.CONE_BEAM, 2.1, 1.5),          # ragged: W,H not multiples of 16
+    (4000, 96, 80, S.PARALLEL_BEAM, 1.0, 1.0),      # parallel beam (mode 0)
+    (50000, 512, 512, S.CONE_BEAM, 0.7, 1.0),       # BASELINE config B
+]
+IDS = ["A_5k_64", "ragged_50x70", "parallel_96x80", "B_50k_512"]
+
+
+def _case(case):
+    P, H, W, scanner, angle, sm = case
+    c = S.make_cloud(P, seed=P % 97, scanner=scanner, scale_mult=sm)
+    v = S.make_view(angle, (H, W), scanner)
+    return c, v
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_indices_bit_exact(case, oracle, gpu):
+    c, v = _case(case)
+    o = Hh.oracle_raster(oracle, c, v, render=False)
+    h = Hh.hip_raster(c, v, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    for k in ("radii", "tiles_touched", "offsets", "keys_unsorted", "vals_unsorted", "keys", "point_list", "ranges"):
+        assert np.array_equal(h[k], o[k]), "%s differs (%d mismatches)" % (k, int((h[k] != o[k]).sum()))
+    # values feeding the indices are bit-exact too (same op order, no contraction)
+    assert np.array_equal(h["cov3D"].view(np.uint32), o["cov3D"].view(np.uint32))
+    vis = o["radii"] > 0
+    assert np.array_equal(h["means2D"][vis].view(np.uint32), o["means2D"][vis].view(np.uint32))
+    assert np.array_equal(h["depths"][vis].view(np.uint32), o["depths"][vis].view(np.uint32))
+    assert np.array_equal(h["mus"][vis].view(np.uint32), o["mus"][vis].view(np.uint32))
+    np.testing.assert_allclose(h["conic"][vis], o["conic_opacity"][vis, :3], rtol=3e-7, atol=0)
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_projection_within_1e4(case, oracle, gpu):
+    c, v = _case(case)
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    ref = o["color"]
+    err = np.abs(h["color"] - ref)
+    # 1e-4 relative; the absolute floor covers pairs whose alpha sits on the 1e-5 cut-off, where a 1-ulp
+    # difference in exp() flips the test (each flip moves a pixel by < 1e-5)
+    tol = 1e-4 * np.abs(ref) + 2e-5
+    assert (err <= tol).all(), "max err %.3e (ref %.3e)" % (err.max(), ref.flat[err.argmax()])
+    assert ref.max() > 0.05
+
+
+@pytest.mark.parametrize("case", CASES[:3], ids=IDS[:3])
+def test_n_contrib_debug_mode(case, oracle, gpu):
+    c, v = _case(case)
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu, debug=True)
+    mism = (h["n_contrib"] != o["n_contrib"]).mean()
+    assert mism < 2e-3, "n_contrib mismatch fraction %.4f" % mism   # only cut-off flips may differ
+
+
+@pytest.mark.parametrize("case", CASES, ids=IDS)
+def test_backward_vs_oracle(case, oracle, gpu):
+    c, v = _case(case)
+    H, W = v.image_height, v.image_width
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    dL = S.make_pixel_grad(H, W).numpy()
+    xyz, rho, sc, q = Hh.cloud_np(c)
+    vm, pm = Hh.np_view(v)
+    go = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        # the covariance chain (1/det^2 factors) amplifies last-bit differences of the accumulated sums
+        af = 2e-4 if k in ("dL_dcov3D", "dL_dscales", "dL_drotations") else 2e-5
+        Hh.assert_close_scaled(gh[k], go[k].reshape(gh[k].shape), rtol=2e-3, name=k, atol_frac=af)
+
+
+def test_backward_float_oracle_consistency(oracle, gpu):
+    """The float-accumulating oracle (reference-faithful atomics emulation) and the HIP path must both sit
+    within float-accumulation noise of the double-accumulated truth."""
+    c, v = _case(CASES[0])
+    o = Hh.oracle_raster(oracle, c, v)
+    dL = S.make_pixel_grad(64, 64).numpy()
+    xyz, rho, sc, q = Hh.cloud_np(c)
+    vm, pm = Hh.np_view(v)
+    g64 = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
+    g32 = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=False)
+    h = Hh.hip_raster(c, v, gpu)
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    for k in ("dL_dmeans3D", "dL_dscales", "dL_drotations", "dL_dopacity"):
+        s = np.abs(g64[k]).max()
+        e32 = np.abs(g32[k] - g64[k]).max() / s
+        eh = np.abs(gh[k] - g64[k].reshape(gh[k].shape)).max() / s
+        assert eh < max(20 * e32, 5e-5), (k, eh, e32)
+
+
+def test_cov3d_precomp_path(oracle, gpu):
+    c, v = _case(CASES[0])
+    cov = oracle.cov3d(c.scales.numpy(), 1.0, c.rotations.numpy())
+    o = Hh.oracle_raster(oracle, c, v, cov3D_precomp=cov)
+    h = Hh.hip_raster(c, v, gpu, cov3D_precomp=cov)
+    for k in ("radii", "point_list", "ranges"):
+        assert np.array_equal(h[k], o[k])
+    dL = S.make_pixel_grad(64, 64).numpy()
+    vm, pm = Hh.np_view(v)
+    go = oracle.raster_backward(o, c.xyz.numpy(), None, None, 1.0, cov, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    Hh.assert_close_scaled(gh["dL_dcov3D"], go["dL_dcov3D"], rtol=2e-3, name="dL_dcov3D", atol_frac=2e-5)
+    Hh.assert_close_scaled(gh["dL_dmeans3D"], go["dL_dmeans3D"], rtol=2e-3, name="dL_dmeans3D", atol_frac=2e-5)
+    assert not gh["dL_dscales"].any() and not gh["dL_drotations"].any()
+
+
+def test_scale_modifier(oracle, gpu):
+    c, v = _case(CASES[0])
+    o = Hh.oracle_raster(oracle, c, v, scale_modifier=1.7)
+    h = Hh.hip_raster(c, v, gpu, scale_modifier=1.7)
+    assert np.array_equal(h["radii"], o["radii"]) and np.array_equal(h["point_list"], o["point_list"])
+    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+
+
+def test_empty_and_culled(oracle, gpu):
+    from r2_gaussian_amd import _C
+    v = S.make_view(0.0, (64, 64))
+    e = torch.empty(0)
+    # P == 0
+    z3 = torch.zeros((0, 3), device=gpu)
+    R, color, radii, g, b, i = _C.rasterize_gaussians(
+        z3, torch.zeros((0, 1), device=gpu), torch.zeros((0, 3), device=gpu), torch.zeros((0, 4), device=gpu), 1.0, e,
+        v.world_view_transform.to(gpu), v.full_proj_transform.to(gpu), v.tanfovx, v.tanfovy, 64, 64,
+        v.camera_center.to(gpu), False, 1, False)
+    assert R == 0 and color.shape == (1, 64, 64) and not color.any() and radii.numel() == 0
+    assert g.numel() == 0 and b.numel() == 0 and i.numel() == 0
+    # every Gaussian behind the source (z_view <= 0.2) -> num_rendered 0, zero image, radii 0
+    c = S.make_cloud(500, seed=3)
+    far = S.Cloud(c.xyz * 0.01 + torch.tensor([20.0, 0.0, 0.0]), c.scales, c.rotations, c.density)
+    o = Hh.oracle_raster(oracle, far, v)
+    h = Hh.hip_raster(far, v, gpu)
+    assert o["num_rendered"] == 0 and h["num_rendered"] == 0
+    assert not h["color"].any() and not h["radii"].any()
+    gh = Hh.hip_raster_backward(h, far, v, S.make_pixel_grad(64, 64).numpy(), gpu)
+    assert all(not x.any() for x in gh.values())
+
+
+def test_single_gaussian_kat(oracle, gpu):
+    """One isotropic Gaussian at the isocentre: the centre-pixel line integral is rho*sqrt(2 pi)*sigma
+    (the disabled one-Gaussian debug scene of r2_gaussian/gaussian/gaussian_model.py:166-186)."""
+    v = S.make_view(0.3, (65, 65))   # odd size: the centre pixel sits exactly on the projected mean
+    c = S.Cloud(torch.zeros(1, 3), torch.full((1, 3), 0.1), torch.tensor([[1.0, 0, 0, 0]]), torch.tensor([[0.8]]))
+    h = Hh.hip_raster(c, v, gpu)
+    assert abs(h["color"][0, 32, 32] - 0.8 * np.sqrt(2 * np.pi) * 0.1) < 2e-5
+    o = Hh.oracle_raster(oracle, c, v)
+    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+
+
+def test_huge_and_tied_gaussians(oracle, gpu):
+    """A Gaussian covering every tile, exact duplicates (equal depth keys -> stable ties), degenerate scale."""
+    v = S.make_view(1.3, (96, 96))
+    c = S.make_cloud(300, seed=11)
+    xyz = c.xyz.clone(); sc = c.scales.clone(); q = c.rotations.clone(); rho = c.density.clone()
+    sc[0] = 0.45                      # 3 sigma >> detector: touches all 36 tiles
+    xyz[10:20] = xyz[10]              # ten identical centres: identical depth bits
+    sc[10:20] = sc[10]; q[10:20] = q[10]
+    sc[30] = torch.tensor([1e-6, 1e-6, 1e-6])   # sub-pixel: radius floor sqrt(0.1) path
+    cl = S.Cloud(xyz, sc, q, rho)
+    o = Hh.oracle_raster(oracle, cl, v)
+    h = Hh.hip_raster(cl, v, gpu)
+    assert o["tiles_touched"][0] == 36
+    for k in ("radii", "tiles_touched", "keys", "point_list", "ranges"):
+        assert np.array_equal(h[k], o[k]), k
+    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+
+
+def test_mark_visible(oracle, gpu):
+    from r2_gaussian_amd import _C
+    v = S.make_view(0.9, (64, 64))
+    c = S.make_cloud(2000, seed=5)
+    xyz = c.xyz * 8.0   # spread so that some points fall behind the near plane
+    vis = _C.mark_visible(xyz.to(gpu), v.world_view_transform.to(gpu), v.full_proj_transform.to(gpu)).cpu().numpy()
+    ref = oracle.mark_visible(xyz.numpy(), *Hh.np_view(v))
+    assert np.array_equal(vis, ref) and 0 < ref.sum() < ref.size
