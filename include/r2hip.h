@@ -88,7 +88,7 @@ R2_API int r2_raster_backward(
     char *geom_buffer, char *binning_buffer, char *img_buffer,
     const float *dL_dpix,      /* [1,H,W] */
     float *dL_dmean2D,         /* [P,3] (z stays 0) */
-    float *dL_dconic,          /* [P,2,2] (slots 0,1,3) */
+    float *dL_dconic,          /* [P,2,2] (slots 0,1,3); 16-byte aligned */
     float *dL_dopacity,        /* [P,1] */
     float *dL_dmu,             /* [P,1] */
     float *dL_dmean3D,         /* [P,3] */
@@ -139,12 +139,23 @@ R2_API int r2_voxel_backward(
 /* mean of the 3 smallest squared distances to the other points; out[P].  No workspace needed. */
 R2_API int r2_knn_dist2(int P, const float *points /* [P,3] */, float *out /* [P] */, void *stream);
 
+/* ---- measurement: per-stage HIP-event timing on the caller's stream ---------------------------- */
+/* bit i of stage_mask enables stage i (0 = off, the default: no events are recorded).  Enabled stages are
+ * bracketed by hipEventRecord on the stream they are launched on; r2_profile_read synchronises the recorded
+ * events and returns accumulated milliseconds and launch counts per stage (arrays of r2_profile_stage_count()
+ * entries).  Not thread-safe; meant for bench.py. */
+R2_API void r2_profile_enable(unsigned long long stage_mask);
+R2_API int r2_profile_stage_count(void);
+R2_API const char *r2_profile_stage_name(int stage);
+R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
+
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
 /* Byte offsets of the private arrays inside the state buffers of the LAST forward call with the
  * given sizes; lets tests read radii/offsets/keys/point_list/ranges back without fixing the layout
  * in the ABI.  which: 0 tiles_touched u32[P], 1 point_offsets u32[P], 2 keys_unsorted u64[R],
  * 3 values_unsorted u32[R], 4 keys_sorted u64[R], 5 point_list u32[R], 6 ranges uint2[T],
- * 7 cov3D f32[6P], 8 n_contrib u32[N] (only filled when forward ran with debug != 0).
+ * 7 cov3D f32[6P], 8 n_contrib u32[N] (only filled when forward ran with debug != 0),
+ * 9 packed render records f32[8P] (voxelizer: f32[12P]), 10 depths f32[P], 11 mu f32[P] (rasterizer).
  * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
 R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);
 R2_API long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id);

@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libr2hip.so")
+# R2HIP_LIB selects an experiment build (profiling ablations); the default is the product library
+LIB_PATH = os.environ.get("R2HIP_LIB") or os.path.join(_HERE, "libr2hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
@@ -30,6 +31,10 @@ _SIGNATURES = {
     "r2_voxel_backward": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _fp, _f, _fp, _fp, _p, _p, _p,
                                     _p, _p, _p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _p]),
     "r2_knn_dist2": (C.c_int, [_i, _fp, _fp, _p]),
+    "r2_profile_enable": (None, [C.c_ulonglong]),
+    "r2_profile_stage_count": (C.c_int, []),
+    "r2_profile_stage_name": (C.c_char_p, [_i]),
+    "r2_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_raster_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, C.POINTER(C.c_int)]),
     "r2_voxel_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, _i, C.POINTER(C.c_int)]),
 }
@@ -69,3 +74,31 @@ def check(rc, what):
         msg = lib().r2_last_error()
         raise R2HipError("%s failed (code %d): %s" % (what, rc, msg.decode() if msg else ""))
     return rc
+
+
+def stage_names():
+    L = lib()
+    return [L.r2_profile_stage_name(i).decode() for i in range(L.r2_profile_stage_count())]
+
+
+def profile_enable(stages=None):
+    """Enable HIP-event timing for the named stages (None = all, [] = off)."""
+    names = stage_names()
+    if stages is None:
+        mask = (1 << len(names)) - 1
+    else:
+        mask = 0
+        for s in stages:
+            mask |= 1 << names.index(s)
+    lib().r2_profile_enable(mask)
+
+
+def profile_read(reset=True):
+    """-> {stage: (total_ms, launches)} for stages that ran."""
+    L = lib()
+    n = L.r2_profile_stage_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_longlong * n)()
+    L.r2_profile_read(ms, cnt, int(reset))
+    names = stage_names()
+    return {names[i]: (ms[i], cnt[i]) for i in range(n) if cnt[i] > 0}

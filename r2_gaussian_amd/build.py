@@ -20,7 +20,9 @@ LIB = os.path.join(HERE, "libr2hip.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
 EXACT = ["-ffp-contract=off"]
-FAST = ["-ffp-contract=fast"]
+# -fno-slp-vectorize: hipcc would otherwise pack adjacent scalar f32 ops into v_pk_*_f32, which issue ~8x slower
+# than plain VALU ops on gfx950 (measured: render_bwd 532 -> see profiles/)
+FAST = ["-ffp-contract=fast", "-fno-slp-vectorize"]
 
 SOURCES = {
     "binning.hip": FAST,
@@ -62,7 +64,14 @@ def _compile(src, flags, force, hdr_mtime):
     return o, True
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=None, out=None):
+    """extra_flags/out: experiment builds (kernel ablations for profiling) into a separate .so."""
+    global OBJ, LIB
+    if extra_flags or out:
+        tag = os.path.splitext(os.path.basename(out or "libr2hip_exp.so"))[0]
+        OBJ = os.path.join(HERE, "csrc", "build_" + tag)
+        LIB = os.path.join(HERE, os.path.basename(out or "libr2hip_exp.so"))
+        COMMON.extend(extra_flags or [])
     os.makedirs(OBJ, exist_ok=True)
     present = {k: v for k, v in SOURCES.items() if os.path.exists(os.path.join(CSRC, k))}
     missing = sorted(set(SOURCES) - set(present))
@@ -83,4 +92,6 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    extra = [a for a in sys.argv[1:] if a.startswith("-D")]
+    outs = [a[len("--out="):] for a in sys.argv[1:] if a.startswith("--out=")]
+    print(build(force="--force" in sys.argv, verbose=True, extra_flags=extra or None, out=outs[0] if outs else None))

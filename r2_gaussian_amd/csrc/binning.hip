@@ -6,6 +6,8 @@
 #include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <stdarg.h>
+#include <vector>
+#include <string.h>
 
 namespace r2 {
 
@@ -18,6 +20,42 @@ void set_error(const char *fmt, ...)
     va_end(ap);
 }
 const char *get_error() { return g_err; }
+
+// ---- stage timers: event pairs recorded on the caller's stream, resolved lazily in r2_profile_read
+int g_profile_mask_on = 0;
+static unsigned long long g_profile_mask = 0;
+struct Pending { int stage; hipEvent_t a, b; };
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_pool;
+static hipEvent_t g_open[ST_COUNT];
+static double g_ms[ST_COUNT];
+static long long g_cnt[ST_COUNT];
+static const char *const g_stage_names[ST_COUNT] = {
+    "raster.preprocess", "raster.scan", "raster.duplicate", "raster.sort", "raster.ranges", "raster.render_fwd",
+    "raster.render_bwd", "raster.geom_bwd", "voxel.preprocess", "voxel.scan", "voxel.duplicate", "voxel.sort",
+    "voxel.ranges", "voxel.render_fwd", "voxel.render_bwd", "voxel.geom_bwd", "knn.dist2"};
+
+static hipEvent_t pool_get()
+{
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void stage_begin(int stage, hipStream_t s)
+{
+    if (!((g_profile_mask >> stage) & 1ull)) return;
+    hipEvent_t e = pool_get();
+    (void)hipEventRecord(e, s);
+    g_open[stage] = e;
+}
+void stage_end(int stage, hipStream_t s)
+{
+    if (!((g_profile_mask >> stage) & 1ull)) return;
+    hipEvent_t e = pool_get();
+    (void)hipEventRecord(e, s);
+    g_pending.push_back({stage, g_open[stage], e});
+}
 
 uint32_t higher_msb(uint32_t n)
 {
@@ -92,3 +130,34 @@ int tile_ranges(const uint64_t *keys_sorted, size_t R, uint2 *ranges, size_t T, 
 
 extern "C" const char *r2_last_error(void) { return r2::get_error(); }
 extern "C" int r2_abi_version(void) { return R2_ABI_VERSION; }
+
+extern "C" void r2_profile_enable(unsigned long long stage_mask)
+{
+    r2::g_profile_mask = stage_mask;
+    r2::g_profile_mask_on = stage_mask != 0;
+}
+extern "C" int r2_profile_stage_count(void) { return r2::ST_COUNT; }
+extern "C" const char *r2_profile_stage_name(int stage)
+{
+    return (stage >= 0 && stage < r2::ST_COUNT) ? r2::g_stage_names[stage] : "";
+}
+extern "C" int r2_profile_read(double *total_ms, long long *counts, int reset)
+{
+    using namespace r2;
+    for (auto &p : g_pending) {
+        float ms = 0.f;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_ms[p.stage] += ms;
+            g_cnt[p.stage] += 1;
+        }
+        g_pool.push_back(p.a);
+        g_pool.push_back(p.b);
+    }
+    g_pending.clear();
+    for (int i = 0; i < ST_COUNT; ++i) {
+        if (total_ms) total_ms[i] = g_ms[i];
+        if (counts) counts[i] = g_cnt[i];
+    }
+    if (reset) { memset(g_ms, 0, sizeof(g_ms)); memset(g_cnt, 0, sizeof(g_cnt)); }
+    return ST_COUNT;
+}

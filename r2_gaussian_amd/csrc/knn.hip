@@ -60,7 +60,8 @@ extern "C" int r2_knn_dist2(int P, const float *points, float *out, void *stream
         r2::set_error("r2_knn_dist2: invalid argument");
         return R2_ERR_INVALID;
     }
-    r2::knn_dist2_kernel<<<dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(P, points, out);
+    { r2::StageScope t(r2::ST_KNN, (hipStream_t)stream);
+    r2::knn_dist2_kernel<<<dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(P, points, out); }
     R2_STAGE_CHECK(0, (hipStream_t)stream, "knn");
     return 0;
 }

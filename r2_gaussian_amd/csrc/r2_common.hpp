@@ -36,6 +36,22 @@ void set_error(const char *fmt, ...);
         }                                                                                         \
     } while (0)
 
+// ---- optional per-stage timing with HIP events on the caller's stream (r2_profile_* in r2hip.h)
+enum Stage {
+    ST_RAS_PREPROCESS = 0, ST_RAS_SCAN, ST_RAS_DUPLICATE, ST_RAS_SORT, ST_RAS_RANGES, ST_RAS_RENDER_FWD,
+    ST_RAS_RENDER_BWD, ST_RAS_GEOM_BWD,
+    ST_VOX_PREPROCESS, ST_VOX_SCAN, ST_VOX_DUPLICATE, ST_VOX_SORT, ST_VOX_RANGES, ST_VOX_RENDER_FWD,
+    ST_VOX_RENDER_BWD, ST_VOX_GEOM_BWD, ST_KNN, ST_COUNT
+};
+extern int g_profile_mask_on;
+void stage_begin(int stage, hipStream_t s);
+void stage_end(int stage, hipStream_t s);
+struct StageScope {
+    int st; hipStream_t s; bool on;
+    StageScope(int stage, hipStream_t stream) : st(stage), s(stream), on(g_profile_mask_on != 0) { if (on) stage_begin(st, s); }
+    ~StageScope() { if (on) stage_end(st, s); }
+};
+
 // 128-byte aligned bump allocation inside a caller-provided chunk (reference: obtain(), RAS/rasterizer_impl.h:21-31)
 struct Bump {
     char *base;

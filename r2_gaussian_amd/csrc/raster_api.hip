@@ -35,19 +35,24 @@ extern "C" int r2_raster_forward(
         return R2_ERR_INVALID;
     }
 
+    if (gx > 1023 || gy > 2047) {
+        set_error("r2_raster_forward: detector %dx%d exceeds the packed tile-rectangle range (16368 x 32752 px)", width, height);
+        return R2_ERR_INVALID;
+    }
     char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P).bytes, geometry_user);
-    char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N).bytes, image_user);
-    if (!gchunk || !ichunk) {
+    if (!gchunk) {
         set_error("r2_raster_forward: state allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const RasterGeom geom = RasterGeom::carve(gchunk, P);
-    const RasterImage img = RasterImage::carve(ichunk, T, N);
 
+    { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
-                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, s);
+                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
-    int rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s);
+    int rc;
+    { StageScope t(ST_RAS_SCAN, s);
+    rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
 
@@ -57,26 +62,34 @@ extern "C" int r2_raster_forward(
     R2_HIP_TRY(hipStreamSynchronize(s));
     const size_t R = num_rendered;
 
+    // both remaining state buffers are sized by R: the sorted lists (+ backward scratch) and the
+    // forward work list / per-chunk partial images
     char *bchunk = binningBuffer(RasterBinning::carve(nullptr, R).bytes, binning_user);
-    if (!bchunk) {
-        set_error("r2_raster_forward: binning allocation callback returned NULL");
+    char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, R, debug != 0).bytes, image_user);
+    if (!bchunk || !ichunk) {
+        set_error("r2_raster_forward: binning/image allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const RasterBinning bin = RasterBinning::carve(bchunk, R);
+    const RasterImage img = RasterImage::carve(ichunk, T, N, R, debug != 0);
 
     if (R > 0) {
-        launch_raster_duplicate(geom, bin, P, radii, width, height, s);
+        { StageScope t(ST_RAS_DUPLICATE, s);
+        launch_raster_duplicate(geom, bin, P, radii, width, height, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
+        { StageScope t(ST_RAS_SORT, s);
         rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
-                                bin.point_list, R, 32 + bit, s);
+                                bin.point_list, R, 32 + bit, s); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
-    rc = tile_ranges(bin.keys, R, img.ranges, T, s);
+    { StageScope t(ST_RAS_RANGES, s);
+    rc = tile_ranges(bin.keys, R, img.ranges, T, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
-    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, s);
+    { StageScope t(ST_RAS_RENDER_FWD, s);
+    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     return (int)num_rendered;
 }
@@ -89,27 +102,26 @@ extern "C" int r2_raster_backward(
     float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, void *stream)
 {
     (void)campos;
+    (void)img_buffer;   // the backward needs only the geometry and binning state
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return 0;
-    if (P < 0 || R < 0 || !means3D || !radii || !geom_buffer || !img_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
+    if (P < 0 || R < 0 || !means3D || !radii || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
         !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmu || !dL_dmean3D || !dL_dcov3D ||
         (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
         set_error("r2_raster_backward: invalid argument");
         return R2_ERR_INVALID;
     }
-    const size_t N = (size_t)width * height;
-    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
     const RasterGeom geom = RasterGeom::carve(geom_buffer, P);
     const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
-    const RasterImage img = RasterImage::carve(img_buffer, (size_t)gx * gy, N);
 
-    launch_raster_render_backward(geom, bin, img, width, height, (size_t)R, dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity,
-                                  dL_dmu, s);
+    { StageScope t(ST_RAS_RENDER_BWD, s);
+    launch_raster_render_backward(geom, bin, width, height, (size_t)R, dL_dpix, s); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    { StageScope t(ST_RAS_GEOM_BWD, s);
     launch_raster_geom_backward(P, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
-                                tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dmean3D, dL_dcov3D,
-                                dL_dscale, dL_drot, mode, s);
+                                tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D,
+                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }
@@ -134,7 +146,7 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
     const RasterGeom g = RasterGeom::carve(base, P);
     const RasterBinning b = RasterBinning::carve(base, (size_t)R);
-    const RasterImage im = RasterImage::carve(base, (size_t)gx * gy, (size_t)width * height);
+    const RasterImage im = RasterImage::carve(base, (size_t)gx * gy, (size_t)width * height, (size_t)R, true);
     const char *p = nullptr;
     int buf = -1;
     switch (which) {
@@ -149,6 +161,7 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     case 8: p = (char *)im.n_contrib; buf = 2; break;
     case 9: p = (char *)g.rec; buf = 0; break;
     case 10: p = (char *)g.depths; buf = 0; break;
+    case 11: p = (char *)g.mus; buf = 0; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

@@ -76,8 +76,8 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
-    int *__restrict__ radii, float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ cov3Ds,
-    uint32_t *__restrict__ tiles_touched)
+    int *__restrict__ radii, float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ mus,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -128,10 +128,13 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     radii[idx] = (int)my_radius;
     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
     // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
-    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), then opacity*mu and the two factors.
+    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), opacity*mu, then two integer words for the
+    // backward: index of this Gaussian's first instance in the unsorted list (filled by the duplicate
+    // kernel once the scan is known) and its packed tile rectangle.
     const float op = opacities[idx];
+    mus[idx] = mu;
     rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
-    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, op, mu);
+    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, 0.f, __uint_as_float(pack_rect(x0, y0, x1 - x0)));
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -150,7 +153,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 // owner with a 6-step search over the lanes' exclusive offsets (ds_bpermute), instead of every lane
 // dribbling out its own run.
 __global__ void __launch_bounds__(256) raster_duplicate_kernel(
-    int P, const float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
+    int P, float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -172,6 +175,7 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
         const float4 r0 = rec[2 * idx];
         tile_rect(r0.x, r0.y, radii[idx], gx, gy, x0, y0, x1, y1);
         dbits = __float_as_uint(depths[idx]);
+        reinterpret_cast<uint32_t *>(rec)[8 * idx + 6] = excl;   // first instance index, for the backward scratch
     }
     const uint32_t wbeg = __shfl(excl, 0);
     const int last_lane = min(63, P - 1 - wave_first);
@@ -201,27 +205,55 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
 }
 
 // ------------------------------------------------------------------ backward: fused geometry gradient
-// computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA (RAS/backward.cu:402-444) in one pass:
-// the per-Gaussian accumulators of the render backward are read once, all four output rows written once.
+// One pass per Gaussian:
+//   1. reduce the per-instance moment rows written by the render backward (this Gaussian's instances are
+//      contiguous in the UNSORTED list: [first, first + tiles_touched)), in a fixed order -> deterministic,
+//      atomic-free gradients (the reference accumulates with float atomicAdd, RAS/backward.cu:562-572);
+//   2. turn the moments into dL/dmean2D, dL/dconic, dL/dopacity, dL/dmu (the 7 sums of the reference);
+//   3. computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA backward (RAS/backward.cu:402-444).
 // Outputs are ASSIGNED; the caller's zero-initialisation covers the rows of culled Gaussians.
 __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     int P, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
-    const float *__restrict__ proj, const float *__restrict__ dL_dconics, const float *__restrict__ dL_dmus,
-    const float *__restrict__ dL_dmean2D, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
+    const float *__restrict__ proj, const float4 *__restrict__ rec, const float *__restrict__ mus,
+    const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
+    float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
+    float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot, int mode)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || !(radii[idx] > 0)) return;
 
+    // ---- 1. moments of w = G * dL/dpix over all tiles of this Gaussian
+    const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
+    const uint32_t first = __float_as_uint(rb.z), ninst = tiles_touched[idx];
+    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
+    for (uint32_t j = 0; j < ninst; ++j) {
+        const float4 m0 = part[2 * (size_t)(first + j)];
+        const float4 m1 = part[2 * (size_t)(first + j) + 1];
+        S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
+    }
+    // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
+    const float mu_f = mus[idx];
+    const float opmu = rb.y;
+    const float op = (mu_f != 0.0f) ? opmu / mu_f : 0.0f;   // only multiplies S0 into dL/dmu; exact value irrelevant when mu == 0 (Q8 zeroes the chain)
+    const float cA = ra.z * (-2.0f * LN2), cB = ra.w * (-LN2), cC = rb.x * (-2.0f * LN2);
+    const float g2x = opmu * W_half * (-cA * S1 - cB * S2);
+    const float g2y = opmu * H_half * (-cC * S2 - cB * S1);
+    const float gx_ = -0.5f * opmu * S3, gy_ = -opmu * S4, gz_ = -0.5f * opmu * S5;
+    const float dL_dmu = op * S0;
+    dL_dmean2D[3 * idx + 0] = g2x;
+    dL_dmean2D[3 * idx + 1] = g2y;
+    dL_dopacity[idx] = mu_f * S0;
+    dL_dmus[idx] = dL_dmu;
+    reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(gx_, gy_, 0.f, gz_);
+
+    // ---- 3. geometry chain
     float cov3D[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    const float4 gcon = reinterpret_cast<const float4 *>(dL_dconics)[idx];
-    const float gx_ = gcon.x, gy_ = gcon.y, gz_ = gcon.w;
-    const float dL_dmu = dL_dmus[idx];
 
     Cov2D c;
     cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, mode, c);
@@ -300,7 +332,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float m_w = 1.0f / (m_hom.w + 0.0000001f);
     const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
     const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-    const float g0 = dL_dmean2D[3 * idx], g1 = dL_dmean2D[3 * idx + 1];
+    const float g0 = g2x, g1 = g2y;
     const float ddx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
     const float ddy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
     const float ddz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
@@ -331,7 +363,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, c
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depths, g.cov3D, g.tiles_touched);
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depths, g.mus, g.cov3D, g.tiles_touched);
     return 0;
 }
 
@@ -352,15 +384,17 @@ int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t 
 
 int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
-                                float tan_fovy, const float *view, const float *proj, const float *dL_dconic,
-                                const float *dL_dmu, const float *dL_dmean2D, float *dL_dmean3D, float *dL_dcov3D,
-                                float *dL_dscale, float *dL_drot, int mode, hipStream_t s)
+                                float tan_fovy, const float *view, const float *proj, float *dL_dconic,
+                                float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
+                                float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
+                                const float *part, hipStream_t s)
 {
     const float h_y = H / (2.0f * tan_fovy);
     const float h_x = W / (2.0f * tan_fovx);
     raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, dL_dconic,
-        dL_dmu, dL_dmean2D, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
+        P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
+        g.mus, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
+        dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }
 

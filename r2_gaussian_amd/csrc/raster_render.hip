@@ -1,20 +1,28 @@
 // raster_render.hip -- per-tile additive line-integral render of the X-ray rasterizer and its backward.
 //
 // Reference: renderCUDA forward RAS/forward.cu:294-395, renderCUDA backward RAS/backward.cu:447-575.
-// These two kernels are VALU/exp-bound (256 pixel-Gaussian pairs per 32 bytes gathered), so this file
-// is compiled with FMA contraction ON; their results are tolerance-checked, not bit-checked.
+// These kernels are VALU/exp-bound (256 pixel-Gaussian pairs per 32 bytes gathered; ~15 VALU issue slots
+// per pair, v_exp_f32 alone costs ~7 of them), so this file is compiled with FMA contraction ON and
+// without SLP packing; results are tolerance-checked, not bit-checked.
 //
-// Forward : one workgroup = one 16x16 tile = 4 waves of 16x4 pixels; the tile's depth-sorted list is
-//           staged through LDS in 256-record batches (32-byte packed records, two b128 gathers per
-//           record), every lane then reads the records as wave-uniform LDS broadcasts.
+// Forward : a tile's depth-sorted list is cut into work items of FWD_CHUNK instances.  One workgroup =
+//           one work item = 4 waves of 16x4 pixels; records are staged through LDS in 256-record batches
+//           (32-byte packed records, two b128 gathers each) and read back as wave-uniform broadcasts.
+//           Each work item writes 256 partial pixel sums; a second tiny kernel adds a tile's partials IN
+//           LIST ORDER, so the image is deterministic.  Cutting the lists is what balances the machine:
+//           list lengths span 0..9000 on the benchmark scene (median 50), and a workgroup per tile left
+//           most CUs idle behind a few dense tiles.
 // Backward: the loop nest is inverted.  One LANE owns one (tile, Gaussian) instance of the sorted list and
-//           walks the 256 pixels of its tile; pixel data (dL/dpix) is wave-uniform and arrives through
-//           scalar loads.  The 7 gradient terms of the reference are linear in 6 moments
+//           walks the 256 pixels of its tile; dL/dpix of the tile is staged once per wave in LDS and read
+//           as b128 broadcasts.  The 7 gradient sums of the reference are linear in 6 moments
 //           sum(w), sum(w dx), sum(w dy), sum(w dx^2), sum(w dx dy), sum(w dy^2), w = G*dL/dpix,
-//           accumulated in registers, so there is no cross-lane reduction and only 7 atomics per
-//           INSTANCE instead of 7 per contributing (pixel, Gaussian) pair (RAS/backward.cu:562-572).
-//           Workgroups are cut as 256 consecutive instances of the global sorted list, which balances
-//           the load perfectly whatever the tile occupancy.
+//           accumulated in registers: no cross-lane reduction, and NO atomics -- each instance stores its
+//           moment row to scratch at its UNSORTED list position (contiguous per Gaussian), which the
+//           geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
+//           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
+//           Workgroups are cut as 256 consecutive instances of the global sorted list: perfect balance.
+//           Waves that straddle many sparse tiles switch to a per-lane gather of dL/dpix instead of
+//           re-walking 256 pixels once per tile.
 //           The reference's n_contrib skip (RAS/backward.cu:523-525) only prunes pairs that failed the
 //           forward tests; re-evaluating the tests prunes the same pairs, so n_contrib is not needed.
 #include "raster_state.hpp"
@@ -23,37 +31,80 @@ namespace r2 {
 
 constexpr float ALPHA_MIN_2D = 0.00001f;   // RAS/forward.cu:374
 
+// ------------------------------------------------------------------------------------------------ forward
+// work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
+__global__ void __launch_bounds__(1024) raster_build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T,
+                                                                 uint32_t *__restrict__ chunk_base,
+                                                                 uint32_t *__restrict__ work_tile)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < T; base += 1024) {
+        const uint32_t t = base + tid;
+        uint32_t n = 0;
+        if (t < T) {
+            const uint2 r = ranges[t];
+            n = (r.y - r.x + FWD_CHUNK - 1) / FWD_CHUNK;
+        }
+        // inclusive scan inside the wave, then across the 16 waves
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t excl = carry + woff + incl - n;
+        if (t < T) {
+            chunk_base[t] = excl;
+            for (uint32_t j = 0; j < n; ++j) work_tile[excl + j] = t;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = excl + n;
+        __syncthreads();
+    }
+    if (tid == 0) chunk_base[T] = carry;
+}
+
 template <bool NCONTRIB>
 __global__ void __launch_bounds__(256) raster_render_forward_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int W,
-    int H, int gx, uint32_t T, float *__restrict__ out_color, uint32_t *__restrict__ n_contrib)
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
+    float *__restrict__ partial, uint32_t *__restrict__ partial_last)
 {
-    const uint32_t tile = xcd_remap(blockIdx.x, T);
-    if (tile >= T) return;
+    const uint32_t w = blockIdx.x;
+    if (w >= chunk_base[T]) return;
+    const uint32_t tile = work_tile[w];
+    const uint32_t j0 = (w - chunk_base[tile]) * FWD_CHUNK;
+    const uint2 range = ranges[tile];
+    const uint32_t beg = range.x + j0, end = min(range.y, beg + FWD_CHUNK);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
-    const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
-    const bool inside = px < W && py < H;
-    const float fx = (float)px, fy = (float)py;
-    const uint2 range = ranges[tile];
+    const float fx = (float)(tx * TILE2D + (tid & 15)), fy = (float)(ty * TILE2D + (tid >> 4));
 
     __shared__ float4 sA[256];
     __shared__ float2 sB[256];
 
     float C = 0.f;
     uint32_t last = 0;
-    for (uint32_t base = range.x; base < range.y; base += 256) {
+    for (uint32_t base = beg; base < end; base += 256) {
         __syncthreads();
         const uint32_t k = base + tid;
-        if (k < range.y) {
+        if (k < end) {
             const uint32_t id = point_list[k];
             const float4 a = rec[2 * id];
-            const float4 b = rec[2 * id + 1];
+            const float2 b = *reinterpret_cast<const float2 *>(&rec[2 * id + 1]);
             sA[tid] = a;
-            sB[tid] = make_float2(b.x, b.y);
+            sB[tid] = b;
         }
         __syncthreads();
-        const int n = min(256u, range.y - base);
+        const int n = min(256u, end - base);
 #pragma unroll 4
         for (int j = 0; j < n; ++j) {
             const float4 a = sA[j];
@@ -66,59 +117,103 @@ __global__ void __launch_bounds__(256) raster_render_forward_kernel(
             if (NCONTRIB) last = ok ? (base - range.x) + (uint32_t)j + 1u : last;
         }
     }
-    if (inside) {
+    partial[(size_t)w * 256 + tid] = C;
+    if (NCONTRIB) partial_last[(size_t)w * 256 + tid] = last;
+}
+
+// adds the partial sums of a tile's work items in list order and writes the image (zeros for empty tiles)
+template <bool NCONTRIB>
+__global__ void __launch_bounds__(256) raster_combine_kernel(
+    const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial,
+    const uint32_t *__restrict__ partial_last, int W, int H, int gx, float *__restrict__ out_color,
+    uint32_t *__restrict__ n_contrib)
+{
+    const uint32_t tile = blockIdx.x;
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x;
+    const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
+    const uint32_t w0 = chunk_base[tile], w1 = chunk_base[tile + 1];
+    float C = 0.f;
+    uint32_t last = 0;
+    for (uint32_t w = w0; w < w1; ++w) {
+        C += partial[(size_t)w * 256 + tid];
+        if (NCONTRIB) {
+            const uint32_t l = partial_last[(size_t)w * 256 + tid];
+            last = l ? l : last;
+        }
+    }
+    if (px < W && py < H) {
         out_color[py * W + px] = C;
         if (NCONTRIB) n_contrib[py * W + px] = last;
     }
 }
 
-// moments of w = G * dL/dpix over one tile, for the instance held by this lane.  FULLW: the tile has all
-// 16 columns, so the 16 wave-uniform dL loads of a row are unconditional (merged into wide scalar loads).
-template <bool FULLW>
-__device__ __forceinline__ void tile_moments(const float4 a, const float4 b, const float *__restrict__ dL_dpix, int W,
-                                             int x0, int y0, int ncols, int nrows, float &S0, float &S1, float &S2,
-                                             float &S3, float &S4, float &S5)
+// ------------------------------------------------------------------------------------------------ backward
+__device__ __forceinline__ void pixel_moments(const float4 a, const float4 b, float dx, float bdy, float cdy2, float g,
+                                              float &r0, float &r1, float &r3)
+{
+    const float p2 = dx * (a.z * dx + bdy) + cdy2;
+    const float G = __builtin_amdgcn_exp2f(p2);
+    const bool ok = (p2 <= 0.0f) && (b.y * G >= ALPHA_MIN_2D);
+    const float w = ok ? G * g : 0.f;
+    const float wdx = w * dx;
+    r0 += w;
+    r1 += wdx;
+    r3 += wdx * dx;
+}
+
+// moments of w = G * dL/dpix over one tile whose 16x16 block of dL/dpix sits in this wave's LDS slab
+// (zeros outside the image): every read is a wave-uniform b128 broadcast, the loop has no bounds logic.
+__device__ __forceinline__ void tile_moments_uniform(const float4 a, const float4 b, const float4 *__restrict__ gt,
+                                                     int x0, int y0, float *S)
 {
     const float dx0 = a.x - (float)x0;
-    for (int r = 0; r < nrows; ++r) {
+#pragma unroll 2
+    for (int r = 0; r < TILE2D; ++r) {
         const float dy = a.y - (float)(y0 + r);
         const float bdy = a.w * dy;           // B2*dy
         const float cdy2 = (b.x * dy) * dy;   // C2*dy^2
-        const float *__restrict__ row = dL_dpix + (size_t)(y0 + r) * W + x0;
+        float g[TILE2D];
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 v = gt[r * 4 + c4];
+            g[4 * c4 + 0] = v.x; g[4 * c4 + 1] = v.y; g[4 * c4 + 2] = v.z; g[4 * c4 + 3] = v.w;
+        }
         float r0 = 0.f, r1 = 0.f, r3 = 0.f;
 #pragma unroll
-        for (int c = 0; c < TILE2D; ++c) {
-            float g;   // wave-uniform address -> scalar load
-            if (FULLW) g = row[c];
-            else g = (c < ncols) ? row[min(c, ncols - 1)] : 0.f;
-            const float dx = dx0 - (float)c;
-            const float p2 = dx * (a.z * dx + bdy) + cdy2;
-            const float G = __builtin_amdgcn_exp2f(p2);
-            const bool ok = (p2 <= 0.0f) && (b.y * G >= ALPHA_MIN_2D);
-            const float w = ok ? G * g : 0.f;
-            const float wdx = w * dx;
-            r0 += w;
-            r1 += wdx;
-            r3 += wdx * dx;
-        }
-        S0 += r0;
-        S1 += r1;
-        S3 += r3;
-        S2 += dy * r0;
-        S4 += dy * r1;
-        S5 += dy * dy * r0;
+        for (int c = 0; c < TILE2D; ++c) pixel_moments(a, b, dx0 - (float)c, bdy, cdy2, g[c], r0, r1, r3);
+        S[0] += r0; S[1] += r1; S[3] += r3;
+        S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
+    }
+}
+
+// same, for a wave whose lanes sit in MANY different (sparse) tiles: every lane gathers the dL/dpix of its
+// own tile straight from memory, one pass for the whole wave instead of one pass per tile.
+__device__ __forceinline__ void tile_moments_gather(const float4 a, const float4 b, const float *__restrict__ dL, int W,
+                                                    int H, int x0, int y0, float *S)
+{
+    const float dx0 = a.x - (float)x0;
+    const int nrows = min(TILE2D, H - y0), ncols = min(TILE2D, W - x0);
+    for (int r = 0; r < nrows; ++r) {
+        const float dy = a.y - (float)(y0 + r);
+        const float bdy = a.w * dy, cdy2 = (b.x * dy) * dy;
+        const float *__restrict__ row = dL + (size_t)(y0 + r) * W + x0;
+        float r0 = 0.f, r1 = 0.f, r3 = 0.f;
+        for (int c = 0; c < ncols; ++c) pixel_moments(a, b, dx0 - (float)c, bdy, cdy2, row[c], r0, r1, r3);
+        S[0] += r0; S[1] += r1; S[3] += r3;
+        S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
     }
 }
 
 __global__ void __launch_bounds__(256) raster_render_backward_kernel(
     const uint64_t *__restrict__ keys, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
-    uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix,
-    float *__restrict__ dL_dmean2D, float *__restrict__ dL_dconic, float *__restrict__ dL_dopacity,
-    float *__restrict__ dL_dmu)
+    uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
 {
+    __shared__ float4 gtile[4][64];   // one 16x16 dL/dpix block per wave
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
     if (chunk >= nchunks) return;
     const uint32_t k = chunk * 256u + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = k < R;
     uint32_t tile = 0xffffffffu, id = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -128,65 +223,87 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
         a = rec[2 * id];
         b = rec[2 * id + 1];
     }
-    float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
+    float S[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    float4 *gt = gtile[wave];
 
-    // a wave usually sits inside one tile; at list boundaries it serves each tile in turn
-    unsigned long long todo = __ballot(live);
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
-        const bool mine = live && tile == t;
-        todo &= ~__ballot(mine);
-        const int tx = t % gx, ty = t / gx;
-        const int x0 = tx * TILE2D, y0 = ty * TILE2D;
-        const int ncols = min(TILE2D, W - x0), nrows = min(TILE2D, H - y0);
-        if (mine) {
-            if (ncols == TILE2D)
-                tile_moments<true>(a, b, dL_dpix, W, x0, y0, ncols, nrows, S0, S1, S2, S3, S4, S5);
-            else
-                tile_moments<false>(a, b, dL_dpix, W, x0, y0, ncols, nrows, S0, S1, S2, S3, S4, S5);
+    // number of distinct tiles in this wave (the list is tile-sorted: count the run starts)
+    const uint32_t prev_tile = __shfl_up(tile, 1);
+    const unsigned long long heads = __ballot(live && (lane == 0 || tile != prev_tile));
+    if (__popcll(heads) > 3) {
+        if (live) tile_moments_gather(a, b, dL_dpix, W, H, (int)(tile % gx) * TILE2D, (int)(tile / gx) * TILE2D, S);
+    } else {
+        unsigned long long todo = __ballot(live);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
+            const bool mine = live && tile == t;
+            todo &= ~__ballot(mine);
+            const int x0 = (int)(t % gx) * TILE2D, y0 = (int)(t / gx) * TILE2D;
+            {   // stage the tile's dL/dpix: lane -> (row = lane/4, 4 columns), zero outside the image
+                const int ry = y0 + (lane >> 2), cx = x0 + (lane & 3) * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ry < H) {
+                    const float *__restrict__ src = dL_dpix + (size_t)ry * W + cx;
+                    if (cx + 3 < W && (W & 3) == 0) v = *reinterpret_cast<const float4 *>(src);
+                    else {
+                        if (cx + 0 < W) v.x = src[0];
+                        if (cx + 1 < W) v.y = src[1];
+                        if (cx + 2 < W) v.z = src[2];
+                        if (cx + 3 < W) v.w = src[3];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();   // readers of the previous tile are done (same wave, in order)
+                gt[lane] = v;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (mine) tile_moments_uniform(a, b, gt, x0, y0, S);
         }
     }
     if (live) {
-        const float op = b.z, mu = b.w, opmu = b.y;
-        const float A = a.z * (-2.0f * LN2), B = a.w * (-LN2), Cc = b.x * (-2.0f * LN2);   // undo the log2e pre-scale
-        unsafeAtomicAdd(&dL_dmean2D[3 * id + 0], opmu * (0.5f * (float)W) * (-A * S1 - B * S2));
-        unsafeAtomicAdd(&dL_dmean2D[3 * id + 1], opmu * (0.5f * (float)H) * (-Cc * S2 - B * S1));
-        unsafeAtomicAdd(&dL_dconic[4 * id + 0], -0.5f * opmu * S3);
-        unsafeAtomicAdd(&dL_dconic[4 * id + 1], -opmu * S4);
-        unsafeAtomicAdd(&dL_dconic[4 * id + 3], -0.5f * opmu * S5);
-        unsafeAtomicAdd(&dL_dopacity[id], mu * S0);
-        unsafeAtomicAdd(&dL_dmu[id], op * S0);
+        // scratch row of this instance: first instance of the Gaussian + position of the tile in its rectangle
+        const uint32_t first = __float_as_uint(b.z), rp = __float_as_uint(b.w);
+        const uint32_t rx0 = rp & 2047u, ry0 = (rp >> 11) & 2047u, rw = rp >> 22;
+        const uint32_t u = first + (tile / gx - ry0) * rw + (tile % gx - rx0);
+        part[2 * (size_t)u] = make_float4(S[0], S[1], S[2], S[3]);
+        part[2 * (size_t)u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
 }
 
+// ------------------------------------------------------------------------------------------------ launchers
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
                                  float *out_color, bool write_ncontrib, hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
-    const uint32_t grid = ((T + 7u) >> 3) << 3;
+    raster_build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(im.ranges, T, im.chunk_base, im.work_tile);
+    if (im.NW > 0) {
+        if (write_ncontrib)
+            raster_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
+        else
+            raster_render_forward_kernel<false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
+    }
     if (write_ncontrib)
-        raster_render_forward_kernel<true><<<dim3(grid), dim3(256), 0, s>>>(im.ranges, b.point_list, g.rec, W, H, gx, T,
-                                                                            out_color, im.n_contrib);
+        raster_combine_kernel<true><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
+                                                                  out_color, im.n_contrib);
     else
-        raster_render_forward_kernel<false><<<dim3(grid), dim3(256), 0, s>>>(im.ranges, b.point_list, g.rec, W, H, gx, T,
-                                                                             out_color, im.n_contrib);
+        raster_combine_kernel<false><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
+                                                                   out_color, im.n_contrib);
     return 0;
 }
 
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                  size_t R, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
-                                  float *dL_dopacity, float *dL_dmu, hipStream_t s)
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, int W, int H, size_t R,
+                                  const float *dL_dpix, hipStream_t s)
 {
-    (void)im;
     if (R == 0) return 0;
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
     raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.keys, b.point_list, g.rec, (uint32_t)R, W, H, gx,
-                                                                   nchunks, dL_dpix, dL_dmean2D, dL_dconic,
-                                                                   dL_dopacity, dL_dmu);
+                                                                   nchunks, dL_dpix,
+                                                                   reinterpret_cast<float4 *>(b.part));
     return 0;
 }
 

@@ -7,9 +7,17 @@
 
 namespace r2 {
 
+constexpr uint32_t FWD_CHUNK = 512;   // instances of one tile list rendered by one workgroup (load balance)
+constexpr int PART_STRIDE = 8;        // floats per instance in the backward moment scratch (6 used)
+
+// packed tile rectangle of a Gaussian: x0 (11 bits) | y0 (11 bits) | width in tiles (10 bits)
+__host__ __device__ inline uint32_t pack_rect(int x0, int y0, int rw) { return (uint32_t)x0 | ((uint32_t)y0 << 11) | ((uint32_t)rw << 22); }
+
 struct RasterGeom {
-    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, op*mu, op, mu}   (A2,B2,C2: conic * -log2e/2, -log2e, -log2e/2)
+    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, op*mu, bits(first instance index), bits(pack_rect)}
+                              //       (A2,B2,C2: conic * -log2e/2, -log2e, -log2e/2)
     float *depths;            // [P]   view-space z (sort key low word)
+    float *mus;               // [P]   ray-integration factor mu (kept for inspection / parity tests)
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
     uint32_t *offsets;        // [P]   inclusive scan of tiles_touched
@@ -22,6 +30,7 @@ struct RasterGeom {
         Bump b(chunk);
         g.rec = b.take<float4>(2 * (size_t)P);
         g.depths = b.take<float>(P);
+        g.mus = b.take<float>(P);
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
@@ -37,6 +46,7 @@ struct RasterBinning {
     uint64_t *keys;           // [R]
     uint32_t *vals_unsorted;  // [R]
     uint32_t *point_list;     // [R]
+    float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by UNSORTED position
     char *sort_temp;
     size_t sort_bytes;
     size_t bytes;
@@ -48,6 +58,7 @@ struct RasterBinning {
         s.keys = b.take<uint64_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
         s.point_list = b.take<uint32_t>(R);
+        s.part = b.take<float>(R * PART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);
         s.sort_temp = b.take<char>(s.sort_bytes);
         s.bytes = b.total();
@@ -56,15 +67,25 @@ struct RasterBinning {
 };
 
 struct RasterImage {
-    uint2 *ranges;        // [T]
-    uint32_t *n_contrib;  // [N]  last contributing list position per pixel; only written in debug mode
+    uint2 *ranges;         // [T]
+    uint32_t *chunk_base;  // [T+1] exclusive scan of ceil(len/FWD_CHUNK): first work item of each tile; [T] = total
+    uint32_t *work_tile;   // [NW]  tile of each forward work item
+    float *partial;        // [NW*256] per-work-item partial pixel sums, combined in list order
+    uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
+    uint32_t *n_contrib;   // [N]  last contributing list position per pixel; only written in debug mode
+    size_t NW;             // upper bound on work items: R/FWD_CHUNK + T
     size_t bytes;
-    static RasterImage carve(char *chunk, size_t T, size_t N)
+    static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug)
     {
         RasterImage s;
         Bump b(chunk);
+        s.NW = R / FWD_CHUNK + T;
         s.ranges = b.take<uint2>(T);
-        s.n_contrib = b.take<uint32_t>(N);
+        s.chunk_base = b.take<uint32_t>(T + 1);
+        s.work_tile = b.take<uint32_t>(s.NW);
+        s.partial = b.take<float>(s.NW * 256);
+        s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
+        s.n_contrib = b.take<uint32_t>(debug ? N : 0);
         s.bytes = b.total();
         return s;
     }
@@ -80,13 +101,13 @@ int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, 
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
-                                float tan_fovy, const float *view, const float *proj, const float *dL_dconic,
-                                const float *dL_dmu, const float *dL_dmean2D, float *dL_dmean3D, float *dL_dcov3D,
-                                float *dL_dscale, float *dL_drot, int mode, hipStream_t s);
+                                float tan_fovy, const float *view, const float *proj, float *dL_dconic,
+                                float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
+                                float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
+                                const float *part, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
                                  float *out_color, bool write_ncontrib, hipStream_t s);
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                  size_t R, const float *dL_dpix, float *dL_dmean2D, float *dL_dconic,
-                                  float *dL_dopacity, float *dL_dmu, hipStream_t s);
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, int W, int H, size_t R,
+                                  const float *dL_dpix, hipStream_t s);
 
 }  // namespace r2

@@ -53,10 +53,13 @@ extern "C" int r2_voxel_forward(
     const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, debug != 0);
 
+    { StageScope t(ST_VOX_PREPROCESS, s);
     launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
-                            radii_y, radii_z, s);
+                            radii_y, radii_z, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
-    int rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s);
+    int rc;
+    { StageScope t(ST_VOX_SCAN, s);
+    rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
     uint32_t num_rendered = 0;
@@ -71,18 +74,22 @@ extern "C" int r2_voxel_forward(
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
     if (R > 0) {
-        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s);
+        { StageScope t(ST_VOX_DUPLICATE, s);
+        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
+        { StageScope t(ST_VOX_SORT, s);
         rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
-                                bin.point_list, R, 32 + bit, s);
+                                bin.point_list, R, 32 + bit, s); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
-    rc = tile_ranges(bin.keys, R, img.ranges, T, s);
+    { StageScope t(ST_VOX_RANGES, s);
+    rc = tile_ranges(bin.keys, R, img.ranges, T, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
-    launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s);
+    { StageScope t(ST_VOX_RENDER_FWD, s);
+    launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     return (int)num_rendered;
 }
@@ -108,12 +115,14 @@ extern "C" int r2_voxel_backward(
     const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
-    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, dL_dmean3D_norm, dL_dconic3D, dL_dopacity, s);
+    { StageScope t(ST_VOX_RENDER_BWD, s);
+    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, dL_dmean3D_norm, dL_dconic3D, dL_dopacity, s); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    { StageScope t(ST_VOX_GEOM_BWD, s);
     launch_voxel_geom_backward(v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
                                cov3D_precomp ? nullptr : rotations, scale_modifier, dL_dconic3D, dL_dmean3D_norm,
-                               dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s);
+                               dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }

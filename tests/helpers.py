@@ -69,8 +69,7 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     # decode the packed render record back to the reference's quantities
     out["means2D"] = rec[:, 0:2]
     out["conic"] = np.stack([rec[:, 2] / (-0.5 * LOG2E), rec[:, 3] / (-LOG2E), rec[:, 4] / (-0.5 * LOG2E)], 1)
-    out["mus"] = rec[:, 7]
-    out["opacity"] = rec[:, 6]
+    out["mus"] = read(11, np.float32, P)
     return out
 
 

@@ -1,0 +1,130 @@
+"""The drop-in seam: the nn.Module / autograd surface used by render() and query()
+(r2_gaussian/gaussian/render_query.py:27-160) driven exactly the way the reference drives it."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(pc, v, dev):
+    """render() of the reference, verbatim semantics (render_query.py:80-160)."""
+    from xray_gaussian_rasterization_voxelization import GaussianRasterizationSettings, GaussianRasterizer
+    xyz, scales, rot, dens = pc
+    screenspace_points = torch.zeros_like(xyz, dtype=xyz.dtype, requires_grad=True, device=dev) + 0
+    screenspace_points.retain_grad()
+    rs = GaussianRasterizationSettings(
+        image_height=v.image_height, image_width=v.image_width, tanfovx=v.tanfovx, tanfovy=v.tanfovy,
+        scale_modifier=1.0, viewmatrix=v.world_view_transform.to(dev), projmatrix=v.full_proj_transform.to(dev),
+        campos=v.camera_center.to(dev), prefiltered=False, mode=v.mode, debug=False)
+    img, radii = GaussianRasterizer(raster_settings=rs)(means3D=xyz, means2D=screenspace_points, opacities=dens,
+                                                        scales=scales, rotations=rot, cov3D_precomp=None)
+    return dict(render=img, viewspace_points=screenspace_points, visibility_filter=radii > 0, radii=radii)
+
+
+def _query(pc, center, nVoxel, sVoxel, dev):
+    from xray_gaussian_rasterization_voxelization import GaussianVoxelizationSettings, GaussianVoxelizer
+    xyz, scales, rot, dens = pc
+    vs = GaussianVoxelizationSettings(
+        scale_modifier=1.0, nVoxel_x=int(nVoxel[0]), nVoxel_y=int(nVoxel[1]), nVoxel_z=int(nVoxel[2]),
+        sVoxel_x=float(sVoxel[0]), sVoxel_y=float(sVoxel[1]), sVoxel_z=float(sVoxel[2]), center_x=float(center[0]),
+        center_y=float(center[1]), center_z=float(center[2]), prefiltered=False, debug=False)
+    vol, radii = GaussianVoxelizer(voxel_settings=vs)(means3D=xyz, opacities=dens, scales=scales, rotations=rot,
+                                                      cov3D_precomp=None)
+    return dict(vol=vol, radii=radii)
+
+
+def test_training_iteration_like_reference(oracle, gpu):
+    """One iteration of train.py:97-177 in miniature: raw params -> activations -> render + TV query -> loss
+    -> backward -> densification statistics; gradients checked against oracle backward + torch autograd of
+    the activations."""
+    P = 4000
+    c = S.make_cloud(P, seed=4)
+    v = S.make_view(0.5, (64, 64))
+    _xyz = c.xyz.clone().to(gpu).requires_grad_(True)
+    _scal = torch.log(c.scales / (1.0 - c.scales)).to(gpu).requires_grad_(True)          # bounded-sigmoid style raw
+    _rot = (c.rotations * 1.7).to(gpu).requires_grad_(True)                              # un-normalised raw quats
+    _den = torch.log(torch.expm1(c.density)).to(gpu).requires_grad_(True)                # inverse softplus
+    scales = torch.sigmoid(_scal)
+    rot = torch.nn.functional.normalize(_rot)
+    dens = torch.nn.functional.softplus(_den)
+    pc = (_xyz, scales, rot, dens)
+    out = _render(pc, v, gpu)
+    gt = torch.full_like(out["render"], 0.2)
+    loss_img = (out["render"] - gt).abs().mean()
+    q = _query(pc, (0.1, 0.0, -0.1), (32, 32, 32), (0.25, 0.25, 0.25), gpu)
+    vol = q["vol"]
+    tv = ((vol[1:] - vol[:-1]).abs().mean() + (vol[:, 1:] - vol[:, :-1]).abs().mean()
+          + (vol[:, :, 1:] - vol[:, :, :-1]).abs().mean())
+    (loss_img + 0.05 * tv).backward()
+    torch.cuda.synchronize()
+    assert out["render"].shape == (1, 64, 64) and vol.shape == (32, 32, 32)
+    assert len(q["radii"]) == 3 and out["radii"].dtype == torch.int32
+    for p in (_xyz, _scal, _rot, _den):
+        assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # densification statistic input (gaussian_model.py:552-556): NDC-space 2D mean gradient, z == 0
+    vsp = out["viewspace_points"].grad
+    assert vsp is not None and vsp.shape == (P, 3) and not vsp[:, 2].any()
+    assert torch.norm(vsp[out["visibility_filter"], :2], dim=-1).sum() > 0
+
+    # oracle cross-check of the image part of the gradient w.r.t. the ACTIVATED inputs
+    xyz_n, rho_n, sc_n, q_n = (t.detach().cpu().numpy() for t in (_xyz, dens, scales, rot))
+    vm, pm = Hh.np_view(v)
+    o = oracle.raster_forward(xyz_n, rho_n, sc_n, q_n, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, 64, 64, 1)
+    np.testing.assert_allclose(out["render"].detach().cpu().numpy(), o["color"], rtol=1e-4, atol=2e-5)
+    dL = (torch.sign(out["render"].detach() - gt) / gt.numel()).cpu().numpy()
+    go = oracle.raster_backward(o, xyz_n, sc_n, q_n, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
+    Hh.assert_close_scaled(vsp.cpu().numpy(), go["dL_dmeans2D"], rtol=2e-3, name="viewspace grad", atol_frac=2e-5)
+
+
+def test_argument_validation(gpu):
+    from r2_gaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+    v = S.make_view(0.0, (32, 32))
+    rs = GaussianRasterizationSettings(32, 32, v.tanfovx, v.tanfovy, 1.0, v.world_view_transform.to(gpu),
+                                       v.full_proj_transform.to(gpu), v.camera_center.to(gpu), False, 1, False)
+    r = GaussianRasterizer(rs)
+    x = torch.zeros(4, 3, device=gpu)
+    with pytest.raises(Exception, match="exactly one"):
+        r(x, x, torch.ones(4, 1, device=gpu))                       # neither scales/rot nor cov
+    with pytest.raises(Exception, match="exactly one"):
+        r(x, x, torch.ones(4, 1, device=gpu), scales=x, rotations=torch.zeros(4, 4, device=gpu),
+          cov3D_precomp=torch.zeros(4, 6, device=gpu))
+    with pytest.raises(RuntimeError, match="num_points, 3"):
+        r(torch.zeros(4, 2, device=gpu), x, torch.ones(4, 1, device=gpu), scales=x,
+          rotations=torch.zeros(4, 4, device=gpu))
+    with pytest.raises(_lib.R2HipError, match="no CPU fallback"):
+        r(torch.zeros(4, 3), x, torch.ones(4, 1), scales=torch.zeros(4, 3), rotations=torch.zeros(4, 4))
+
+
+def test_large_sizes_properties(gpu):
+    """BASELINE full-size config (300k Gaussians, 512^2): size-independent properties instead of an oracle run --
+    linearity in density, sortedness of the key list, range/list consistency, determinism of the forward."""
+    from r2_gaussian_amd import _C
+    P = 300000
+    c = S.make_cloud(P, seed=0)
+    v = S.make_view(0.4, (512, 512))
+    h1 = Hh.hip_raster(c, v, gpu)
+    h2 = Hh.hip_raster(S.Cloud(c.xyz, c.scales, c.rotations, c.density * 2.0), v, gpu)
+    R = h1["num_rendered"]
+    assert R == h2["num_rendered"] and R > P
+    keys = h1["keys"]
+    assert (keys[1:] >= keys[:-1]).all()                                  # sorted
+    assert np.array_equal(np.sort(h1["point_list"]), np.sort(h1["vals_unsorted"]))   # a permutation
+    rg = h1["ranges"].astype(np.int64)
+    assert (rg[:, 1] - rg[:, 0]).sum() == R                               # ranges tile the list exactly
+    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    nz = rg[:, 1] > rg[:, 0]
+    assert (tiles[rg[nz, 0]] == np.nonzero(nz)[0]).all() and (tiles[rg[nz, 1] - 1] == np.nonzero(nz)[0]).all()
+    assert h1["offsets"][-1] == R and (np.diff(h1["offsets"].astype(np.int64)) == h1["tiles_touched"][1:]).all()
+    # doubling the density doubles every alpha: pairs above the 1e-5 cut-off scale exactly, pairs in
+    # [0.5e-5, 1e-5) newly pass it -> the image is >= 2x, by at most (list length) * 1e-5 per pixel
+    d = h2["color"].astype(np.float64) - 2.0 * h1["color"].astype(np.float64)
+    assert (d >= -1e-4 * h1["color"] - 1e-6).all()
+    assert d.max() <= 1e-5 * (rg[:, 1] - rg[:, 0]).max()
+    h3 = Hh.hip_raster(c, v, gpu)
+    assert np.array_equal(h3["color"], h1["color"])                       # forward is deterministic

@@ -169,6 +169,7 @@ def test_huge_and_tied_gaussians(oracle, gpu):
     v = S.make_view(1.3, (96, 96))
     c = S.make_cloud(300, seed=11)
     xyz = c.xyz.clone(); sc = c.scales.clone(); q = c.rotations.clone(); rho = c.density.clone()
+    xyz[0] = 0.0
     sc[0] = 0.45                      # 3 sigma >> detector: touches all 36 tiles
     xyz[10:20] = xyz[10]              # ten identical centres: identical depth bits
     sc[10:20] = sc[10]; q[10:20] = q[10]
