@@ -150,12 +150,17 @@ R2_API const char *r2_profile_stage_name(int stage);
 R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
 
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
-/* Byte offsets of the private arrays inside the state buffers of the LAST forward call with the
- * given sizes; lets tests read radii/offsets/keys/point_list/ranges back without fixing the layout
- * in the ABI.  which: 0 tiles_touched u32[P], 1 point_offsets u32[P], 2 keys_unsorted u64[R],
- * 3 values_unsorted u32[R], 4 keys_sorted u64[R], 5 point_list u32[R], 6 ranges uint2[T],
- * 7 cov3D f32[6P], 8 n_contrib u32[N] (only filled when forward ran with debug != 0),
- * 9 packed render records f32[8P] (voxelizer: f32[12P]), 10 depths f32[P], 11 mu f32[P] (rasterizer).
+/* Byte offsets of the private arrays inside the state buffers of a forward call with the given sizes; lets
+ * tests read the binning intermediates back without fixing the layout in the ABI.  which:
+ *   0 tiles_touched u32[P]      1 point_offsets u32[P] (inclusive scan over Gaussians in depth order)
+ *   2 tiles_unsorted u32[R]     3 values_unsorted u32[R] (emission: depth-ordered Gaussians, tiles y/x-minor)
+ *   4 tiles_sorted u32[R]       5 point_list u32[R] (== the reference's sorted point_list)
+ *   6 ranges uint2[T]           7 cov3D f32[6P]
+ *   8 n_contrib u32[N] (only filled when forward ran with debug != 0)
+ *   9 packed render records f32[8P] (voxelizer: f32[12P])
+ *  10 depth sort keys u32[P] (bits of the depth; 0xFFFFFFFF for culled Gaussians)
+ *  11 first-instance index u32[P]   12 depth order u32[P] (Gaussian ids sorted by (depth, id))
+ *  13 perm u32[R] (emission index of every sorted instance)
  * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
 R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);
 R2_API long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id);

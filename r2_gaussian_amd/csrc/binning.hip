@@ -1,10 +1,10 @@
-// binning.hip -- prefix sum, stable radix sort and tile-range detection shared by the rasterizer
-// and the voxelizer.  Replaces cub::DeviceScan::InclusiveSum / cub::DeviceRadixSort::SortPairs /
-// identifyTileRanges of the reference (RAS/rasterizer_impl.cu:116-138,275,301-316).
+// binning.hip -- prefix sum, tile-range detection, work-list construction and the stage profiler shared by
+// the rasterizer and the voxelizer.  Replaces cub::DeviceScan::InclusiveSum / identifyTileRanges of the
+// reference (RAS/rasterizer_impl.cu:116-138,275,308-316); the sort lives in radix_sort.hip.
 #include "r2_common.hpp"
 #include <cstring>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
 #include <stdarg.h>
 #include <vector>
 #include <string.h>
@@ -33,7 +33,8 @@ static long long g_cnt[ST_COUNT];
 static const char *const g_stage_names[ST_COUNT] = {
     "raster.preprocess", "raster.scan", "raster.duplicate", "raster.sort", "raster.ranges", "raster.render_fwd",
     "raster.render_bwd", "raster.geom_bwd", "voxel.preprocess", "voxel.scan", "voxel.duplicate", "voxel.sort",
-    "voxel.ranges", "voxel.render_fwd", "voxel.render_bwd", "voxel.geom_bwd", "knn.dist2"};
+    "voxel.ranges", "voxel.render_fwd", "voxel.render_bwd", "voxel.geom_bwd", "knn.dist2", "raster.depth_sort",
+    "voxel.depth_sort"};
 
 static hipEvent_t pool_get()
 {
@@ -84,32 +85,42 @@ int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32
     return 0;
 }
 
-size_t sort_temp_bytes(size_t R)
+struct GatherU32 {
+    const uint32_t *in;
+    __host__ __device__ uint32_t operator()(uint32_t i) const { return in[i]; }
+};
+
+size_t scan_gather_temp_bytes(int P)
 {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, R, 0, 64);
+    auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, GatherU32{nullptr});
+    (void)rocprim::inclusive_scan(nullptr, bytes, it, (uint32_t *)nullptr, (size_t)P, rocprim::plus<uint32_t>());
     return bytes;
 }
 
-int sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
-                       uint32_t *vout, size_t R, int end_bit, hipStream_t s)
+int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
+                              int P, hipStream_t s)
 {
-    R2_HIP_TRY(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, R, 0u, (unsigned)end_bit, s));
+    auto it = rocprim::make_transform_iterator(order, GatherU32{in});
+    R2_HIP_TRY(rocprim::inclusive_scan(temp, temp_bytes, it, out, (size_t)P, rocprim::plus<uint32_t>(), s));
     return 0;
 }
 
 // One thread per sorted instance; a tile boundary writes the end of the previous tile's range and the
 // start of the next one.  ranges must be zeroed first (tiles with no instance keep (0,0)).
-__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__restrict__ keys, uint32_t L,
+__global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__restrict__ tiles,
+                                                          const uint32_t *__restrict__ perm,
+                                                          const uint32_t *__restrict__ vals_unsorted,
+                                                          uint32_t *__restrict__ point_list, uint32_t L,
                                                           uint2 *__restrict__ ranges)
 {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    point_list[idx] = vals_unsorted[perm[idx]];
+    const uint32_t cur = tiles[idx];
     if (idx == 0) ranges[cur].x = 0;
     else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prev = tiles[idx - 1];
         if (cur != prev) {
             ranges[prev].y = idx;
             ranges[cur].x = idx;
@@ -118,12 +129,61 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint64_t *__rest
     if (idx == L - 1) ranges[cur].y = L;
 }
 
-int tile_ranges(const uint64_t *keys_sorted, size_t R, uint2 *ranges, size_t T, hipStream_t s)
+int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
+                size_t R, uint2 *ranges, size_t T, hipStream_t s)
 {
     R2_HIP_TRY(hipMemsetAsync(ranges, 0, T * sizeof(uint2), s));
     if (R > 0)
-        tile_ranges_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(keys_sorted, (uint32_t)R, ranges);
+        tile_ranges_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(tiles_sorted, perm, vals_unsorted,
+                                                                                  point_list, (uint32_t)R, ranges);
     return 0;
+}
+
+// The tile lists are cut into work items of `chunk` instances for the render kernels (load balance).
+// work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
+__global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
+                                                          uint32_t *__restrict__ chunk_base,
+                                                          uint32_t *__restrict__ work_tile)
+{
+    __shared__ uint32_t wsum[16];
+    __shared__ uint32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < T; base += 1024) {
+        const uint32_t t = base + tid;
+        uint32_t n = 0;
+        if (t < T) {
+            const uint2 r = ranges[t];
+            n = (r.y - r.x + chunk - 1) / chunk;
+        }
+        // inclusive scan inside the wave, then across the 16 waves
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t excl = carry + woff + incl - n;
+        if (t < T) {
+            chunk_base[t] = excl;
+            for (uint32_t j = 0; j < n; ++j) work_tile[excl + j] = t;
+        }
+        __syncthreads();
+        if (tid == 1023) carry = excl + n;
+        __syncthreads();
+    }
+    if (tid == 0) chunk_base[T] = carry;
+}
+
+void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint32_t *work_tile,
+                       hipStream_t s)
+{
+    build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile);
 }
 
 }  // namespace r2

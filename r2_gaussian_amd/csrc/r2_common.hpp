@@ -41,7 +41,7 @@ enum Stage {
     ST_RAS_PREPROCESS = 0, ST_RAS_SCAN, ST_RAS_DUPLICATE, ST_RAS_SORT, ST_RAS_RANGES, ST_RAS_RENDER_FWD,
     ST_RAS_RENDER_BWD, ST_RAS_GEOM_BWD,
     ST_VOX_PREPROCESS, ST_VOX_SCAN, ST_VOX_DUPLICATE, ST_VOX_SORT, ST_VOX_RANGES, ST_VOX_RENDER_FWD,
-    ST_VOX_RENDER_BWD, ST_VOX_GEOM_BWD, ST_KNN, ST_COUNT
+    ST_VOX_RENDER_BWD, ST_VOX_GEOM_BWD, ST_KNN, ST_RAS_DEPTHSORT, ST_VOX_DEPTHSORT, ST_COUNT
 };
 extern int g_profile_mask_on;
 void stage_begin(int stage, hipStream_t s);
@@ -72,11 +72,25 @@ struct Bump {
 // ---- binning.hip: scan / stable radix sort / tile ranges (shared by rasterizer and voxelizer)
 size_t scan_temp_bytes(int P);
 int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s);
-size_t sort_temp_bytes(size_t R);
-int sort_pairs_u64_u32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, const uint32_t *vin,
-                       uint32_t *vout, size_t R, int end_bit, hipStream_t s);
-int tile_ranges(const uint64_t *keys_sorted, size_t R, uint2 *ranges, size_t T, hipStream_t s);
+// radix_sort.hip: stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, end_bit).
+// The binning pipeline sorts TWICE instead of once on 64-bit (tile|depth) keys like the reference
+// (RAS/rasterizer_impl.cu:301-306): the P Gaussians by depth bits (ties keep ascending id), then the R
+// instances -- emitted in that depth order -- by tile id only.  A stable sort by tile of a depth-ordered
+// sequence IS the (tile|depth) order with the reference's tie rule, so point_list is bit-identical.
+size_t sort_temp_bytes(size_t n);
+int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
+                       uint32_t *vout, size_t n, int end_bit, hipStream_t s);
+// inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
+size_t scan_gather_temp_bytes(int P);
+int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
+                              int P, hipStream_t s);
+// tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
+int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
+                size_t R, uint2 *ranges, size_t T, hipStream_t s);
 uint32_t higher_msb(uint32_t n);
+// forward work list: tile t owns work items [chunk_base[t], chunk_base[t+1]), one per `chunk` list entries
+void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint32_t *work_tile,
+                       hipStream_t s);
 
 // XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,
 // which share Gaussian records) stay on one XCD's L2 instead of being dealt round-robin over 8.

@@ -35,10 +35,6 @@ extern "C" int r2_raster_forward(
         return R2_ERR_INVALID;
     }
 
-    if (gx > 1023 || gy > 2047) {
-        set_error("r2_raster_forward: detector %dx%d exceeds the packed tile-rectangle range (16368 x 32752 px)", width, height);
-        return R2_ERR_INVALID;
-    }
     char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P).bytes, geometry_user);
     if (!gchunk) {
         set_error("r2_raster_forward: state allocation callback returned NULL");
@@ -51,8 +47,14 @@ extern "C" int r2_raster_forward(
                              projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     int rc;
+    // Gaussians in (depth, id) order; instance runs are then laid out in that order
+    { StageScope t(ST_RAS_DEPTHSORT, s);
+    rc = sort_pairs_u32_u32(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order,
+                            (size_t)P, 32, s); }
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "depth sort");
     { StageScope t(ST_RAS_SCAN, s);
-    rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s); }
+    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
 
@@ -79,13 +81,13 @@ extern "C" int r2_raster_forward(
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         { StageScope t(ST_RAS_SORT, s);
-        rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
-                                bin.point_list, R, 32 + bit, s); }
+        rc = sort_pairs_u32_u32(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.iota, bin.perm, R,
+                                bit, s); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_RAS_RANGES, s);
-    rc = tile_ranges(bin.keys, R, img.ranges, T, s); }
+    rc = tile_ranges(bin.tiles, bin.perm, bin.vals_unsorted, bin.point_list, R, img.ranges, T, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
@@ -152,16 +154,18 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     switch (which) {
     case 0: p = (char *)g.tiles_touched; buf = 0; break;
     case 1: p = (char *)g.offsets; buf = 0; break;
-    case 2: p = (char *)b.keys_unsorted; buf = 1; break;
+    case 2: p = (char *)b.tiles_unsorted; buf = 1; break;
     case 3: p = (char *)b.vals_unsorted; buf = 1; break;
-    case 4: p = (char *)b.keys; buf = 1; break;
+    case 4: p = (char *)b.tiles; buf = 1; break;
     case 5: p = (char *)b.point_list; buf = 1; break;
     case 6: p = (char *)im.ranges; buf = 2; break;
     case 7: p = (char *)g.cov3D; buf = 0; break;
     case 8: p = (char *)im.n_contrib; buf = 2; break;
     case 9: p = (char *)g.rec; buf = 0; break;
-    case 10: p = (char *)g.depths; buf = 0; break;
-    case 11: p = (char *)g.mus; buf = 0; break;
+    case 10: p = (char *)g.depth_key; buf = 0; break;
+    case 12: p = (char *)g.order; buf = 0; break;
+    case 11: p = (char *)g.first; buf = 0; break;
+    case 13: p = (char *)b.perm; buf = 1; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

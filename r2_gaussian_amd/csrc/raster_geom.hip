@@ -76,13 +76,15 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
-    int *__restrict__ radii, float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ mus,
+    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
     radii[idx] = 0;
     tiles_touched[idx] = 0;
+    depth_key[idx] = 0xFFFFFFFFu;   // culled Gaussians sort behind every visible one
+    iota[idx] = (uint32_t)idx;
 
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float3 p_view = xform4x3(p, view);
@@ -124,17 +126,14 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     tile_rect(px, py, (int)my_radius, gx, gy, x0, y0, x1, y1);
     if ((uint32_t)(x1 - x0) * (uint32_t)(y1 - y0) == 0) return;
 
-    depths[idx] = p_view.z;
+    depth_key[idx] = __float_as_uint(p_view.z);   // z > 0.2: float order == unsigned order of the bits
     radii[idx] = (int)my_radius;
     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
     // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
-    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), opacity*mu, then two integer words for the
-    // backward: index of this Gaussian's first instance in the unsorted list (filled by the duplicate
-    // kernel once the scan is known) and its packed tile rectangle.
+    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), then opacity*mu and the two factors.
     const float op = opacities[idx];
-    mus[idx] = mu;
     rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
-    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, 0.f, __uint_as_float(pack_rect(x0, y0, x1 - x0)));
+    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, op, mu);
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -147,35 +146,42 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
     present[idx] = xform4x3(p, view).z <= 0.2f ? 0 : 1;
 }
 
-// (tile | depth) keys + Gaussian ids, emitted y-major/x-minor per Gaussian (RAS/rasterizer_impl.cu:70-111).
-// One WAVE serves 64 consecutive Gaussians: the 64 output runs are contiguous in the key array, so the
-// wave walks that span 64 instances at a time (coalesced 8-byte/4-byte stores) and each lane finds its
-// owner with a 6-step search over the lanes' exclusive offsets (ds_bpermute), instead of every lane
-// dribbling out its own run.
+// Instance emission (the reference's duplicateWithKeys, RAS/rasterizer_impl.cu:70-111), in DEPTH order:
+// sorted position j -> Gaussian order[j] -> its tiles, y-major / x-minor, written at offsets[j-1]...
+// Only the tile id is emitted as the sort key: the list is already depth-ordered, so a stable sort by
+// tile reproduces the reference's (tile | depth) order exactly (see binning.hip).
+// One WAVE serves 64 consecutive sorted positions: their output runs are contiguous, so the wave walks that
+// span 64 instances at a time (coalesced stores) and each lane finds its owner with a 6-step search over
+// the lanes' exclusive offsets (ds_bpermute), instead of every lane dribbling out its own run.
 __global__ void __launch_bounds__(256) raster_duplicate_kernel(
-    int P, float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
-    const int *__restrict__ radii, int gx, int gy, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+    int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
+    const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
+    uint32_t *__restrict__ vals, uint32_t *__restrict__ iota)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave_first = idx - lane;
+    const int wave_first = j - lane;
     if (wave_first >= P) return;
-    const bool live = idx < P && radii[idx] > 0;
+    uint32_t id = 0;
+    int rad = 0;
+    if (j < P) {
+        id = order[j];
+        rad = radii[id];
+    }
+    const bool live = rad > 0;
     // exclusive offset of this lane's run; dead lanes get the running offset so the search stays monotone
     uint32_t excl = 0, incl = 0;
-    if (idx < P) {
-        incl = offsets[idx];
-        excl = idx == 0 ? 0u : offsets[idx - 1];
+    if (j < P) {
+        incl = offsets[j];
+        excl = j == 0 ? 0u : offsets[j - 1];
     } else {
         incl = excl = offsets[P - 1];
     }
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
-    uint32_t dbits = 0;
     if (live) {
-        const float4 r0 = rec[2 * idx];
-        tile_rect(r0.x, r0.y, radii[idx], gx, gy, x0, y0, x1, y1);
-        dbits = __float_as_uint(depths[idx]);
-        reinterpret_cast<uint32_t *>(rec)[8 * idx + 6] = excl;   // first instance index, for the backward scratch
+        const float4 r0 = rec[2 * id];
+        tile_rect(r0.x, r0.y, rad, gx, gy, x0, y0, x1, y1);
+        first[id] = excl;   // where this Gaussian's instance run starts: the backward's scratch rows
     }
     const uint32_t wbeg = __shfl(excl, 0);
     const int last_lane = min(63, P - 1 - wave_first);
@@ -193,13 +199,14 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
         }
         const uint32_t o_excl = __shfl(excl, lo);
         const int o_x0 = __shfl(x0, lo), o_y0 = __shfl(y0, lo), o_rw = __shfl(rw, lo);
-        const uint32_t o_d = __shfl(dbits, lo);
+        const uint32_t o_id = __shfl(id, lo);
         if (k < wend) {
             const uint32_t local = k - o_excl;
             const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
             const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
-            keys[k] = ((uint64_t)(uint32_t)(ty * gx + tx) << 32) | o_d;
-            vals[k] = (uint32_t)(wave_first + lo);
+            tiles[k] = (uint32_t)(ty * gx + tx);
+            vals[k] = o_id;
+            iota[k] = k;
         }
     }
 }
@@ -216,7 +223,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     int P, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
-    const float *__restrict__ proj, const float4 *__restrict__ rec, const float *__restrict__ mus,
+    const float *__restrict__ proj, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
     float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
@@ -227,7 +234,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 
     // ---- 1. moments of w = G * dL/dpix over all tiles of this Gaussian
     const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
-    const uint32_t first = __float_as_uint(rb.z), ninst = tiles_touched[idx];
+    const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
     for (uint32_t j = 0; j < ninst; ++j) {
         const float4 m0 = part[2 * (size_t)(first + j)];
@@ -235,9 +242,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
-    const float mu_f = mus[idx];
-    const float opmu = rb.y;
-    const float op = (mu_f != 0.0f) ? opmu / mu_f : 0.0f;   // only multiplies S0 into dL/dmu; exact value irrelevant when mu == 0 (Q8 zeroes the chain)
+    const float opmu = rb.y, op = rb.z, mu_f = rb.w;
     const float cA = ra.z * (-2.0f * LN2), cB = ra.w * (-LN2), cC = rb.x * (-2.0f * LN2);
     const float g2x = opmu * W_half * (-cA * S1 - cB * S2);
     const float g2y = opmu * H_half * (-cC * S2 - cB * S1);
@@ -363,7 +368,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, c
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depths, g.mus, g.cov3D, g.tiles_touched);
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched);
     return 0;
 }
 
@@ -371,8 +376,9 @@ int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, 
                             hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.depths, g.offsets, radii, gx, gy,
-                                                                        b.keys_unsorted, b.vals_unsorted);
+    raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii, gx, gy,
+                                                                        g.first, b.tiles_unsorted, b.vals_unsorted,
+                                                                        b.iota);
     return 0;
 }
 
@@ -393,7 +399,7 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
     const float h_x = W / (2.0f * tan_fovx);
     raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
-        g.mus, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
+        g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
         dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }

@@ -32,46 +32,6 @@ namespace r2 {
 constexpr float ALPHA_MIN_2D = 0.00001f;   // RAS/forward.cu:374
 
 // ------------------------------------------------------------------------------------------------ forward
-// work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
-__global__ void __launch_bounds__(1024) raster_build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T,
-                                                                 uint32_t *__restrict__ chunk_base,
-                                                                 uint32_t *__restrict__ work_tile)
-{
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < T; base += 1024) {
-        const uint32_t t = base + tid;
-        uint32_t n = 0;
-        if (t < T) {
-            const uint2 r = ranges[t];
-            n = (r.y - r.x + FWD_CHUNK - 1) / FWD_CHUNK;
-        }
-        // inclusive scan inside the wave, then across the 16 waves
-        uint32_t incl = n;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d);
-            if (lane >= d) incl += up;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        const uint32_t excl = carry + woff + incl - n;
-        if (t < T) {
-            chunk_base[t] = excl;
-            for (uint32_t j = 0; j < n; ++j) work_tile[excl + j] = t;
-        }
-        __syncthreads();
-        if (tid == 1023) carry = excl + n;
-        __syncthreads();
-    }
-    if (tid == 0) chunk_base[T] = carry;
-}
-
 template <bool NCONTRIB>
 __global__ void __launch_bounds__(256) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
@@ -206,8 +166,8 @@ __device__ __forceinline__ void tile_moments_gather(const float4 a, const float4
 }
 
 __global__ void __launch_bounds__(256) raster_render_backward_kernel(
-    const uint64_t *__restrict__ keys, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
-    uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
+    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ perm,
+    const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
 {
     __shared__ float4 gtile[4][64];   // one 16x16 dL/dpix block per wave
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
@@ -218,7 +178,7 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
     uint32_t tile = 0xffffffffu, id = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
     if (live) {
-        tile = (uint32_t)(keys[k] >> 32);
+        tile = tiles[k];
         id = point_list[k];
         a = rec[2 * id];
         b = rec[2 * id + 1];
@@ -261,10 +221,8 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
         }
     }
     if (live) {
-        // scratch row of this instance: first instance of the Gaussian + position of the tile in its rectangle
-        const uint32_t first = __float_as_uint(b.z), rp = __float_as_uint(b.w);
-        const uint32_t rx0 = rp & 2047u, ry0 = (rp >> 11) & 2047u, rw = rp >> 22;
-        const uint32_t u = first + (tile / gx - ry0) * rw + (tile % gx - rx0);
+        // scratch row = the instance's position in the emission list (the sort carried it as payload)
+        const uint32_t u = perm[k];
         part[2 * (size_t)u] = make_float4(S[0], S[1], S[2], S[3]);
         part[2 * (size_t)u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
@@ -276,7 +234,7 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
-    raster_build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(im.ranges, T, im.chunk_base, im.work_tile);
+    launch_build_work(im.ranges, T, FWD_CHUNK, im.chunk_base, im.work_tile, s);
     if (im.NW > 0) {
         if (write_ncontrib)
             raster_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
@@ -301,7 +259,7 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, i
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.keys, b.point_list, g.rec, (uint32_t)R, W, H, gx,
+    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, b.perm, g.rec, (uint32_t)R, W, H, gx,
                                                                    nchunks, dL_dpix,
                                                                    reinterpret_cast<float4 *>(b.part));
     return 0;

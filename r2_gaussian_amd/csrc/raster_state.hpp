@@ -10,42 +10,50 @@ namespace r2 {
 constexpr uint32_t FWD_CHUNK = 512;   // instances of one tile list rendered by one workgroup (load balance)
 constexpr int PART_STRIDE = 8;        // floats per instance in the backward moment scratch (6 used)
 
-// packed tile rectangle of a Gaussian: x0 (11 bits) | y0 (11 bits) | width in tiles (10 bits)
-__host__ __device__ inline uint32_t pack_rect(int x0, int y0, int rw) { return (uint32_t)x0 | ((uint32_t)y0 << 11) | ((uint32_t)rw << 22); }
-
 struct RasterGeom {
-    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, op*mu, bits(first instance index), bits(pack_rect)}
-                              //       (A2,B2,C2: conic * -log2e/2, -log2e, -log2e/2)
-    float *depths;            // [P]   view-space z (sort key low word)
-    float *mus;               // [P]   ray-integration factor mu (kept for inspection / parity tests)
+    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, op*mu, op, mu}   (A2,B2,C2: conic * -log2e/2, -log2e, -log2e/2)
+    uint32_t *depth_key;      // [P]   bits of view-space z (positive floats order like unsigned ints); 0xFFFFFFFF = culled
+    uint32_t *iota;           // [P]   0..P-1, value input of the depth sort
+    uint32_t *depth_sorted;   // [P]   sorted depth keys (unused afterwards)
+    uint32_t *order;          // [P]   Gaussian ids in (depth, id) order; culled ones last
+    uint32_t *first;          // [P]   index of the Gaussian's first instance in the unsorted (emission) list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
-    uint32_t *offsets;        // [P]   inclusive scan of tiles_touched
+    uint32_t *offsets;        // [P]   inclusive scan of tiles_touched[order[j]]: instance runs in depth order
     char *scan_temp;
     size_t scan_bytes;
+    char *psort_temp;
+    size_t psort_bytes;
     size_t bytes;
     static RasterGeom carve(char *chunk, int P)
     {
         RasterGeom g;
         Bump b(chunk);
         g.rec = b.take<float4>(2 * (size_t)P);
-        g.depths = b.take<float>(P);
-        g.mus = b.take<float>(P);
+        g.depth_key = b.take<uint32_t>(P);
+        g.iota = b.take<uint32_t>(P);
+        g.depth_sorted = b.take<uint32_t>(P);
+        g.order = b.take<uint32_t>(P);
+        g.first = b.take<uint32_t>(P);
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
-        g.scan_bytes = scan_temp_bytes(P);
+        g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
+        g.psort_bytes = sort_temp_bytes((size_t)P);
+        g.psort_temp = b.take<char>(g.psort_bytes);
         g.bytes = b.total();
         return g;
     }
 };
 
 struct RasterBinning {
-    uint64_t *keys_unsorted;  // [R]
-    uint64_t *keys;           // [R]
-    uint32_t *vals_unsorted;  // [R]
-    uint32_t *point_list;     // [R]
+    uint32_t *tiles_unsorted; // [R]  tile id of every instance, emitted Gaussian by Gaussian in depth order
+    uint32_t *tiles;          // [R]  the same, stably sorted by tile == (tile|depth) order of the reference
+    uint32_t *vals_unsorted;  // [R]  Gaussian id of every instance (emission order)
+    uint32_t *iota;           // [R]  0..R-1: the sort payload is the emission index itself ...
+    uint32_t *perm;           // [R]  ... so perm[k] = emission index of sorted position k (backward scratch row)
+    uint32_t *point_list;     // [R]  sorted Gaussian ids = vals_unsorted[perm[k]] (the reference's point_list, bit-identical)
     float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by UNSORTED position
     char *sort_temp;
     size_t sort_bytes;
@@ -54,9 +62,11 @@ struct RasterBinning {
     {
         RasterBinning s;
         Bump b(chunk);
-        s.keys_unsorted = b.take<uint64_t>(R);
-        s.keys = b.take<uint64_t>(R);
+        s.tiles_unsorted = b.take<uint32_t>(R);
+        s.tiles = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
+        s.iota = b.take<uint32_t>(R);
+        s.perm = b.take<uint32_t>(R);
         s.point_list = b.take<uint32_t>(R);
         s.part = b.take<float>(R * PART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);

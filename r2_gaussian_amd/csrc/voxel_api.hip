@@ -45,21 +45,24 @@ extern "C" int r2_voxel_forward(
         return R2_ERR_INVALID;
     }
     char *gchunk = geometryBuffer(VoxelGeom::carve(nullptr, P).bytes, geometry_user);
-    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, debug != 0).bytes, image_user);
-    if (!gchunk || !ichunk) {
+    if (!gchunk) {
         set_error("r2_voxel_forward: state allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
-    const VoxelImage img = VoxelImage::carve(ichunk, T, V, debug != 0);
 
     { StageScope t(ST_VOX_PREPROCESS, s);
     launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
                             radii_y, radii_z, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     int rc;
+    { StageScope t(ST_VOX_DEPTHSORT, s);
+    rc = sort_pairs_u32_u32(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order,
+                            (size_t)P, 32, s); }
+    if (rc) return rc;
+    R2_STAGE_CHECK(debug, s, "depth sort");
     { StageScope t(ST_VOX_SCAN, s);
-    rc = inclusive_scan_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.offsets, P, s); }
+    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
     uint32_t num_rendered = 0;
@@ -68,24 +71,26 @@ extern "C" int r2_voxel_forward(
     const size_t R = num_rendered;
 
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
-    if (!bchunk) {
-        set_error("r2_voxel_forward: binning allocation callback returned NULL");
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, debug != 0).bytes, image_user);
+    if (!bchunk || !ichunk) {
+        set_error("r2_voxel_forward: binning/image allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0);
     if (R > 0) {
         { StageScope t(ST_VOX_DUPLICATE, s);
         launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         { StageScope t(ST_VOX_SORT, s);
-        rc = sort_pairs_u64_u32(bin.sort_temp, bin.sort_bytes, bin.keys_unsorted, bin.keys, bin.vals_unsorted,
-                                bin.point_list, R, 32 + bit, s); }
+        rc = sort_pairs_u32_u32(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.iota, bin.perm, R,
+                                bit, s); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_VOX_RANGES, s);
-    rc = tile_ranges(bin.keys, R, img.ranges, T, s); }
+    rc = tile_ranges(bin.tiles, bin.perm, bin.vals_unsorted, bin.point_list, R, img.ranges, T, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_VOX_RENDER_FWD, s);
@@ -116,13 +121,13 @@ extern "C" int r2_voxel_backward(
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
     { StageScope t(ST_VOX_RENDER_BWD, s);
-    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, dL_dmean3D_norm, dL_dconic3D, dL_dopacity, s); }
+    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, s); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_VOX_GEOM_BWD, s);
-    launch_voxel_geom_backward(v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
-                               cov3D_precomp ? nullptr : rotations, scale_modifier, dL_dconic3D, dL_dmean3D_norm,
-                               dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
+    launch_voxel_geom_backward(geom, v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
+                               cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, dL_dconic3D,
+                               dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }
@@ -133,21 +138,24 @@ extern "C" long long r2_voxel_state_offset(int which, int P, long long R, int nx
     const VoxelGrid v = make_grid(nx, ny, nz, 1, 1, 1, 0, 0, 0);
     const VoxelGeom g = VoxelGeom::carve(base, P);
     const VoxelBinning b = VoxelBinning::carve(base, (size_t)R);
-    const VoxelImage im = VoxelImage::carve(base, (size_t)v.gx * v.gy * v.gz, (size_t)nx * ny * nz, true);
+    const VoxelImage im = VoxelImage::carve(base, (size_t)v.gx * v.gy * v.gz, (size_t)nx * ny * nz, (size_t)R, true);
     const char *p = nullptr;
     int buf = -1;
     switch (which) {
     case 0: p = (char *)g.tiles_touched; buf = 0; break;
     case 1: p = (char *)g.offsets; buf = 0; break;
-    case 2: p = (char *)b.keys_unsorted; buf = 1; break;
+    case 2: p = (char *)b.tiles_unsorted; buf = 1; break;
     case 3: p = (char *)b.vals_unsorted; buf = 1; break;
-    case 4: p = (char *)b.keys; buf = 1; break;
+    case 4: p = (char *)b.tiles; buf = 1; break;
     case 5: p = (char *)b.point_list; buf = 1; break;
     case 6: p = (char *)im.ranges; buf = 2; break;
     case 7: p = (char *)g.cov3D; buf = 0; break;
     case 8: p = (char *)im.n_contrib; buf = 2; break;
     case 9: p = (char *)g.rec; buf = 0; break;
-    case 10: p = (char *)g.depths; buf = 0; break;
+    case 10: p = (char *)g.depth_key; buf = 0; break;
+    case 11: p = (char *)g.first; buf = 0; break;
+    case 12: p = (char *)g.order; buf = 0; break;
+    case 13: p = (char *)b.perm; buf = 1; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

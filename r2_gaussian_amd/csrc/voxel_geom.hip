@@ -33,8 +33,8 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
-    float4 *__restrict__ rec, float *__restrict__ depths, float *__restrict__ cov3Ds,
-    uint32_t *__restrict__ tiles_touched)
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -44,6 +44,11 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     tiles_touched[idx] = 0;
     const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    // low sort word of the reference: the raw bits of world z ("just give a value", VOX/forward.cu:166; as
+    // unsigned ints, negative z sorts after positive -- quirk Q10).  Culled Gaussians emit nothing, so their
+    // position in the depth order is irrelevant.
+    depth_key[idx] = __float_as_uint(p.z);
+    iota[idx] = (uint32_t)idx;
 
     float cov3D[6];
     if (cov3D_precomp != nullptr) {
@@ -87,38 +92,44 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     radii_y[idx] = (int)rad.y;
     radii_z[idx] = (int)rad.z;
     tiles_touched[idx] = n;
-    depths[idx] = p.z;
     rec[3 * idx] = make_float4(pv.x, pv.y, pv.z, opacities[idx]);
     rec[3 * idx + 1] = make_float4((-0.5f * LOG2E) * inv_a, (-LOG2E) * inv_b, (-LOG2E) * inv_c, (-0.5f * LOG2E) * inv_d);
     rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, 0.f, 0.f);
 }
 
-// (tile | depth) keys, z-major / y / x-minor per Gaussian (VOX/voxelizer_impl.cu:54-101); one wave serves
-// 64 consecutive Gaussians and walks their contiguous output span with coalesced stores (see raster_geom.hip).
+// Instance emission (duplicateWithKeys, VOX/voxelizer_impl.cu:54-101) in DEPTH order: sorted position j ->
+// Gaussian order[j] -> its tiles z-major / y / x-minor.  Only the tile id is the sort key (see binning.hip).
+// One wave serves 64 consecutive sorted positions and walks their contiguous output span with coalesced
+// stores (see raster_geom.hip).
 __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
-    int P, const float4 *__restrict__ rec, const float *__restrict__ depths, const uint32_t *__restrict__ offsets,
+    int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
-    int gz, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals)
+    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
+    uint32_t *__restrict__ iota)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int wave_first = idx - lane;
+    const int wave_first = j - lane;
     if (wave_first >= P) return;
-    const bool live = idx < P && radii_x[idx] > 0 && radii_y[idx] > 0 && radii_z[idx] > 0;
+    uint32_t id = 0;
+    int rx = 0, ry = 0, rz = 0;
+    if (j < P) {
+        id = order[j];
+        rx = radii_x[id]; ry = radii_y[id]; rz = radii_z[id];
+    }
+    const bool live = rx > 0 && ry > 0 && rz > 0;
     uint32_t excl, incl;
-    if (idx < P) {
-        incl = offsets[idx];
-        excl = idx == 0 ? 0u : offsets[idx - 1];
+    if (j < P) {
+        incl = offsets[j];
+        excl = j == 0 ? 0u : offsets[j - 1];
     } else {
         incl = excl = offsets[P - 1];
     }
     int3 lo = make_int3(0, 0, 0), hi = lo;
-    uint32_t dbits = 0;
     if (live) {
-        const float4 r0 = rec[3 * idx];
-        tile_cube(make_float3(r0.x, r0.y, r0.z),
-                  make_float3((float)radii_x[idx], (float)radii_y[idx], (float)radii_z[idx]), gx, gy, gz, lo, hi);
-        dbits = __float_as_uint(depths[idx]);
+        const float4 r0 = rec[3 * id];
+        tile_cube(make_float3(r0.x, r0.y, r0.z), make_float3((float)rx, (float)ry, (float)rz), gx, gy, gz, lo, hi);
+        first[id] = excl;
     }
     const uint32_t wbeg = __shfl(excl, 0);
     const int last_lane = min(63, P - 1 - wave_first);
@@ -136,7 +147,7 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
         const uint32_t o_excl = __shfl(excl, own);
         const int ox = __shfl(lo.x, own), oy = __shfl(lo.y, own), oz = __shfl(lo.z, own);
         const int orw = __shfl(rw, own), orh = __shfl(rh, own);
-        const uint32_t o_d = __shfl(dbits, own);
+        const uint32_t o_id = __shfl(id, own);
         if (k < wend) {
             const uint32_t local = k - o_excl;
             const uint32_t xy = (uint32_t)orw * (uint32_t)orh;
@@ -144,28 +155,64 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
             const uint32_t rem = local % xy;
             const int y = oy + (int)(rem / (uint32_t)orw);
             const int x = ox + (int)(rem % (uint32_t)orw);
-            keys[k] = ((uint64_t)(uint32_t)(z * gy * gx + y * gx + x) << 32) | o_d;
-            vals[k] = (uint32_t)(wave_first + own);
+            tiles[k] = (uint32_t)(z * gy * gx + y * gx + x);
+            vals[k] = o_id;
+            iota[k] = k;
         }
     }
 }
 
-// computeCov3DCUDA (VOX/backward.cu:86-177) + preprocessCUDA backward (VOX/backward.cu:180-213), fused.
+// Fused geometry backward, one pass per Gaussian:
+//   1. reduce the per-instance moment rows of the render backward (contiguous run in the emission list),
+//      fixed order -> deterministic, atomic-free (reference: 10 float atomicAdd per pair, VOX/backward.cu:359-370);
+//   2. moments -> dL/dmean3D_norm (x dVoxel, quirk Q4), dL/dconic3D, dL/dopacity;
+//   3. computeCov3DCUDA (VOX/backward.cu:86-177) + preprocessCUDA backward (VOX/backward.cu:180-213).
 __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     int P, const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
     const float *__restrict__ cov3Ds, const float *__restrict__ scales, const float *__restrict__ rotations,
-    float scale_modifier, VoxelGrid v, const float *__restrict__ dL_dconic3D, const float *__restrict__ dL_dmean3D_norm,
-    float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov, float *__restrict__ dL_dscale,
-    float *__restrict__ dL_drot)
+    float scale_modifier, VoxelGrid v, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
+    const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float *__restrict__ dL_dconic3D,
+    float *__restrict__ dL_dmean3D_norm, float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans,
+    float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P || !(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) return;
     const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+
+    // ---- 1. moments: S0, (Sx,Sy,Sz), (Sxx,Sxy,Sxz,Syy,Syz,Szz)
+    const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
+    float S[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) S[k] = 0.f;
+    for (uint32_t j = 0; j < ninst; ++j) {
+        const float4 m0 = part[3 * (size_t)(first + j)];
+        const float4 m1 = part[3 * (size_t)(first + j) + 1];
+        const float4 m2 = part[3 * (size_t)(first + j) + 2];
+        S[0] += m0.x; S[1] += m0.y; S[2] += m0.z; S[3] += m0.w;
+        S[4] += m1.x; S[5] += m1.y; S[6] += m1.z; S[7] += m1.w;
+        S[8] += m2.x; S[9] += m2.y;
+    }
+    // ---- 2. the reference's accumulated sums (VOX/backward.cu:345-370), inverse covariance un-scaled
+    const float4 r0 = rec[3 * idx], r1 = rec[3 * idx + 1], r2 = rec[3 * idx + 2];
+    const float opa = r0.w;
+    const float ia = r1.x * (-2.0f * LN2), ib = r1.y * (-LN2), ic = r1.z * (-LN2);
+    const float id_ = r1.w * (-2.0f * LN2), ie = r2.x * (-LN2), if_ = r2.y * (-2.0f * LN2);
+    const float gmx = opa * dvx * (-ia * S[1] - ib * S[2] - ic * S[3]);
+    const float gmy = opa * dvy * (-id_ * S[2] - ib * S[1] - ie * S[3]);
+    const float gmz = opa * dvz * (-if_ * S[3] - ic * S[1] - ie * S[2]);
+    const float ga = -0.5f * opa * S[4], gb = -opa * S[5], gc = -opa * S[6];
+    const float gd = -0.5f * opa * S[7], ge = -opa * S[8], gf = -0.5f * opa * S[9];
+    dL_dmean3D_norm[3 * idx + 0] = gmx;
+    dL_dmean3D_norm[3 * idx + 1] = gmy;
+    dL_dmean3D_norm[3 * idx + 2] = gmz;
+    dL_dconic3D[6 * idx + 0] = ga; dL_dconic3D[6 * idx + 1] = gb; dL_dconic3D[6 * idx + 2] = gc;
+    dL_dconic3D[6 * idx + 3] = gd; dL_dconic3D[6 * idx + 4] = ge; dL_dconic3D[6 * idx + 5] = gf;
+    dL_dopacity[idx] = S[0];
+
+    // ---- 3. geometry chain
     float cov3D[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
-    const float ga = dL_dconic3D[6 * idx + 0], gb = dL_dconic3D[6 * idx + 1], gc = dL_dconic3D[6 * idx + 2];
-    const float gd = dL_dconic3D[6 * idx + 3], ge = dL_dconic3D[6 * idx + 4], gf = dL_dconic3D[6 * idx + 5];
     M3 M;
     float h[6];
     voxel_cov(cov3D, dvx, dvy, dvz, M, h);
@@ -193,8 +240,9 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = o[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) dL_dmeans[3 * idx + k] = dL_dmean3D_norm[3 * idx + k];   // zero-init + "+=" in the reference
+    dL_dmeans[3 * idx + 0] = gmx;   // zero-init + "+= dL_dmean3D_norm" in the reference
+    dL_dmeans[3 * idx + 1] = gmy;
+    dL_dmeans[3 * idx + 2] = gmz;
     if (scales != nullptr && rotations != nullptr) {
         float ds[3];
         float4 dq;
@@ -213,7 +261,7 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
 {
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
-                                                                        radii_z, g.rec, g.depths, g.cov3D,
+                                                                        radii_z, g.rec, g.depth_key, g.iota, g.cov3D,
                                                                         g.tiles_touched);
     return 0;
 }
@@ -221,21 +269,22 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, hipStream_t s)
 {
-    voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.depths, g.offsets, radii_x, radii_y,
-                                                                       radii_z, v.gx, v.gy, v.gz, b.keys_unsorted,
-                                                                       b.vals_unsorted);
+    voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii_x, radii_y,
+                                                                       radii_z, v.gx, v.gy, v.gz, g.first,
+                                                                       b.tiles_unsorted, b.vals_unsorted, b.iota);
     return 0;
 }
 
-int launch_voxel_geom_backward(const VoxelGrid &v, int P, const int *radii_x, const int *radii_y, const int *radii_z,
-                               const float *cov3D, const float *scales, const float *rotations, float scale_modifier,
-                               const float *dL_dconic3D, const float *dL_dmean3D_norm, float *dL_dmean3D,
-                               float *dL_dcov3D, float *dL_dscale, float *dL_drot, hipStream_t s)
+int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
+                               const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
+                               float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
+                               float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
+                               hipStream_t s)
 {
-    voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, radii_x, radii_y, radii_z, cov3D, scales,
-                                                                           rotations, scale_modifier, v, dL_dconic3D,
-                                                                           dL_dmean3D_norm, dL_dmean3D, dL_dcov3D,
-                                                                           dL_dscale, dL_drot);
+    voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, g.tiles_touched,
+        reinterpret_cast<const float4 *>(part), dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D,
+        dL_dscale, dL_drot);
     return 0;
 }
 

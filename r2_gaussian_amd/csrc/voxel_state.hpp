@@ -5,35 +5,53 @@
 
 namespace r2 {
 
+constexpr uint32_t VOX_CHUNK = 1024;  // instances of one tile list evaluated by one workgroup (load balance)
+constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
+
 struct VoxelGeom {
     float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,-,-}: inverse covariance
                               //      (xx,xy,xz,yy,yz,zz) pre-scaled by -log2e/2 (diagonal) or -log2e (off-diagonal)
-    float *depths;            // [P]  world z, the arbitrary low sort word of the reference (Q10)
+    uint32_t *depth_key;      // [P]  bits of world z, the arbitrary low sort word of the reference (Q10); 
+    uint32_t *iota;           // [P]
+    uint32_t *depth_sorted;   // [P]
+    uint32_t *order;          // [P]  Gaussian ids in (z bits, id) order
+    uint32_t *first;          // [P]  first instance of the Gaussian in the emission list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
-    uint32_t *offsets;        // [P]
+    uint32_t *offsets;        // [P]  inclusive scan of tiles_touched[order[j]]
     char *scan_temp;
     size_t scan_bytes;
+    char *psort_temp;
+    size_t psort_bytes;
     size_t bytes;
     static VoxelGeom carve(char *chunk, int P)
     {
         VoxelGeom g;
         Bump b(chunk);
         g.rec = b.take<float4>(3 * (size_t)P);
-        g.depths = b.take<float>(P);
+        g.depth_key = b.take<uint32_t>(P);
+        g.iota = b.take<uint32_t>(P);
+        g.depth_sorted = b.take<uint32_t>(P);
+        g.order = b.take<uint32_t>(P);
+        g.first = b.take<uint32_t>(P);
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
-        g.scan_bytes = scan_temp_bytes(P);
+        g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
+        g.psort_bytes = sort_temp_bytes((size_t)P);
+        g.psort_temp = b.take<char>(g.psort_bytes);
         g.bytes = b.total();
         return g;
     }
 };
 
 struct VoxelBinning {
-    uint64_t *keys_unsorted, *keys;
-    uint32_t *vals_unsorted, *point_list;
+    uint32_t *tiles_unsorted, *tiles;   // [R]
+    uint32_t *vals_unsorted;            // [R] Gaussian id per instance (emission order)
+    uint32_t *iota, *perm;              // [R] sort payload = emission index
+    uint32_t *point_list;               // [R]
+    float *part;                        // [R*VPART_STRIDE] backward scratch
     char *sort_temp;
     size_t sort_bytes;
     size_t bytes;
@@ -41,10 +59,13 @@ struct VoxelBinning {
     {
         VoxelBinning s;
         Bump b(chunk);
-        s.keys_unsorted = b.take<uint64_t>(R);
-        s.keys = b.take<uint64_t>(R);
+        s.tiles_unsorted = b.take<uint32_t>(R);
+        s.tiles = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
+        s.iota = b.take<uint32_t>(R);
+        s.perm = b.take<uint32_t>(R);
         s.point_list = b.take<uint32_t>(R);
+        s.part = b.take<float>(R * VPART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);
         s.sort_temp = b.take<char>(s.sort_bytes);
         s.bytes = b.total();
@@ -53,15 +74,25 @@ struct VoxelBinning {
 };
 
 struct VoxelImage {
-    uint2 *ranges;        // [T3]
-    uint32_t *n_contrib;  // [V], debug only
+    uint2 *ranges;          // [T3]
+    uint32_t *chunk_base;   // [T3+1]
+    uint32_t *work_tile;    // [NW]
+    float *partial;         // [NW*512]
+    uint32_t *partial_last; // [NW*512] debug only
+    uint32_t *n_contrib;    // [V], debug only
+    size_t NW;
     size_t bytes;
-    static VoxelImage carve(char *chunk, size_t T, size_t V, bool with_ncontrib)
+    static VoxelImage carve(char *chunk, size_t T, size_t V, size_t R, bool debug)
     {
         VoxelImage s;
         Bump b(chunk);
+        s.NW = R / VOX_CHUNK + T;
         s.ranges = b.take<uint2>(T);
-        s.n_contrib = b.take<uint32_t>(with_ncontrib ? V : 0);
+        s.chunk_base = b.take<uint32_t>(T + 1);
+        s.work_tile = b.take<uint32_t>(s.NW);
+        s.partial = b.take<float>(s.NW * 512);
+        s.partial_last = b.take<uint32_t>(debug ? s.NW * 512 : 0);
+        s.n_contrib = b.take<uint32_t>(debug ? V : 0);
         s.bytes = b.total();
         return s;
     }
@@ -79,14 +110,15 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, hipStream_t s);
-int launch_voxel_geom_backward(const VoxelGrid &v, int P, const int *radii_x, const int *radii_y, const int *radii_z,
-                               const float *cov3D, const float *scales, const float *rotations, float scale_modifier,
-                               const float *dL_dconic3D, const float *dL_dmean3D_norm, float *dL_dmean3D,
-                               float *dL_dcov3D, float *dL_dscale, float *dL_drot, hipStream_t s);
+int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
+                               const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
+                               float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
+                               float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
+                               hipStream_t s);
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,
                                 float *out_volume, bool write_ncontrib, hipStream_t s);
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
-                                 const float *dL_dvol, float *dL_dmean3D_norm, float *dL_dconic3D, float *dL_dopacity,
-                                 hipStream_t s);
+                                 const float *dL_dvol, hipStream_t s);
+
 
 }  // namespace r2

@@ -55,9 +55,9 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
 
     out["tiles_touched"] = read(0, np.uint32, P)
     out["offsets"] = read(1, np.uint32, P)
-    out["keys_unsorted"] = read(2, np.uint64, R)
+    out["tiles_unsorted"] = read(2, np.uint32, R)
     out["vals_unsorted"] = read(3, np.uint32, R)
-    out["keys"] = read(4, np.uint64, R)
+    out["tiles"] = read(4, np.uint32, R)
     out["point_list"] = read(5, np.uint32, R)
     out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
     out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
@@ -65,11 +65,18 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
         out["n_contrib"] = read(8, np.uint32, H * W)
     rec = read(9, np.float32, 8 * P).reshape(P, 8)
     out["rec"] = rec
-    out["depths"] = read(10, np.float32, P)
+    out["depth_key"] = read(10, np.uint32, P)
+    out["depths"] = out["depth_key"].view(np.float32)
+    out["first"] = read(11, np.uint32, P)
+    out["order"] = read(12, np.uint32, P)
+    out["perm"] = read(13, np.uint32, R)
+    # the reference's 64-bit sort keys, reconstructed: (tile << 32) | depth bits of the listed Gaussian
+    out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     # decode the packed render record back to the reference's quantities
     out["means2D"] = rec[:, 0:2]
     out["conic"] = np.stack([rec[:, 2] / (-0.5 * LOG2E), rec[:, 3] / (-LOG2E), rec[:, 4] / (-0.5 * LOG2E)], 1)
-    out["mus"] = read(11, np.float32, P)
+    out["mus"] = rec[:, 7]
+    out["opacity"] = rec[:, 6]
     return out
 
 
@@ -118,14 +125,19 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
 
     out["tiles_touched"] = read(0, np.uint32, P)
     out["offsets"] = read(1, np.uint32, P)
-    out["keys_unsorted"] = read(2, np.uint64, R)
+    out["tiles_unsorted"] = read(2, np.uint32, R)
     out["vals_unsorted"] = read(3, np.uint32, R)
-    out["keys"] = read(4, np.uint64, R)
+    out["tiles"] = read(4, np.uint32, R)
     out["point_list"] = read(5, np.uint32, R)
     out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
     out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
     if debug:
         out["n_contrib"] = read(8, np.uint32, nx * ny * nz)
+    out["depth_key"] = read(10, np.uint32, P)
+    out["first"] = read(11, np.uint32, P)
+    out["order"] = read(12, np.uint32, P)
+    out["perm"] = read(13, np.uint32, R)
+    out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     rec = read(9, np.float32, 12 * P).reshape(P, 12)
     out["rec"] = rec
     out["means3D_norm"] = rec[:, 0:3]
@@ -164,3 +176,38 @@ def assert_close_scaled(a, b, rtol, name, atol_frac=1e-6):
 
 def ellipsoid_cloud(P, seed=0, scale_mult=1.0):
     return S.make_cloud(P, seed=seed, scale_mult=scale_mult)
+
+
+def check_binning(h, o):
+    """Bit-exact comparison of the binning pipeline with the oracle.  The HIP path sorts the Gaussians by depth
+    first and emits instances in that order (then sorts by tile only), so its UNSORTED arrays are a per-Gaussian
+    permutation of the reference's; everything the reference defines -- per-Gaussian tile runs, the sorted
+    (tile|depth) key list, point_list, ranges -- must match exactly."""
+    P = o["P"]
+    assert h["num_rendered"] == o["num_rendered"]
+    R = o["num_rendered"]
+    assert np.array_equal(h["tiles_touched"], o["tiles_touched"])
+    tt = o["tiles_touched"].astype(np.int64)
+    # depth order: stable argsort of the depth bits; culled Gaussians emit nothing so only visible order matters
+    vis = tt > 0
+    order = h["order"].astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(P))
+    ov = order[vis[order]]
+    dk = o["depths"].view(np.uint32)
+    ref_ov = np.nonzero(vis)[0][np.argsort(dk[vis], kind="stable")]
+    assert np.array_equal(ov, ref_ov), "depth order differs"
+    assert np.array_equal(h["offsets"].astype(np.int64), np.cumsum(tt[order]))
+    # per-Gaussian runs: same tiles in the same (y-major / x-minor) order as the reference's emission
+    o_start = o["offsets"].astype(np.int64) - tt
+    h_start = h["first"].astype(np.int64)
+    ids = np.repeat(np.arange(P), tt)
+    within = np.arange(R) - np.repeat(np.cumsum(tt) - tt, tt)
+    o_tiles = (o["keys_unsorted"] >> np.uint64(32)).astype(np.uint32)[o_start[ids] + within]
+    h_idx = h_start[ids] + within
+    assert np.array_equal(h["tiles_unsorted"][h_idx], o_tiles), "emitted tile runs differ"
+    assert np.array_equal(h["vals_unsorted"][h_idx], ids.astype(np.uint32))
+    # the sorted list is the reference's, bit for bit
+    assert np.array_equal(h["keys"], o["keys"]), "sorted (tile|depth) keys differ"
+    assert np.array_equal(h["point_list"], o["point_list"]), "point_list differs"
+    assert np.array_equal(h["ranges"], o["ranges"]), "ranges differ"
+    assert np.array_equal(h["vals_unsorted"][h["perm"]], h["point_list"])

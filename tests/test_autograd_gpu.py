@@ -117,10 +117,11 @@ def test_large_sizes_properties(gpu):
     assert np.array_equal(np.sort(h1["point_list"]), np.sort(h1["vals_unsorted"]))   # a permutation
     rg = h1["ranges"].astype(np.int64)
     assert (rg[:, 1] - rg[:, 0]).sum() == R                               # ranges tile the list exactly
-    tiles = (keys >> np.uint64(32)).astype(np.int64)
+    tiles = h1["tiles"].astype(np.int64)
     nz = rg[:, 1] > rg[:, 0]
     assert (tiles[rg[nz, 0]] == np.nonzero(nz)[0]).all() and (tiles[rg[nz, 1] - 1] == np.nonzero(nz)[0]).all()
-    assert h1["offsets"][-1] == R and (np.diff(h1["offsets"].astype(np.int64)) == h1["tiles_touched"][1:]).all()
+    assert h1["offsets"][-1] == R
+    assert (np.diff(h1["offsets"].astype(np.int64)) == h1["tiles_touched"][h1["order"]][1:]).all()
     # doubling the density doubles every alpha: pairs above the 1e-5 cut-off scale exactly, pairs in
     # [0.5e-5, 1e-5) newly pass it -> the image is >= 2x, by at most (list length) * 1e-5 per pixel
     d = h2["color"].astype(np.float64) - 2.0 * h1["color"].astype(np.float64)

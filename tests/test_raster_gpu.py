@@ -36,8 +36,8 @@ def test_indices_bit_exact(case, oracle, gpu):
     o = Hh.oracle_raster(oracle, c, v, render=False)
     h = Hh.hip_raster(c, v, gpu)
     assert h["num_rendered"] == o["num_rendered"] > 0
-    for k in ("radii", "tiles_touched", "offsets", "keys_unsorted", "vals_unsorted", "keys", "point_list", "ranges"):
-        assert np.array_equal(h[k], o[k]), "%s differs (%d mismatches)" % (k, int((h[k] != o[k]).sum()))
+    assert np.array_equal(h["radii"], o["radii"])
+    Hh.check_binning(h, o)
     # values feeding the indices are bit-exact too (same op order, no contraction)
     assert np.array_equal(h["cov3D"].view(np.uint32), o["cov3D"].view(np.uint32))
     vis = o["radii"] > 0
@@ -178,8 +178,8 @@ def test_huge_and_tied_gaussians(oracle, gpu):
     o = Hh.oracle_raster(oracle, cl, v)
     h = Hh.hip_raster(cl, v, gpu)
     assert o["tiles_touched"][0] == 36
-    for k in ("radii", "tiles_touched", "keys", "point_list", "ranges"):
-        assert np.array_equal(h[k], o[k]), k
+    assert np.array_equal(h["radii"], o["radii"])
+    Hh.check_binning(h, o)
     np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
 
 
