@@ -13,16 +13,25 @@
  * that feeds an integer decision (radius, tile rect, sort key), so that tile / sort
  * indices are bit-exact between the two.
  *
- * PARITY PINNING.  The reference ships no tests / golden vectors for this path and its
- * CUDA sources cannot be compiled here (no nvcc, glm submodule empty).
- * The oracle is pinned instead by: (1) closed-form known-answer tests (single Gaussian
- * line integral, tests/test_oracle_kat.py); (2) golden vectors generated by importing the
- * reference's *Python* statements of the same algebra (covariance, camera matrices;
- * tests/golden/make_golden.py); (3) a float64 torch-autograd cross-check of every
- * backward formula away from the documented quirks.  simple-knn (distCUDA2) is an
- * un-vendored third-party submodule (gitlab.inria.fr/bkerbl/simple-knn, version unknown):
- * for it, parity is UNPINNED; the restatement here is the published algorithm's exact
- * result (mean of the 3 smallest squared distances, self excluded).
+ * PARITY PINNING.  The reference ships no tests / golden vectors for this path, so
+ * the oracle is pinned against THE REFERENCE ITSELF RUN HERE: oracle/_ref is the reference's own
+ * CUDA sources (SUB/cuda_rasterizer/*.cu, SUB/cuda_voxelizer/*.cu) compiled for the host CPU from
+ * where they lie under /root/reference (oracle/Makefile target `ref`; the shim boundary -- glm,
+ * CUB and the CUDA execution model are restated, the kernels are not -- is described there).
+ *   (1) tests/test_oracle_vs_ref.py compares this file with oracle/_ref live: every forward
+ *       intermediate (radii, tile counts, keys, sorted lists, ranges, n_contrib, image / volume)
+ *       is BIT-exact, backward sums agree to 1e-6 (float summation order);
+ *   (2) tests/golden/*.npz are outputs of oracle/_ref and of the reference's Python (camera
+ *       matrices, covariance, PSNR), committed with their generator tests/golden/make_golden.py,
+ *       so the pinning travels to machines without the reference tree (tests/test_oracle_golden.py);
+ *   (3) closed-form known-answer tests (tests/test_oracle_kat.py).
+ * Residual caveat: nvcc contracts a*b+c into FMAs, g++/-ffp-contract=off does not, so "bit-exact"
+ * is between uncontracted builds; a real CUDA run can differ in the last bit of a float that sits
+ * exactly on a tile boundary.
+ * simple-knn (distCUDA2) is an un-vendored third-party submodule (gitlab.inria.fr/bkerbl/simple-knn,
+ * version unknown, source absent): for it parity is UNPINNED; the restatement here is the published
+ * algorithm's exact result (mean of the 3 smallest squared distances, self excluded), checked
+ * against a float64 brute force.
  *
  * Each function cites the reference file:line it follows (paths relative to SUB unless noted;
  * RAS = cuda_rasterizer, VOX = cuda_voxelizer).

@@ -1,0 +1,98 @@
+"""CPU, world_size 2 over gloo: the view-sharded data-parallel exchange (r2_gaussian_amd/dist.py).  The N>1 path of
+bench.py / training uses exactly these functions with backend "nccl" (= RCCL) on GPUs."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from r2_gaussian_amd import dist as D
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        P = 257
+        g = torch.Generator().manual_seed(100 + rank)
+        grads = [torch.randn(P, w, generator=g) for w in (3, 1, 3, 4)]
+        flat = D.pack_grads(*grads)
+        assert flat.shape == (P, D.GRAD_WIDTH)
+        for a, b in zip(D.unpack_grads(flat), grads):
+            assert torch.equal(a, b)
+        # expected mean over ranks, computed locally from the known seeds
+        want = torch.zeros(P, D.GRAD_WIDTH)
+        for r in range(world):
+            gr = torch.Generator().manual_seed(100 + r)
+            want += D.pack_grads(*[torch.randn(P, w, generator=gr) for w in (3, 1, 3, 4)])
+        D.allreduce_grads(flat, average=True)
+        assert torch.allclose(flat, want / world, atol=1e-6)
+        # parameter-level helper writes the reduced gradients back
+        params = [torch.zeros(P, w, requires_grad=True) for w in (3, 1, 3, 4)]
+        for p, g_ in zip(params, grads):
+            p.grad = g_.clone()
+        D.allreduce_param_grads(params, average=False)
+        assert torch.allclose(D.pack_grads(*(p.grad for p in params)), want, atol=1e-5)
+        # densification statistics: sums and max
+        gn = torch.full((P,), float(rank + 1))
+        dn = (torch.arange(P) % (rank + 2) == 0).float()
+        rad = torch.arange(P, dtype=torch.int32) * (rank + 1)
+        s_gn, s_dn, m_rad = D.allreduce_densify_stats(gn, dn, rad)
+        assert torch.equal(s_gn, torch.full((P,), float(sum(range(1, world + 1)))))
+        assert torch.equal(s_dn, sum((torch.arange(P) % (r + 2) == 0).float() for r in range(world)))
+        assert torch.equal(m_rad, torch.arange(P, dtype=torch.int32) * world)
+        # view sharding: ranks of one step render distinct views; over an epoch every view is visited
+        n_views = 7
+        mine = [D.view_for(k, n_views) for k in range(n_views)]
+        allv = [None] * world
+        dist.all_gather_object(allv, mine)
+        for k in range(n_views):
+            assert len({allv[r][k] for r in range(world)}) == world
+        assert sorted(v for r in range(world) for v in allv[r]) == sorted(list(range(n_views)) * world)
+        # replica check: equal tensors pass, diverged tensors raise on every rank
+        D.assert_replicas_equal(torch.ones(5), "same")
+        try:
+            D.assert_replicas_equal(torch.ones(5) * (rank + 1), "diverged")
+            q.put((rank, "divergence not detected"))
+            return
+        except RuntimeError:
+            pass
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        q.put((rank, "FAIL %r\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.timeout(180)
+def test_world2_gloo_exchange():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in range(world)]
+    for p in procs:
+        p.join(30)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_single_process_is_identity():
+    assert D.world() == 1 and D.rank() == 0
+    flat = torch.ones(4, D.GRAD_WIDTH)
+    assert D.allreduce_grads(flat) is None and torch.equal(flat, torch.ones(4, D.GRAD_WIDTH))
+    assert [D.view_for(k, 5, rank_=1, world_=2) for k in range(5)] == [1, 3, 0, 2, 4]
