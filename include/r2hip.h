@@ -157,7 +157,7 @@ R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
  *   4 tiles_sorted u32[R]       5 point_list u32[R] (== the reference's sorted point_list)
  *   6 ranges uint2[T]           7 cov3D f32[6P]
  *   8 n_contrib u32[N] (only filled when forward ran with debug != 0)
- *   9 packed render records f32[8P] (voxelizer: f32[12P])
+ *   9 packed render records f32[8P] (voxelizer: f32[12P])                14 {opacity, mu} f32[2P] (rasterizer)
  *  10 depth sort keys u32[P] (bits of the depth; 0xFFFFFFFF for culled Gaussians)
  *  11 first-instance index u32[P]   12 depth order u32[P] (Gaussian ids sorted by (depth, id))
  *  13 perm u32[R] (emission index of every sorted instance)

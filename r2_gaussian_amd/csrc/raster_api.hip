@@ -166,6 +166,7 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     case 12: p = (char *)g.order; buf = 0; break;
     case 11: p = (char *)g.first; buf = 0; break;
     case 13: p = (char *)b.perm; buf = 1; break;
+    case 14: p = (char *)g.op_mu; buf = 0; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

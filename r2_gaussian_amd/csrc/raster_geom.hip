@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -130,10 +130,30 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     radii[idx] = (int)my_radius;
     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
     // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
-    // exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2), then opacity*mu and the two factors.
+    // alpha = opacity*mu*exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2 + L), L = log2(opacity*mu), and the
+    // half-extents (hx, hy) of the bounding box of the set where alpha can reach the reference's 1e-5 cut-off
+    // (RAS/forward.cu:374) -- the render kernels skip 8x8 pixel blocks that lie outside it.
     const float op = opacities[idx];
+    const float opmu = op * mu;
+    const float L = opmu > 0.0f ? log2f(opmu) : -INFINITY;
+    float hx = INFINITY, hy = INFINITY;   // +inf: never cull (degenerate / ill-conditioned conics)
+    {
+        // alpha >= 1e-5  <=>  q = A dx^2 + 2 B dx dy + C dy^2 <= 2 ln2 (L - log2(1e-5)); the bounding box of that
+        // ellipse has half-widths sqrt(qmax * C / det), sqrt(qmax * A / det), computed in double from the float
+        // conic the kernels actually evaluate, then padded (0.4 % + 0.05 px) against float rounding of q.
+        const double qmax = 2.0 * (double)LN2 * ((double)L - (double)LOG2_ALPHA_MIN_2D) + 1e-3;
+        const double A = conA, B = conB, C = conC;
+        const double det2 = A * C - B * B, trc = A + C;
+        if (!(qmax > 0.0)) {
+            hx = hy = -INFINITY;   // opacity*mu below the cut-off: no pixel can pass (exp(power) <= 1)
+        } else if (det2 > 0.0 && A > 0.0 && C > 0.0 && trc * trc <= 1.0e4 * det2) {
+            const double ex = sqrt(qmax * C / det2) * 1.004 + 0.05, ey = sqrt(qmax * A / det2) * 1.004 + 0.05;
+            if (ex < 1.0e30 && ey < 1.0e30) { hx = (float)ex; hy = (float)ey; }
+        }
+    }
     rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
-    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, op * mu, op, mu);
+    rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, L, hx, hy);
+    op_mu[idx] = make_float2(op, mu);
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -223,7 +243,8 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     int P, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
-    const float *__restrict__ proj, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
+    const float *__restrict__ proj, const float4 *__restrict__ rec, const float2 *__restrict__ op_mu,
+    const uint32_t *__restrict__ first_inst,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
     float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
@@ -242,7 +263,8 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
-    const float opmu = rb.y, op = rb.z, mu_f = rb.w;
+    const float2 om = op_mu[idx];
+    const float op = om.x, mu_f = om.y, opmu = op * mu_f;
     const float cA = ra.z * (-2.0f * LN2), cB = ra.w * (-LN2), cC = rb.x * (-2.0f * LN2);
     const float g2x = opmu * W_half * (-cA * S1 - cB * S2);
     const float g2y = opmu * H_half * (-cC * S2 - cB * S1);
@@ -368,7 +390,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, c
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched);
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu);
     return 0;
 }
 
@@ -399,7 +421,7 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
     const float h_x = W / (2.0f * tan_fovx);
     raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
-        g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
+        g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
         dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }

@@ -9,9 +9,21 @@ namespace r2 {
 
 constexpr uint32_t FWD_CHUNK = 512;   // instances of one tile list rendered by one workgroup (load balance)
 constexpr int PART_STRIDE = 8;        // floats per instance in the backward moment scratch (6 used)
+constexpr float ALPHA_MIN_2D = 0.00001f;               // RAS/forward.cu:374
+constexpr float LOG2_ALPHA_MIN_2D = -16.609640474436812f;   // log2(1e-5)
+constexpr int SUB2D = 8;              // culling granularity of the render kernels: 8x8 pixel blocks of a 16x16 tile
+
+// does the bounding box (px +- hx, py +- hy) of a Gaussian's alpha >= 1e-5 region touch the pixel block
+// [x0, x0+n) x [y0, y0+n)?  (pixel centres are the integers; +-inf half-extents mean never / always)
+__device__ __forceinline__ bool block_live(float px, float py, float hx, float hy, float x0, float y0, float n)
+{
+    return (px - hx <= x0 + (n - 1.0f)) && (px + hx >= x0) && (py - hy <= y0 + (n - 1.0f)) && (py + hy >= y0);
+}
 
 struct RasterGeom {
-    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, op*mu, op, mu}   (A2,B2,C2: conic * -log2e/2, -log2e, -log2e/2)
+    float4 *rec;              // [2P]  {px, py, A2, B2} {C2, L, hx, hy}: A2,B2,C2 = conic * (-log2e/2, -log2e, -log2e/2),
+                              //       L = log2(opacity*mu), (hx, hy) = half-extents of the alpha >= 1e-5 bounding box
+    float2 *op_mu;            // [P]   {opacity, mu} for the geometry backward
     uint32_t *depth_key;      // [P]   bits of view-space z (positive floats order like unsigned ints); 0xFFFFFFFF = culled
     uint32_t *iota;           // [P]   0..P-1, value input of the depth sort
     uint32_t *depth_sorted;   // [P]   sorted depth keys (unused afterwards)
@@ -30,6 +42,7 @@ struct RasterGeom {
         RasterGeom g;
         Bump b(chunk);
         g.rec = b.take<float4>(2 * (size_t)P);
+        g.op_mu = b.take<float2>(P);
         g.depth_key = b.take<uint32_t>(P);
         g.iota = b.take<uint32_t>(P);
         g.depth_sorted = b.take<uint32_t>(P);

@@ -75,8 +75,9 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     # decode the packed render record back to the reference's quantities
     out["means2D"] = rec[:, 0:2]
     out["conic"] = np.stack([rec[:, 2] / (-0.5 * LOG2E), rec[:, 3] / (-LOG2E), rec[:, 4] / (-0.5 * LOG2E)], 1)
-    out["mus"] = rec[:, 7]
-    out["opacity"] = rec[:, 6]
+    om = read(14, np.float32, 2 * P).reshape(P, 2)
+    out["opacity"], out["mus"] = om[:, 0], om[:, 1]
+    out["extent"] = rec[:, 6:8]   # (hx, hy): half-extents of the alpha >= 1e-5 bounding box used for block culling
     return out
 
 

@@ -83,7 +83,9 @@ def test_backward_vs_oracle(case, oracle, gpu):
     gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
         # the covariance chain (1/det^2 factors) amplifies last-bit differences of the accumulated sums
-        af = 2e-4 if k in ("dL_dcov3D", "dL_dscales", "dL_drotations") else 2e-5
+        # ... and a pair whose alpha sits exactly on the 1e-5 cut-off may flip (exp2 vs exp rounding): one flip moves a
+        # covariance-chain entry by ~2.5e-4 of the array scale (alpha * dL/dpix * 13/sigma)
+        af = 5e-4 if k in ("dL_dcov3D", "dL_dscales", "dL_drotations") else 2e-5
         Hh.assert_close_scaled(gh[k], go[k].reshape(gh[k].shape), rtol=2e-3, name=k, atol_frac=af)
 
 
@@ -191,3 +193,61 @@ def test_mark_visible(oracle, gpu):
     vis = _C.mark_visible(xyz.to(gpu), v.world_view_transform.to(gpu), v.full_proj_transform.to(gpu)).cpu().numpy()
     ref = oracle.mark_visible(xyz.numpy(), *Hh.np_view(v))
     assert np.array_equal(vis, ref) and 0 < ref.sum() < ref.size
+
+
+@pytest.mark.parametrize("seed,sm,aniso", [(1, 1.0, 1.0), (2, 3.0, 1.0), (3, 0.3, 1.0), (4, 1.0, 40.0), (5, 0.5, 400.0)],
+                         ids=["bench_like", "large", "small", "aniso40", "needles400"])
+def test_culling_extent_is_conservative(seed, sm, aniso, oracle, gpu):
+    """The render kernels skip 8x8 pixel blocks outside the per-Gaussian bounding box (hx, hy) stored in the packed
+    record.  That is only exact if every pixel the REFERENCE lets contribute (power <= 0 and alpha >= 1e-5,
+    RAS/forward.cu:369-375, evaluated here with the reference's float32 expression) lies inside the box."""
+    c = S.make_cloud(3000, seed=seed, scale_mult=sm)
+    if aniso != 1.0:   # stretch one axis: needle / pancake Gaussians, ill-conditioned conics
+        sc = c.scales.clone()
+        sc[:, 0] = (sc[:, 0] * aniso).clamp(max=1.0)
+        sc[:, 1] = (sc[:, 1] / aniso ** 0.5).clamp(min=0.001)
+        c = c._replace(scales=sc.contiguous())
+    v = S.make_view(0.9 + seed, (128, 128))
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    ext = h["extent"]
+    vis = np.nonzero(o["radii"] > 0)[0]
+    ys, xs = np.mgrid[0:128, 0:128].astype(np.float32)
+    checked = 0
+    for i in vis[:: max(1, len(vis) // 400)]:
+        con = o["conic_opacity"][i]
+        px, py = o["means2D"][i]
+        dx, dy = px - xs, py - ys
+        power = np.float32(-0.5) * (con[0] * dx * dx + con[2] * dy * dy) - con[1] * dx * dy
+        alpha = con[3] * o["mus"][i] * np.exp(power)
+        contrib = (power <= 0) & (alpha >= np.float32(1e-5))
+        if not contrib.any():
+            continue
+        checked += 1
+        assert np.abs(dx[contrib]).max() <= ext[i, 0] and np.abs(dy[contrib]).max() <= ext[i, 1], (
+            "Gaussian %d: contributing pixel outside the culling box (%.3f, %.3f)" % (i, ext[i, 0], ext[i, 1]))
+    assert checked > 50
+    # ... and the image is right.  Needle Gaussians have ill-conditioned conics: float32 evaluation of
+    # power = -0.5(A dx^2 + C dy^2) - B dx dy cancels catastrophically, so the float32 ORACLE itself is off the exact
+    # value by more than 1e-4 there (and nvcc's FMA contraction would move the reference again).  Judge both against a
+    # float64 evaluation over the same tile lists: the HIP image may not be further from it than the oracle is.
+    ref = o["color"][0]
+    truth = np.zeros((128, 128))
+    con, m2, mu = (o[k].astype(np.float64) for k in ("conic_opacity", "means2D", "mus"))
+    pl, rng = o["point_list"].astype(np.int64), o["ranges"]
+    for t in range(64):
+        ty, tx = divmod(t, 8)
+        ids = pl[rng[t, 0]:rng[t, 1]]
+        if ids.size == 0:
+            continue
+        yy, xx = np.mgrid[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].astype(np.float64)
+        dx = m2[ids, 0, None, None] - xx[None]
+        dy = m2[ids, 1, None, None] - yy[None]
+        power = -0.5 * (con[ids, 0, None, None] * dx * dx + con[ids, 2, None, None] * dy * dy) - con[ids, 1, None, None] * dx * dy
+        alpha = (con[ids, 3] * mu[ids])[:, None, None] * np.exp(np.minimum(power, 0.0))
+        truth[ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16] = np.where((power <= 0) & (alpha >= 1e-5), alpha, 0.0).sum(0)
+    tol = 1e-4 * np.abs(truth) + 2e-5
+    e_oracle, e_hip = np.abs(ref - truth), np.abs(h["color"][0] - truth)
+    assert (e_hip <= tol + 2.0 * e_oracle.max()).all(), "hip err %.3e, oracle err %.3e" % (e_hip.max(), e_oracle.max())
+    if aniso == 1.0:
+        assert (np.abs(h["color"][0] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
