@@ -30,16 +30,166 @@
 namespace r2 {
 
 // ------------------------------------------------------------------------------------------------ forward
-// One workgroup = one work item (<= FWD_CHUNK consecutive instances of one tile list); its 4 waves own the 4
-// 8x8 pixel blocks of the tile and never synchronise with each other.  Per batch of 256 list entries a wave
-//   1. gathers the 32-byte records (4 per lane, every load issued before the first use),
-//   2. keeps the entries whose alpha >= 1e-5 bounding box touches ITS block (ballot + prefix-popcount
-//      compaction into a per-wave LDS list; list order is preserved, so sums stay in sorted order),
-//   3. evaluates its 64 pixels against the kept entries only (wave-uniform LDS broadcast reads).
-// On the benchmark scene 46 % of the (entry, block) pairs survive step 2: the reference evaluates every pixel
-// of every listed tile and discards 84 % of the pairs at its alpha test.
-template <bool NCONTRIB>
-__global__ void __launch_bounds__(256) raster_render_forward_kernel(
+// Work item = (<= FWD_CHUNK consecutive instances of one tile list) x (one 8x8 pixel block): a workgroup's 4 waves own
+// the 4 blocks of the tile and never synchronise with each other.
+//
+// Production kernel (item-parallel): one LANE owns one list entry and evaluates the 64 pixels of the wave's block
+// into 64 register accumulators; entries are streamed through a per-wave LDS compaction buffer (ballot + prefix
+// popcount keeps only entries whose alpha >= 1e-5 bounding box touches the block, 46 % on the benchmark scene) so that
+// all 64 lanes work on live entries; at the end one 64x64 transpose-reduction (6 butterfly steps) leaves pixel p's sum
+// in lane p.  Lane-per-entry makes the Gaussian separable along a pixel row: alpha(c+1) = alpha(c) * r(c),
+// r(c+1) = r(c) * exp2(2 A2), i.e. TWO v_exp_f32 per 8-pixel row instead of 8 -- v_exp_f32 issues at ~1/8 the rate
+// of an FMA on gfx950 and was ~40 % of the pixel-parallel kernel's issue time.  Entries that are too thin for the
+// recurrence or whose conic is not safely positive definite take the exact per-pixel path (see needs_exact_row).
+// Sums are formed in a fixed order (per lane in list order, then a fixed butterfly): the image is deterministic.
+// When may a pixel row be walked with the recurrence?  The only hazard is an underflowed start: exp2(p0) = 0 for
+// p0 < -126, and 0 stays 0 however large the ratios.  Along a row p(c) = -|A2| c^2 + beta c + p0 is a concave parabola
+// that never exceeds 0 (positive definite conic), hence p(c) <= -(sqrt(-p0) - c sqrt|A2|)^2.  With p0 < -126 and
+// c <= 7 no later pixel of the row can reach log2(alpha) >= log2(1e-5), i.e. p(c) >= log2(1e-5) - L, as long as
+//     sqrt|A2| <= (sqrt(126) - sqrt(L - log2(1e-5) + 1)) / 7
+// (for opacity*mu = 0.01 that is |A2| <= 1.3, a conditional sigma of 0.75 px along x).  Gaussians beyond that, or
+// without a finite culling box (conic not safely positive definite), are evaluated exactly, pixel by pixel.
+__device__ __forceinline__ bool needs_exact_row(float A2, float L, float hx)
+{
+    const float smax = (11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f)) * (1.0f / 7.0f);
+    return !(smax > 0.f && fabsf(A2) <= smax * smax) || !(hx < 3.0e38f);
+}
+constexpr int FWD_BATCH = 128;          // list entries examined per compaction round (2 per lane)
+constexpr int FWD_BUF = FWD_BATCH + 64;   // + up to 63 carried over
+
+template <bool EXACT>
+__device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64])
+{
+    const float dx0 = a.x - x0;
+    const float k1 = a.z * (1.0f - 2.0f * dx0);                       // log2 of alpha(1)/alpha(0), minus B2*dy
+    const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * a.z);   // second ratio, constant along the row
+#pragma unroll
+    for (int r = 0; r < SUB2D; ++r) {
+        const float dy = a.y - (y0 + (float)r);
+        const float bdy = a.w * dy;
+        const float cdl = (C2 * dy) * dy + L;
+        if (EXACT) {
+#pragma unroll
+            for (int c = 0; c < SUB2D; ++c) {
+                const float dx = dx0 - (float)c;
+                const float pl = dx * (a.z * dx + bdy) + cdl;     // log2(alpha)
+                const float al = __builtin_amdgcn_exp2f(pl);
+                // power <= 0 (RAS/forward.cu:369) <=> pl <= L ; alpha >= 1e-5 (RAS/forward.cu:374)
+                const bool ok = (pl <= L) && (al >= ALPHA_MIN_2D);
+                acc[r * SUB2D + c] += ok ? al : 0.f;
+            }
+        } else {
+            float g = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdl);
+            float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
+#pragma unroll
+            for (int c = 0; c < SUB2D; ++c) {
+                acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;   // power <= 0 holds for a positive definite conic
+                g *= rt;
+                rt *= rr;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one row at a time: keeps the 64 accumulators + one row of temporaries live
+    }
+}
+
+__global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
+    float *__restrict__ partial)
+{
+    const uint32_t w = blockIdx.x;
+    if (w >= chunk_base[T]) return;
+    const uint32_t tile = work_tile[w];
+    const uint32_t j0 = (w - chunk_base[tile]) * FWD_CHUNK;
+    const uint2 range = ranges[tile];
+    const uint32_t beg = range.x + j0, end = min(range.y, beg + FWD_CHUNK);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;             // this wave's block inside the tile
+    const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    __shared__ float4 sA[4][FWD_BUF];   // compacted live entries of this wave: {px, py, A2, B2}
+    __shared__ float4 sB[4][FWD_BUF];   //                                       {C2, L, exact-path flag, -}
+    float4 *const mA = sA[wave];
+    float4 *const mB = sB[wave];
+
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+
+    int cnt = 0;   // live entries waiting in the buffer (wave-uniform)
+    for (uint32_t base = beg; base < end; base += FWD_BATCH) {
+        float4 a[FWD_BATCH / 64], b[FWD_BATCH / 64];
+        bool cand[FWD_BATCH / 64];
+#pragma unroll
+        for (int r = 0; r < FWD_BATCH / 64; ++r) {
+            const uint32_t k = base + (uint32_t)(r * 64 + lane);
+            cand[r] = k < end;
+            const uint32_t id = cand[r] ? point_list[k] : point_list[beg];
+            a[r] = rec[2 * id];
+            b[r] = rec[2 * id + 1];
+        }
+#pragma unroll
+        for (int r = 0; r < FWD_BATCH / 64; ++r) {
+            const bool keep = cand[r] && block_live(a[r].x, a[r].y, b[r].z, b[r].w, x0, y0, (float)SUB2D);
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int pos = cnt + __popcll(m & lt_mask);
+                const float flag = needs_exact_row(a[r].z, b[r].y, b[r].z) ? 1.f : 0.f;
+                mA[pos] = a[r];
+                mB[pos] = make_float4(b[r].x, b[r].y, flag, 0.f);
+            }
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const bool last_batch = base + FWD_BATCH >= end;
+        int head = 0;
+        while (cnt - head >= 64 || (last_batch && cnt - head > 0)) {
+            const bool have = lane < cnt - head;
+            float4 ea = make_float4(0.f, 0.f, 0.f, 0.f), eb = make_float4(0.f, -INFINITY, 0.f, 0.f);   // dead lane: alpha = 0
+            if (have) { ea = mA[head + lane]; eb = mB[head + lane]; }
+            // recurrence path for the regular entries (flagged lanes contribute 0: L = -inf), then, only if the wave
+            // holds any, the exact path for the flagged ones -- two in-place accumulations, no 64-register merge
+            const bool exact = eb.z != 0.f;
+            fwd_item<false>(exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+            if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
+            head += 64;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (head > 0 && head < cnt) {   // carry the (< 64) unprocessed entries to the front of the buffer
+            float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
+            const bool mv = lane < cnt - head;
+            if (mv) { ca = mA[head + lane]; cb = mB[head + lane]; }
+            __builtin_amdgcn_wave_barrier();
+            if (mv) { mA[lane] = ca; mB[lane] = cb; }
+        }
+        cnt = max(cnt - head, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // 64x64 transpose-reduction: after the step with partner distance d, acc[0..d) hold partial sums of the d pixels
+    // whose index agrees with this lane's bits >= d; after d = 1, acc[0] is the block's pixel number `lane`.
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const float keep = up ? acc[d + i] : acc[i];
+            const float send = up ? acc[i] : acc[d + i];
+            acc[i] = keep + __shfl_xor(send, d);
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the exchange's register footprint
+        }
+    }
+    const int ly = by + (lane >> 3), lx = bx + (lane & 7);
+    partial[(size_t)w * 256 + (ly * TILE2D + lx)] = acc[0];
+}
+
+// Debug-mode kernel (pixel-parallel): also tracks n_contrib (RAS/forward.cu:381,391), which only `debug` callers read
+// back.  One lane per pixel, the wave's live entries are compacted per 256-entry batch and broadcast from LDS.
+__global__ void __launch_bounds__(256) raster_render_forward_debug_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
     float *__restrict__ partial, uint32_t *__restrict__ partial_last)
@@ -52,15 +202,15 @@ __global__ void __launch_bounds__(256) raster_render_forward_kernel(
     const uint32_t beg = range.x + j0, end = min(range.y, beg + FWD_CHUNK);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;             // this wave's block inside the tile
-    const int lx = bx + (lane & 7), ly = by + (lane >> 3);                   // this lane's pixel inside the tile
+    const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;
+    const int lx = bx + (lane & 7), ly = by + (lane >> 3);
     const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
     const float fx = (float)(tx * TILE2D + lx), fy = (float)(ty * TILE2D + ly);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    __shared__ float4 sA[4][256];   // kept entries of the current batch, per wave: {px, py, A2, B2}
-    __shared__ float2 sB[4][256];   //                                               {C2, L}
-    __shared__ uint32_t sK[NCONTRIB ? 4 : 1][NCONTRIB ? 256 : 1];   // debug: 1-based list position of the kept entry
+    __shared__ float4 sA[4][256];
+    __shared__ float2 sB[4][256];
+    __shared__ uint32_t sK[4][256];   // 1-based list position of the kept entry
     float4 *const mA = sA[wave];
     float2 *const mB = sB[wave];
 
@@ -73,11 +223,11 @@ __global__ void __launch_bounds__(256) raster_render_forward_kernel(
         for (int r = 0; r < 4; ++r) {
             const uint32_t k = base + (uint32_t)(r * 64 + lane);
             live[r] = k < end;
-            const uint32_t id = live[r] ? point_list[k] : 0u;
+            const uint32_t id = live[r] ? point_list[k] : point_list[beg];
             a[r] = rec[2 * id];
             b[r] = rec[2 * id + 1];
         }
-        __builtin_amdgcn_wave_barrier();   // the previous batch's readers are done (same wave, DS ops in order)
+        __builtin_amdgcn_wave_barrier();
         int n = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -87,28 +237,25 @@ __global__ void __launch_bounds__(256) raster_render_forward_kernel(
                 const int pos = n + __popcll(m & lt_mask);
                 mA[pos] = a[r];
                 mB[pos] = make_float2(b[r].x, b[r].y);
-                if (NCONTRIB) sK[wave][pos] = (base - range.x) + (uint32_t)(r * 64 + lane) + 1u;
+                sK[wave][pos] = (base - range.x) + (uint32_t)(r * 64 + lane) + 1u;
             }
             n += __popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
         for (int j = 0; j < n; ++j) {
             const float4 ra = mA[j];
             const float2 rb = mB[j];
             const float dx = ra.x - fx, dy = ra.y - fy;
-            // log2(alpha) = A2 dx^2 + B2 dx dy + C2 dy^2 + L
             const float pl = dx * (ra.z * dx + ra.w * dy) + ((rb.x * dy) * dy + rb.y);
             const float alpha = __builtin_amdgcn_exp2f(pl);
-            // power <= 0 (RAS/forward.cu:369) <=> pl <= L ; alpha >= 1e-5 (RAS/forward.cu:374)
             const bool ok = (pl <= rb.y) && (alpha >= ALPHA_MIN_2D);
             C += ok ? alpha : 0.f;
-            if (NCONTRIB) last = ok ? sK[wave][j] : last;
+            last = ok ? sK[wave][j] : last;
         }
     }
     partial[(size_t)w * 256 + (ly * TILE2D + lx)] = C;
-    if (NCONTRIB) partial_last[(size_t)w * 256 + (ly * TILE2D + lx)] = last;
+    partial_last[(size_t)w * 256 + (ly * TILE2D + lx)] = last;
 }
 
 // adds the partial sums of a tile's work items in list order and writes the image (zeros for empty tiles)
@@ -164,13 +311,18 @@ __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, fl
     r3 += wdx * dx;
 }
 
-// moments of w = G * dL/dpix over an n x n pixel block whose dL/dpix rows sit in LDS at gt (row stride GT_STRIDE)
-template <int N>
+// moments of w = G * dL/dpix over an n x n pixel block whose dL/dpix rows sit in LDS at gt (row stride GT_STRIDE).
+// EXACT = false walks each row with the recurrence G(c+1) = G(c) r(c), r(c+1) = r(c) exp2(2 A2) (see the forward
+// kernel): two v_exp_f32 per row instead of one per pixel.
+template <int N, bool EXACT>
 __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b, const float *__restrict__ gt,
                                                   float bx0, float by0, float *S)
 {
     const float dx0 = a.x - bx0;
-    const float lthr = LOG2_ALPHA_MIN_2D - b.y;
+    const float lthr = LOG2_ALPHA_MIN_2D - b.y;                         // alpha >= 1e-5 <=> log2 G >= lthr
+    const float gthr = EXACT ? 0.f : __builtin_amdgcn_exp2f(lthr);
+    const float k1 = a.z * (1.0f - 2.0f * dx0);
+    const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * a.z);
 #pragma unroll 2
     for (int r = 0; r < N; ++r) {
         const float dy = a.y - (by0 + (float)r);
@@ -183,8 +335,28 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             g[4 * c4 + 0] = v.x; g[4 * c4 + 1] = v.y; g[4 * c4 + 2] = v.z; g[4 * c4 + 3] = v.w;
         }
         float r0 = 0.f, r1 = 0.f, r3 = 0.f;
+        if (EXACT) {
 #pragma unroll
-        for (int c = 0; c < N; ++c) pixel_moments(a.z, lthr, dx0 - (float)c, bdy, cdy2, g[c], r0, r1, r3);
+            for (int c = 0; c < N; ++c) pixel_moments(a.z, lthr, dx0 - (float)c, bdy, cdy2, g[c], r0, r1, r3);
+        } else {
+            float G = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdy2);
+            float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
+            // column moments t_k = sum_c c^k w_c (the c^k are literals: one FMA each), turned into moments of
+            // dx = dx0 - c once per row
+            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < N; ++c) {
+                const float w = (G >= gthr) ? G * g[c] : 0.f;   // power <= 0 holds for a positive definite conic
+                t0 += w;
+                t1 = fmaf(w, (float)c, t1);
+                t2 = fmaf(w, (float)(c * c), t2);
+                G *= rt;
+                rt *= rr;
+            }
+            r0 = t0;
+            r1 = dx0 * t0 - t1;
+            r3 = dx0 * (dx0 * t0 - 2.0f * t1) + t2;
+        }
         S[0] += r0; S[1] += r1; S[3] += r3;
         S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
     }
@@ -300,11 +472,16 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
             const uint32_t item = e < total ? (uint32_t)s_q[wave][e] : 0u;
             const int owner = (int)(item >> 4), sl = (int)((item >> 2) & 3u), q = (int)(item & 3u);
             const uint32_t ot = __shfl(tile, owner);   // the owner's tile (all lanes take part in the shuffle)
-            if (e < total) {
-                const float4 oa = s_pa[wave][owner], ob = s_pb[wave][owner];
-                const float bx0 = (float)((int)(ot % gx) * TILE2D + (q % NB) * SUB2D);
-                const float by0 = (float)((int)(ot / gx) * TILE2D + (q / NB) * SUB2D);
-                block_moments_lds<SUB2D>(oa, ob, gt + sl * GT_TILE + (q / NB) * SUB2D * GT_STRIDE + (q % NB) * SUB2D, bx0, by0, M);
+            float4 oa = make_float4(0.f, 0.f, 0.f, 0.f), ob = oa;
+            if (e < total) { oa = s_pa[wave][owner]; ob = s_pb[wave][owner]; }
+            const float bx0 = (float)((int)(ot % gx) * TILE2D + (q % NB) * SUB2D);
+            const float by0 = (float)((int)(ot / gx) * TILE2D + (q / NB) * SUB2D);
+            const float *gq = gt + sl * GT_TILE + (q / NB) * SUB2D * GT_STRIDE + (q % NB) * SUB2D;
+            // exact per-pixel path for thin / not safely positive definite Gaussians, the row recurrence for the rest
+            const bool exact = needs_exact_row(oa.z, ob.y, ob.z);
+            if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M);
+            if (__any(e < total && exact)) {
+                if (e < total && exact) block_moments_lds<SUB2D, true>(oa, ob, gq, bx0, by0, M);
             }
             __builtin_amdgcn_wave_barrier();
             s_r0[wave][lane] = make_float4(M[0], M[1], M[2], M[3]);
@@ -340,11 +517,11 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
     launch_build_work(im.ranges, T, FWD_CHUNK, im.chunk_base, im.work_tile, s);
     if (im.NW > 0) {
         if (write_ncontrib)
-            raster_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+            raster_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
         else
-            raster_render_forward_kernel<false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
+            raster_render_forward_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial);
     }
     if (write_ncontrib)
         raster_combine_kernel<true><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
