@@ -154,13 +154,13 @@ R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
  * tests read the binning intermediates back without fixing the layout in the ABI.  which:
  *   0 tiles_touched u32[P]      1 point_offsets u32[P] (inclusive scan over Gaussians in depth order)
  *   2 tiles_unsorted u32[R]     3 values_unsorted u32[R] (emission: depth-ordered Gaussians, tiles y/x-minor)
- *   4 tiles_sorted u32[R]       5 point_list u32[R] (== the reference's sorted point_list)
+ *   4 tiles_sorted u32[R] (valid after backward, or for > 4096 tiles)   5 point_list u32[R] (== the reference's sorted point_list)
  *   6 ranges uint2[T]           7 cov3D f32[6P]
  *   8 n_contrib u32[N] (only filled when forward ran with debug != 0)
  *   9 packed render records f32[8P] (voxelizer: f32[12P])                14 {opacity, mu} f32[2P] (rasterizer)
  *  10 depth sort keys u32[P] (bits of the depth; 0xFFFFFFFF for culled Gaussians)
  *  11 first-instance index u32[P]   12 depth order u32[P] (Gaussian ids sorted by (depth, id))
- *  13 perm u32[R] (emission index of every sorted instance)
+ *  13 inv u32[R] (sorted position of every emitted instance: the inverse permutation of the tile sort)
  * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
 R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);
 R2_API long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id);

@@ -3,8 +3,6 @@
 // reference (RAS/rasterizer_impl.cu:116-138,275,308-316); the sort lives in radix_sort.hip.
 #include "r2_common.hpp"
 #include <cstring>
-#include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/transform_iterator.hpp>
 #include <stdarg.h>
 #include <vector>
 #include <string.h>
@@ -71,39 +69,102 @@ uint32_t higher_msb(uint32_t n)
     return msb;
 }
 
-size_t scan_temp_bytes(int P)
+// ---- prefix sum (replaces cub::DeviceScan::InclusiveSum, RAS/rasterizer_impl.cu:275): two kernels, no
+// inter-workgroup waiting.  K1: every workgroup reduces its 4096-element tile; K2: every workgroup adds up the
+// partials of the tiles before it (<= a few hundred values) and scans its own tile.  `order` (optional) gathers the
+// input: out[j] = sum_{i<=j} in[order[i]] -- the per-Gaussian tile counts visited in depth order.
+constexpr int SC_THREADS = 1024;
+constexpr int SC_IPT = 4;
+constexpr int SC_TILE = SC_THREADS * SC_IPT;
+
+__device__ __forceinline__ uint32_t block_reduce_1024(uint32_t v, uint32_t *sh /* [16] */)
 {
-    size_t bytes = 0;
-    (void)rocprim::inclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P,
-                                  rocprim::plus<uint32_t>());
-    return bytes;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    uint32_t t = 0;
+#pragma unroll
+    for (int w = 0; w < SC_THREADS / 64; ++w) t += sh[w];
+    __syncthreads();
+    return t;
 }
 
-int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s)
+__global__ void __launch_bounds__(SC_THREADS) scan_reduce_kernel(const uint32_t *__restrict__ in,
+                                                                 const uint32_t *__restrict__ order, uint32_t n,
+                                                                 uint32_t *__restrict__ partial)
 {
-    R2_HIP_TRY(rocprim::inclusive_scan(temp, temp_bytes, in, out, (size_t)P, rocprim::plus<uint32_t>(), s));
-    return 0;
+    __shared__ uint32_t sh[SC_THREADS / 64];
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_IPT;
+    uint32_t v = 0;
+#pragma unroll
+    for (int i = 0; i < SC_IPT; ++i) {
+        const uint32_t j = base + i;
+        if (j < n) v += in[order ? order[j] : j];
+    }
+    const uint32_t t = block_reduce_1024(v, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
 }
 
-struct GatherU32 {
-    const uint32_t *in;
-    __host__ __device__ uint32_t operator()(uint32_t i) const { return in[i]; }
-};
-
-size_t scan_gather_temp_bytes(int P)
+__global__ void __launch_bounds__(SC_THREADS) scan_apply_kernel(const uint32_t *__restrict__ in,
+                                                                const uint32_t *__restrict__ order, uint32_t n,
+                                                                const uint32_t *__restrict__ partial,
+                                                                uint32_t *__restrict__ out)
 {
-    size_t bytes = 0;
-    auto it = rocprim::make_transform_iterator((const uint32_t *)nullptr, GatherU32{nullptr});
-    (void)rocprim::inclusive_scan(nullptr, bytes, it, (uint32_t *)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-    return bytes;
+    __shared__ uint32_t sh[SC_THREADS / 64];
+    __shared__ uint32_t wsum[SC_THREADS / 64];
+    uint32_t pre = 0;
+    for (uint32_t g = threadIdx.x; g < blockIdx.x; g += SC_THREADS) pre += partial[g];
+    const uint32_t tile_base = block_reduce_1024(pre, sh);
+    const uint32_t base = blockIdx.x * SC_TILE + threadIdx.x * SC_IPT;
+    uint32_t x[SC_IPT], sum = 0;
+#pragma unroll
+    for (int i = 0; i < SC_IPT; ++i) {
+        const uint32_t j = base + i;
+        x[i] = j < n ? in[order ? order[j] : j] : 0u;
+        sum += x[i];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t run = tile_base + incl - sum;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+#pragma unroll
+    for (int i = 0; i < SC_IPT; ++i) {
+        run += x[i];
+        if (base + i < n) out[base + i] = run;
+    }
 }
+
+size_t scan_temp_bytes(int P) { return sizeof(uint32_t) * ((size_t)(P + SC_TILE - 1) / SC_TILE + 32); }
+size_t scan_gather_temp_bytes(int P) { return scan_temp_bytes(P); }
 
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
                               int P, hipStream_t s)
 {
-    auto it = rocprim::make_transform_iterator(order, GatherU32{in});
-    R2_HIP_TRY(rocprim::inclusive_scan(temp, temp_bytes, it, out, (size_t)P, rocprim::plus<uint32_t>(), s));
+    if (P <= 0) return 0;
+    if (temp_bytes < scan_temp_bytes(P)) {
+        set_error("inclusive_scan: temp storage too small");
+        return R2_ERR_INVALID;
+    }
+    const uint32_t tiles = (uint32_t)((P + SC_TILE - 1) / SC_TILE);
+    uint32_t *partial = reinterpret_cast<uint32_t *>(temp);
+    scan_reduce_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial);
+    scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out);
+    R2_HIP_TRY(hipGetLastError());
     return 0;
+}
+
+int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s)
+{
+    return inclusive_scan_gather_u32(temp, temp_bytes, in, nullptr, out, P, s);
 }
 
 // One thread per sorted instance; a tile boundary writes the end of the previous tile's range and the
@@ -116,7 +177,7 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 {
     const uint32_t idx = blockIdx.x * 256u + threadIdx.x;
     if (idx >= L) return;
-    point_list[idx] = vals_unsorted[perm[idx]];
+    if (point_list) point_list[idx] = vals_unsorted[perm[idx]];   // absent when the sort carried the ids itself
     const uint32_t cur = tiles[idx];
     if (idx == 0) ranges[cur].x = 0;
     else {
@@ -136,6 +197,28 @@ int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32
     if (R > 0)
         tile_ranges_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(tiles_sorted, perm, vals_unsorted,
                                                                                   point_list, (uint32_t)R, ranges);
+    return 0;
+}
+
+__global__ void __launch_bounds__(256) fill_tiles_kernel(const uint2 *__restrict__ ranges, uint32_t *__restrict__ tiles)
+{
+    const uint2 r = ranges[blockIdx.x];
+    for (uint32_t k = r.x + threadIdx.x; k < r.y; k += 256) tiles[k] = blockIdx.x;
+}
+int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipStream_t s)
+{
+    if (T > 0) fill_tiles_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>(ranges, tiles);
+    return 0;
+}
+__global__ void __launch_bounds__(256) invert_permutation_kernel(const uint32_t *__restrict__ perm, uint32_t *__restrict__ inv,
+                                                                 uint32_t n)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k < n) inv[perm[k]] = k;
+}
+int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_t s)
+{
+    if (n > 0) invert_permutation_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(perm, inv, (uint32_t)n);
     return 0;
 }
 
@@ -184,6 +267,52 @@ void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t
                        hipStream_t s)
 {
     build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile);
+}
+
+// Single-pass tile sort: the sort's digit totals are the per-tile instance counts, so the tile ranges
+// (identifyTileRanges, RAS/rasterizer_impl.cu:116-138) are their exclusive scan -- computed here together with the
+// forward work list, by one workgroup (T <= 4096).
+__global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *__restrict__ counts, uint32_t T,
+                                                               uint32_t chunk, uint2 *__restrict__ ranges,
+                                                               uint32_t *__restrict__ chunk_base,
+                                                               uint32_t *__restrict__ work_tile)
+{
+    __shared__ uint32_t wsum[16], wsum2[16];
+    __shared__ uint32_t carry, carry2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { carry = 0; carry2 = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < T; base += 1024) {
+        const uint32_t t = base + tid;
+        const uint32_t c = t < T ? counts[t] : 0u;
+        const uint32_t nw = (c + chunk - 1) / chunk;
+        uint32_t incl = c, incl2 = nw;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d);
+            if (lane >= d) { incl += up; incl2 += up2; }
+        }
+        if (lane == 63) { wsum[wave] = incl; wsum2[wave] = incl2; }
+        __syncthreads();
+        uint32_t woff = 0, woff2 = 0;
+        for (int w = 0; w < wave; ++w) { woff += wsum[w]; woff2 += wsum2[w]; }
+        const uint32_t start = carry + woff + incl - c, wstart = carry2 + woff2 + incl2 - nw;
+        if (t < T) {
+            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles keep (0,0) like the memset
+            chunk_base[t] = wstart;
+            for (uint32_t j = 0; j < nw; ++j) work_tile[wstart + j] = t;
+        }
+        __syncthreads();
+        if (tid == 1023) { carry = start + c; carry2 = wstart + nw; }
+        __syncthreads();
+    }
+    if (tid == 0) chunk_base[T] = carry2;
+}
+
+void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
+                            uint32_t *work_tile, hipStream_t s)
+{
+    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, T, chunk, ranges, chunk_base, work_tile);
 }
 
 }  // namespace r2

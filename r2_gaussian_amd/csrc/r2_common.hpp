@@ -78,9 +78,24 @@ int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32
 // instances -- emitted in that depth order -- by tile id only.  A stable sort by tile of a depth-ordered
 // sequence IS the (tile|depth) order with the reference's tie rule, so point_list is bit-identical.
 size_t sort_temp_bytes(size_t n);
+// extended form: optional second payload (win -> wout), vin == nullptr means "value = input index", allow_skip lets the
+// device skip digit passes that are constant over all keys, and for a single-pass sort *totals_out receives a device
+// pointer to the per-digit key counts (the bucket sizes), valid until the temp storage is reused.
+int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                  const uint32_t *win, uint32_t *wout, size_t n, int end_bit, bool allow_skip, const uint32_t **totals_out,
+                  hipStream_t s);
 int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                        uint32_t *vout, size_t n, int end_bit, hipStream_t s);
 // inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
+bool sort_is_single_pass(int end_bit);
+// single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
+// *counts_out = per-tile instance counts (device pointer into temp)
+int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
+                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s);
+// tiles[k] = t for k in ranges[t] (the backward's per-instance tile id when the sort did not scatter the keys);
+// inv[perm[k]] = k (inverse of a scattered permutation, for the general multi-pass sort)
+int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipStream_t s);
+int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_t s);
 size_t scan_gather_temp_bytes(int P);
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
                               int P, hipStream_t s);
@@ -91,6 +106,9 @@ uint32_t higher_msb(uint32_t n);
 // forward work list: tile t owns work items [chunk_base[t], chunk_base[t+1]), one per `chunk` list entries
 void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint32_t *work_tile,
                        hipStream_t s);
+// same, but the tile ranges themselves are derived from the per-tile instance counts of a single-pass tile sort
+void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
+                            uint32_t *work_tile, hipStream_t s);
 
 // XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,
 // which share Gaussian records) stay on one XCD's L2 instead of being dealt round-robin over 8.

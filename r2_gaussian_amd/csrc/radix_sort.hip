@@ -1,21 +1,20 @@
-// radix_sort.hip -- stable LSD radix sort of (u32 key, u32 value) pairs on key bits [0, end_bit), written for
-// the binning pipeline's problem sizes (1e5 .. 1e7 pairs) on MI355X.  It replaces the library sort the
-// reference calls (cub::DeviceRadixSort::SortPairs, RAS/rasterizer_impl.cu:301-306): at these sizes a
-// generic device sort is launch/latency-bound (measured ~25 us per digit pass whatever the size), while the
-// data would stream through HBM in 2-5 us.
+// radix_sort.hip -- stable LSD radix sort of (u32 key, u32 value[, u32 value2]) on key bits [0, end_bit), written for
+// the binning pipeline's problem sizes (1e5 .. 1e7 pairs) on MI355X.  It replaces the library sort the reference calls
+// (cub::DeviceRadixSort::SortPairs, RAS/rasterizer_impl.cu:301-306).
 //
-// Structure ("onesweep" with decoupled look-back, one kernel per digit pass):
-//   * one histogram kernel reads the keys ONCE and counts every digit place (the digits of the original keys
-//     do not change between passes);
-//   * per pass, a workgroup takes a ticket (tile id in scheduling order), ranks its keys, publishes its
-//     per-digit counts, resolves the exclusive prefix over earlier tiles by looking back at their published
-//     counts, and scatters.  Thread d of the workgroup owns digit d for the whole exchange.
-//   * ranking is wave-synchronous and needs no atomics: a wave walks its keys 64 at a time; lanes holding the
-//     same digit find each other with one __ballot per digit bit (64-wide match), the lowest peer bumps the
-//     wave's LDS counter.  Keys keep their relative order -> the sort is stable.
-//   * tiles communicate through one dword per (tile, digit): 2 flag bits + a 30-bit count, written and polled
-//     with relaxed AGENT-scope atomics (the per-XCD L2s are not coherent; see the MI355X guide, G16).
-//     Tickets guarantee that a tile only ever waits on tiles that already started.
+// At these sizes a sort is bound by LAUNCH COUNT and dependent memory round trips, not by bandwidth (the data streams
+// through HBM in a few microseconds), so the design minimises digit passes:
+//   * digits are up to 12 bits wide (4096 bins): the 11-bit tile ids of a 512^2 detector sort in ONE pass, 32-bit depth
+//     keys in three (12 + 12 + 8);
+//   * a pass whose digit is the same in every key is detected on the device and skipped (optional): the exponent byte of
+//     cone-beam depths is constant, which leaves two passes for the depth order;
+//   * a pass is three kernels without any inter-workgroup waiting (no look-back spinning, nothing to deadlock):
+//       upsweep   one workgroup per 4096-key tile counts its digits (LDS atomics) -> H[tile][digit]
+//       scan      column-wise exclusive prefix of H over the tiles (32 digits x 8 tile-slices per workgroup) + totals
+//       downsweep re-reads the tile, ranks it (wave-synchronous 64-wide digit matching with __ballot: no atomics,
+//                 keys keep their order -> stable) and scatters to  digit_base + H[tile][digit] + rank
+//   * for a single-pass sort the digit totals ARE the bucket sizes: the caller gets them back and derives the tile
+//     ranges from them instead of scanning the sorted keys for boundaries (identifyTileRanges, RAS/rasterizer_impl.cu:116-138).
 #include "r2_common.hpp"
 #include <algorithm>
 
@@ -23,29 +22,35 @@ namespace r2 {
 
 namespace {
 
-constexpr int SORT_THREADS = 256;      // histogram kernel
-constexpr int PASS_THREADS = 1024;     // pass kernel: 16 waves per tile hide the ranking's dependent chains
-constexpr int PASS_WAVES = PASS_THREADS / 64;
-constexpr int MAX_PASSES = 4;
-constexpr int MAX_RADIX = 256;
-constexpr uint32_t FLAG_AGG = 1u << 30;    // value = this tile's count of the digit
-constexpr uint32_t FLAG_INC = 2u << 30;    // value = inclusive count over tiles 0..this
-constexpr uint32_t VALUE_MASK = (1u << 30) - 1;
-constexpr uint32_t SPIN_LIMIT = 1u << 22;  // bounded wait: a logic error must not hang the GPU
-constexpr int LOOKBACK_WINDOW = 64;   // polls in flight per digit: a pass costs ~ (tiles / window) agent-scope round trips
+constexpr int RS_THREADS = 512;                // 8 waves rank a tile side by side (the per-wave ranking chain is serial)
+constexpr int RS_WAVES = RS_THREADS / 64;
+constexpr int RS_IPT = 8;
+constexpr int RS_TILE = RS_THREADS * RS_IPT;   // 4096 keys per workgroup
+constexpr int RS_SCAN_THREADS = 256;
+constexpr int RS_MAX_BITS = 12;
+constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
+constexpr int RS_MAX_PASSES = 4;
+constexpr int RS_SCAN_DIGITS = 32;             // digits per scan workgroup (one 128-byte row segment of H)
+constexpr int RS_SCAN_ROWS = RS_SCAN_THREADS / RS_SCAN_DIGITS;
 
-struct PassPlan {
+struct Plan {
     int npass;
-    int shift[MAX_PASSES];
-    int bits[MAX_PASSES];
+    int shift[RS_MAX_PASSES];
+    int bits[RS_MAX_PASSES];
 };
 
-inline PassPlan make_plan(int end_bit)
+inline Plan make_plan(int end_bit)
 {
-    PassPlan p;
-    if (end_bit < 1) end_bit = 1;
-    if (end_bit > 32) end_bit = 32;
-    p.npass = (end_bit + 7) / 8;
+    Plan p;
+    end_bit = std::min(32, std::max(1, end_bit));
+    if (end_bit == 32) {   // 12 + 12 + 8: the top pass covers exactly the float exponent byte (skippable, see header)
+        p.npass = 3;
+        p.shift[0] = 0; p.bits[0] = 12;
+        p.shift[1] = 12; p.bits[1] = 12;
+        p.shift[2] = 24; p.bits[2] = 8;
+        return p;
+    }
+    p.npass = (end_bit + RS_MAX_BITS - 1) / RS_MAX_BITS;
     const int base = end_bit / p.npass, extra = end_bit % p.npass;
     int s = 0;
     for (int i = 0; i < p.npass; ++i) {
@@ -56,281 +61,351 @@ inline PassPlan make_plan(int end_bit)
     return p;
 }
 
-inline int items_per_thread(size_t n)
+// the three buffer sets a sort moves between: 0 = caller's input (read-only), 1 = scratch, 2 = caller's output
+struct Buffers {
+    const uint32_t *k0, *v0, *w0;
+    uint32_t *k1, *v1, *w1;
+    uint32_t *k2, *v2, *w2;
+};
+__device__ __forceinline__ const uint32_t *rd_k(const Buffers &b, int i) { return i == 0 ? b.k0 : (i == 1 ? b.k1 : b.k2); }
+__device__ __forceinline__ const uint32_t *rd_v(const Buffers &b, int i) { return i == 0 ? b.v0 : (i == 1 ? b.v1 : b.v2); }
+__device__ __forceinline__ const uint32_t *rd_w(const Buffers &b, int i) { return i == 0 ? b.w0 : (i == 1 ? b.w1 : b.w2); }
+__device__ __forceinline__ uint32_t *wr_k(const Buffers &b, int i) { return i == 1 ? b.k1 : b.k2; }
+__device__ __forceinline__ uint32_t *wr_v(const Buffers &b, int i) { return i == 1 ? b.v1 : b.v2; }
+__device__ __forceinline__ uint32_t *wr_w(const Buffers &b, int i) { return i == 1 ? b.w1 : b.w2; }
+
+// The e-th EXECUTED pass writes buffer set target(e) and reads target(e-1) (the input for e == 0).  `phase` is chosen
+// on the host so that a sort that executes every pass ends in the output set.
+__device__ __host__ __forceinline__ int target_of(int e, int phase) { return ((e + phase) & 1) ? 2 : 1; }
+__device__ __forceinline__ int executed_before(const uint32_t *skip, int pass)
 {
-    // Few, fat tiles: the look-back chain grows with the tile count and costs ~2 us of agent-scope round
-    // trip per window of LOOKBACK_WINDOW tiles; 16 waves per tile keep the CU busy meanwhile.
-    if (n <= (size_t)128 * 1024) return 2;
-    if (n <= (size_t)2 * 1024 * 1024) return 8;
-    return 16;
+    int e = 0;
+    for (int q = 0; q < pass; ++q) e += skip[q] ? 0 : 1;
+    return e;
+}
+
+// LDS digit arrays are padded by one word per 32 digits: the per-digit epilogue walks them with a stride of radix/256
+// words per lane, which would otherwise land on 2 of the 32 banks.
+__device__ __host__ __forceinline__ uint32_t pidx(uint32_t d) { return d + (d >> 5); }
+
+// ---------------------------------------------------------------------------------------------------------- upsweep
+__global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
+                                                                int phase, const uint32_t *__restrict__ skip,
+                                                                uint32_t *__restrict__ H)
+{
+    __shared__ uint32_t hist[RS_MAX_RADIX];
+    const uint32_t radix = 1u << bits;
+    const int e = executed_before(skip, pass);
+    const uint32_t *__restrict__ keys = rd_k(buf, e == 0 ? 0 : target_of(e - 1, phase));
+    for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) hist[d] = 0;
+    __syncthreads();
+    const uint32_t base = blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int i = 0; i < RS_IPT; ++i) {
+        const uint32_t idx = base + (uint32_t)i * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & (radix - 1u)], 1u);
+    }
+    __syncthreads();
+    uint32_t *__restrict__ row = H + (size_t)blockIdx.x * radix;
+    for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) row[d] = hist[d];
+}
+
+// ------------------------------------------------------------------------------------------------------------- scan
+// H[t][d] <- sum of H[t'][d] over t' < t (exclusive, per digit); totals[d] = column sum.  One workgroup owns 32
+// consecutive digits; its 8 thread rows split the tile range, so every access is a full 128-byte row segment.
+__global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__restrict__ H, uint32_t ntiles, int bits, uint32_t n,
+                                                             int pass, int allow_skip, uint32_t *__restrict__ skip,
+                                                             uint32_t *__restrict__ totals)
+{
+    __shared__ uint32_t part[RS_SCAN_ROWS][RS_SCAN_DIGITS];
+    const uint32_t radix = 1u << bits;
+    const uint32_t dl = threadIdx.x % RS_SCAN_DIGITS, row = threadIdx.x / RS_SCAN_DIGITS;
+    const uint32_t d = blockIdx.x * RS_SCAN_DIGITS + dl;
+    const uint32_t per = (ntiles + RS_SCAN_ROWS - 1) / RS_SCAN_ROWS;
+    const uint32_t t0 = row * per, t1 = min(ntiles, t0 + per);
+    uint32_t sum = 0;
+    if (d < radix)
+        for (uint32_t t = t0; t < t1; ++t) sum += H[(size_t)t * radix + d];
+    part[row][dl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int r = 0; r < RS_SCAN_ROWS; ++r) {
+        const uint32_t v = part[r][dl];
+        if ((uint32_t)r < row) run += v;
+        total += v;
+    }
+    if (d < radix) {
+        for (uint32_t t = t0; t < t1; t += 8) {   // 8 loads in flight, then the 8 dependent stores
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (t + u < t1) ? H[(size_t)(t + u) * radix + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (t + u < t1) H[(size_t)(t + u) * radix + d] = run;
+                run += v[u];
+            }
+        }
+        if (row == 0) {
+            totals[d] = total;
+            if (allow_skip && total == n) skip[pass] = 1u;   // every key has this digit: the pass would be the identity
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------------- downsweep
+// INV (single-pass sorts only): instead of scattering keys and the identity payload (out[pos] = index), write the INVERSE
+// permutation inv[index] = pos -- a coalesced store -- and scatter only the second payload.  Scattered 4-byte stores
+// from 8 XCDs into the same cache lines are the expensive part of a wide-digit pass; this cuts them by 3x.
+template <bool HAS_W, bool INV>
+__global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
+                                                                  int phase, const uint32_t *__restrict__ skip,
+                                                                  const uint32_t *__restrict__ H,
+                                                                  const uint32_t *__restrict__ totals,
+                                                                  uint32_t *__restrict__ inv)
+{
+    extern __shared__ uint32_t smem[];
+    const uint32_t radix = 1u << bits;
+    const uint32_t prad = pidx(radix);                 // padded row length
+    uint32_t *wave_hist = smem;                        // [RS_WAVES][prad] per-wave digit counts -> exclusive wave offsets
+    uint32_t *digit_off = smem + RS_WAVES * prad;      // [prad] global position of this tile's first key of each digit
+    __shared__ uint32_t wsum[RS_WAVES];
+
+    if (skip[pass]) return;
+    const int e = executed_before(skip, pass);
+    const int src = e == 0 ? 0 : target_of(e - 1, phase), dst = target_of(e, phase);
+    const uint32_t *__restrict__ kin = rd_k(buf, src);
+    const uint32_t *__restrict__ vin = rd_v(buf, src);
+    const uint32_t *__restrict__ win = rd_w(buf, src);
+    uint32_t *__restrict__ kout = wr_k(buf, dst);
+    uint32_t *__restrict__ vout = wr_v(buf, dst);
+    uint32_t *__restrict__ wout = wr_w(buf, dst);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < RS_WAVES * prad; i += RS_THREADS) wave_hist[i] = 0;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t base = tile * RS_TILE + (uint32_t)wave * (64u * RS_IPT);
+
+    // ---- load the wave's 1024 consecutive keys (rows of 64), every load in flight before the first use
+    uint32_t key[RS_IPT], val[RS_IPT], wal[RS_IPT], rank[RS_IPT];
+#pragma unroll
+    for (int i = 0; i < RS_IPT; ++i) {
+        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
+        key[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
+    }
+#pragma unroll
+    for (int i = 0; i < RS_IPT; ++i) {
+        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
+        val[i] = (!INV && vin && idx < n) ? vin[idx] : idx;   // absent value array = identity (only ever the input set)
+        wal[i] = (HAS_W && idx < n) ? win[idx] : 0u;
+    }
+    __syncthreads();
+    // ---- rank: rows in key order; lanes holding the same digit find each other with one ballot per digit bit
+    uint32_t *wh = wave_hist + wave * prad;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int i = 0; i < RS_IPT; ++i) {
+        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
+        const bool valid = idx < n;
+        const uint32_t d = (key[i] >> shift) & (radix - 1u);
+        unsigned long long peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < RS_MAX_BITS; ++b) {
+            if (b < bits) {   // wave-uniform
+                const bool bit = (d >> b) & 1u;
+                const unsigned long long vote = __ballot(bit);
+                peers &= bit ? vote : ~vote;
+            }
+        }
+        const uint32_t before = wh[pidx(d)];
+        rank[i] = before + (uint32_t)__popcll(peers & lt_mask);
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers & lt_mask) == 0ull) wh[pidx(d)] = before + (uint32_t)__popcll(peers);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // ---- per digit: exclusive offsets of the waves inside the tile; digit base = exclusive scan of the totals
+    const uint32_t dpt = radix / RS_THREADS > 0 ? radix / RS_THREADS : 1;   // consecutive digits per thread
+    uint32_t tsum = 0;
+    for (uint32_t j = 0; j < dpt; ++j) {
+        const uint32_t d = tid * dpt + j;
+        if (d < radix) tsum += totals[d];
+    }
+    uint32_t incl = tsum;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        const uint32_t up = __shfl_up(incl, s);
+        if (lane >= s) incl += up;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t dbase = incl - tsum;
+    for (int w = 0; w < wave; ++w) dbase += wsum[w];
+    const uint32_t *__restrict__ hrow = H + (size_t)tile * radix;
+    for (uint32_t j = 0; j < dpt; ++j) {
+        const uint32_t d = tid * dpt + j;
+        if (d < radix) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < RS_WAVES; ++w) {
+                const uint32_t c = wave_hist[w * prad + pidx(d)];
+                wave_hist[w * prad + pidx(d)] = run;
+                run += c;
+            }
+            digit_off[pidx(d)] = dbase + hrow[d];
+            dbase += totals[d];
+        }
+    }
+    __syncthreads();
+
+    // ---- scatter
+#pragma unroll
+    for (int i = 0; i < RS_IPT; ++i) {
+        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
+        if (idx < n) {
+            const uint32_t d = (key[i] >> shift) & (radix - 1u);
+            const uint32_t pos = digit_off[pidx(d)] + wh[pidx(d)] + rank[i];
+            if (INV) {
+                inv[idx] = pos;
+            } else {
+                kout[pos] = key[i];
+                vout[pos] = val[i];
+            }
+            if (HAS_W) wout[pos] = wal[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------- finalize
+// With pass skipping the result may sit in the input or the scratch set: move it to the output set.
+template <bool HAS_W>
+__global__ void __launch_bounds__(RS_THREADS) rs_finalize_kernel(Buffers buf, uint32_t n, int npass, int phase,
+                                                                 const uint32_t *__restrict__ skip)
+{
+    const int E = executed_before(skip, npass);
+    const int loc = E == 0 ? 0 : target_of(E - 1, phase);
+    if (loc == 2) return;
+    const uint32_t *__restrict__ k = rd_k(buf, loc);
+    const uint32_t *__restrict__ v = rd_v(buf, loc);
+    const uint32_t *__restrict__ w = rd_w(buf, loc);
+    for (uint32_t i = blockIdx.x * RS_THREADS + threadIdx.x; i < n; i += gridDim.x * RS_THREADS) {
+        buf.k2[i] = k[i];
+        buf.v2[i] = v ? v[i] : i;
+        if (HAS_W) buf.w2[i] = w[i];
+    }
 }
 
 struct SortTemp {
-    uint32_t *keys_alt, *vals_alt;
-    uint32_t *ghist;    // [MAX_PASSES][MAX_RADIX]
-    uint32_t *ticket;   // [MAX_PASSES]
-    uint32_t *error;    // [1]
-    uint32_t *status;   // [npass][ntiles][MAX_RADIX]
-    size_t zero_off, zero_bytes, bytes;
-    static SortTemp carve(char *chunk, size_t n, size_t ntiles)
+    uint32_t *keys_alt, *vals_alt, *vals2_alt;
+    uint32_t *H;        // [ntiles][radix_max_used]
+    uint32_t *totals;   // [RS_MAX_RADIX]
+    uint32_t *skip;     // [RS_MAX_PASSES]
+    size_t bytes;
+    static SortTemp carve(char *chunk, size_t n)
     {
         SortTemp t;
         Bump b(chunk);
+        const size_t ntiles = (n + RS_TILE - 1) / RS_TILE;
         t.keys_alt = b.take<uint32_t>(n);
         t.vals_alt = b.take<uint32_t>(n);
-        t.zero_off = b.offset_of_next();
-        t.ghist = b.take<uint32_t>(MAX_PASSES * MAX_RADIX);
-        t.ticket = b.take<uint32_t>(MAX_PASSES);
-        t.error = b.take<uint32_t>(1);
-        t.status = b.take<uint32_t>((size_t)MAX_PASSES * ntiles * MAX_RADIX);
-        t.zero_bytes = b.off - t.zero_off;
+        t.vals2_alt = b.take<uint32_t>(n);
+        t.H = b.take<uint32_t>(ntiles * RS_MAX_RADIX);
+        t.totals = b.take<uint32_t>(RS_MAX_RADIX);
+        t.skip = b.take<uint32_t>(RS_MAX_PASSES * 2);
         t.bytes = b.total();
         return t;
     }
 };
 
-__device__ __forceinline__ uint32_t ld_agent(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent(uint32_t *p, uint32_t v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// counts every digit place of every key in one read of the key array.  The LDS histogram is replicated
-// HIST_COPIES times (copy = lane & 7): depth keys share their high byte, and 64 lanes hammering one LDS
-// counter serialise 64-way.
-constexpr int HIST_COPIES = 8;
-__global__ void __launch_bounds__(SORT_THREADS) radix_hist_kernel(const uint32_t *__restrict__ keys, uint32_t n,
-                                                                  PassPlan plan, uint32_t *__restrict__ ghist)
-{
-    __shared__ uint32_t h[HIST_COPIES][MAX_PASSES * MAX_RADIX];
-    for (int i = threadIdx.x; i < HIST_COPIES * MAX_PASSES * MAX_RADIX; i += SORT_THREADS) (&h[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t stride = gridDim.x * SORT_THREADS;
-    uint32_t *mine = h[threadIdx.x & (HIST_COPIES - 1)];
-    for (uint32_t i = blockIdx.x * SORT_THREADS + threadIdx.x; i < n; i += stride) {
-        const uint32_t k = keys[i];
-#pragma unroll
-        for (int p = 0; p < MAX_PASSES; ++p)
-            if (p < plan.npass) atomicAdd(&mine[p * MAX_RADIX + ((k >> plan.shift[p]) & ((1u << plan.bits[p]) - 1u))], 1u);
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < MAX_PASSES * MAX_RADIX; i += SORT_THREADS) {
-        uint32_t c = 0;
-#pragma unroll
-        for (int j = 0; j < HIST_COPIES; ++j) c += h[j][i];
-        if (c) atomicAdd(&ghist[i], c);
-    }
-}
-
-template <int IPT>
-__global__ void __launch_bounds__(PASS_THREADS) radix_pass_kernel(
-    const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t *__restrict__ kout,
-    uint32_t *__restrict__ vout, uint32_t n, int shift, int bits, const uint32_t *__restrict__ ghist,
-    uint32_t *__restrict__ ticket, uint32_t *__restrict__ status, uint32_t *__restrict__ error)
-{
-    constexpr uint32_t TILE = PASS_THREADS * IPT;
-    __shared__ uint32_t wave_hist[PASS_WAVES][MAX_RADIX];   // per-wave digit counts, then exclusive wave offsets
-    __shared__ uint32_t bin_base[MAX_RADIX];                // global position of the tile's first key per digit
-    __shared__ uint32_t tile_start[MAX_RADIX];              // position of the digit's first key inside the tile
-    __shared__ uint32_t scan_tmp[4], scan_tmp2[4];
-    __shared__ uint32_t s_key[TILE], s_val[TILE];           // the tile, regrouped by digit, for coalesced stores
-    __shared__ uint32_t s_tile;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t radix = 1u << bits;
-    if (tid == 0) s_tile = atomicAdd(ticket, 1u);
-    for (int i = tid; i < PASS_WAVES * MAX_RADIX; i += PASS_THREADS) (&wave_hist[0][0])[i] = 0;
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint32_t base = tile * TILE + (uint32_t)wave * (64u * IPT);
-
-    // ---- load the tile's keys and values up front: every load is in flight before the first use
-    uint32_t key[IPT], val[IPT], rank[IPT];
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
-        key[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
-        val[i] = idx < n ? vin[idx] : 0u;
-    }
-    // ---- rank: wave-synchronous 64-wide digit matching, rows in key order.  The 8 ballots of a row are
-    // independent (digit bits above `bits` are 0 in every lane, so their term is all-ones) and are combined
-    // with a tree of ANDs: the dependent chain per row is ~6 instructions, 16 waves per CU cover its latency.
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
-        const bool valid = idx < n;
-        const uint32_t d = (key[i] >> shift) & (radix - 1u);
-        unsigned long long m[8];
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const unsigned long long vote = __ballot(bit);
-            m[b] = bit ? vote : ~vote;
-        }
-        const unsigned long long peers =
-            __ballot(valid) & ((m[0] & m[1]) & (m[2] & m[3])) & ((m[4] & m[5]) & (m[6] & m[7]));
-        const uint32_t before = wave_hist[wave][d];
-        rank[i] = before + (uint32_t)__popcll(peers & lt_mask);
-        if (valid && (peers & lt_mask) == 0ull) wave_hist[wave][d] = before + (uint32_t)__popcll(peers);
-    }
-    __syncthreads();
-
-    // ---- thread d owns digit d: wave offsets, tile total, look-back, global base
-    uint32_t total = 0, gcount = 0;
-    if ((uint32_t)tid < radix) {
-#pragma unroll
-        for (int w = 0; w < PASS_WAVES; ++w) {
-            const uint32_t c = wave_hist[w][tid];
-            wave_hist[w][tid] = total;
-            total += c;
-        }
-        gcount = ghist[tid];
-        st_agent(&status[(size_t)tile * MAX_RADIX + tid], (tile == 0 ? FLAG_INC : FLAG_AGG) | total);
-    }
-    // exclusive scan of the global digit histogram (first 256 threads) -> first output position of each digit
-    // ... and of the tile's own digit counts -> where each digit's run starts inside the regrouped tile
-    uint32_t digit_start = 0, local_start = 0;
-    if (tid < MAX_RADIX) {
-        uint32_t incl = gcount, incl2 = total;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d);
-            if (lane >= d) { incl += up; incl2 += up2; }
-        }
-        if (lane == 63) { scan_tmp[wave] = incl; scan_tmp2[wave] = incl2; }
-        digit_start = incl - gcount;
-        local_start = incl2 - total;
-    }
-    __syncthreads();
-    if (tid < MAX_RADIX) {
-        for (int w = 0; w < wave; ++w) { digit_start += scan_tmp[w]; local_start += scan_tmp2[w]; }
-        tile_start[tid] = local_start;
-    }
-    __syncthreads();
-    // regroup the tile by digit in LDS while the look-back is in flight (stable: rank keeps key order)
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
-        if (idx < n) {
-            const uint32_t d = (key[i] >> shift) & (radix - 1u);
-            const uint32_t pos = tile_start[d] + wave_hist[wave][d] + rank[i];
-            s_key[pos] = key[i];
-            s_val[pos] = val[i];
-        }
-    }
-
-    if ((uint32_t)tid < radix) {
-        uint32_t excl = 0;
-        if (tile > 0) {
-            // walk back over earlier tiles, LOOKBACK_WINDOW independent polls in flight at a time: a tile that
-            // already resolved its own prefix (FLAG_INC) ends the walk, aggregates are summed on the way
-            uint32_t t = tile, spins = 0;
-            bool done = false;
-            while (!done) {
-                const uint32_t wlen = min(t, (uint32_t)LOOKBACK_WINDOW);
-                uint32_t sv[LOOKBACK_WINDOW];
-#pragma unroll
-                for (int j = 0; j < LOOKBACK_WINDOW; ++j)
-                    sv[j] = (uint32_t)j < wlen ? ld_agent(&status[(size_t)(t - 1 - j) * MAX_RADIX + tid]) : FLAG_INC;
-                uint32_t used = 0;
-#pragma unroll
-                for (int j = 0; j < LOOKBACK_WINDOW; ++j) {
-                    if (done || used != (uint32_t)j) continue;   // stop at the first unpublished entry
-                    if (sv[j] == 0) continue;
-                    excl += sv[j] & VALUE_MASK;
-                    ++used;
-                    if (sv[j] & FLAG_INC) done = true;
-                }
-                t -= min(used, wlen);
-                if (t == 0) done = true;
-                if (!done && used == 0) {
-                    if (++spins > SPIN_LIMIT) { atomicOr(error, 1u); break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            st_agent(&status[(size_t)tile * MAX_RADIX + tid], FLAG_INC | (excl + total));
-        }
-        bin_base[tid] = digit_start + excl;
-    }
-    __syncthreads();
-
-    // ---- store: slot j of the regrouped tile goes to bin_base[d] + (j - tile_start[d]); consecutive slots of
-    // one digit are consecutive in memory, so a wave writes a few contiguous runs instead of 64 scattered words
-    const uint32_t tile_n = min(TILE, n - tile * TILE);
-#pragma unroll
-    for (int i = 0; i < IPT; ++i) {
-        const uint32_t j = (uint32_t)i * PASS_THREADS + (uint32_t)tid;
-        if (j < tile_n) {
-            const uint32_t k = s_key[j];
-            const uint32_t d = (k >> shift) & (radix - 1u);
-            const uint32_t dst = bin_base[d] + (j - tile_start[d]);
-            kout[dst] = k;
-            vout[dst] = s_val[j];
-        }
-    }
-}
-
-template <int IPT>
-void launch_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, uint32_t n, int shift,
-                 int bits, const uint32_t *ghist, uint32_t *ticket, uint32_t *status, uint32_t *error, uint32_t ntiles,
-                 hipStream_t s)
-{
-    radix_pass_kernel<IPT><<<dim3(ntiles), dim3(PASS_THREADS), 0, s>>>(kin, vin, kout, vout, n, shift, bits, ghist,
-                                                                       ticket, status, error);
-}
-
 }  // namespace
 
-size_t sort_temp_bytes(size_t n)
+size_t sort_temp_bytes(size_t n) { return SortTemp::carve(nullptr, n).bytes; }
+
+int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
+                  const uint32_t *win, uint32_t *wout, size_t n, int end_bit, bool allow_skip, const uint32_t **totals_out,
+                  hipStream_t s)
 {
-    const size_t tile = (size_t)PASS_THREADS * items_per_thread(n);
-    return SortTemp::carve(nullptr, n, (n + tile - 1) / tile).bytes;
+    if (totals_out) *totals_out = nullptr;
+    if (n == 0) return 0;
+    if (n >= (size_t)1 << 31) {
+        set_error("sort_pairs: %zu pairs exceed the 2^31 index range", n);
+        return R2_ERR_INVALID;
+    }
+    const SortTemp t = SortTemp::carve(reinterpret_cast<char *>(temp), n);
+    if (t.bytes > temp_bytes) {
+        set_error("sort_pairs: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
+        return R2_ERR_INVALID;
+    }
+    const Plan plan = make_plan(end_bit);
+    const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const int phase = plan.npass & 1;
+    const bool has_w = win != nullptr;
+    Buffers buf{kin, vin, win, t.keys_alt, t.vals_alt, t.vals2_alt, kout, vout, wout};
+    R2_HIP_TRY(hipMemsetAsync(t.skip, 0, sizeof(uint32_t) * RS_MAX_PASSES * 2, s));
+    for (int p = 0; p < plan.npass; ++p) {
+        const int bits = plan.bits[p], radix = 1 << bits;
+        rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip,
+                                                                     t.H);
+        rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
+            t.H, ntiles, bits, (uint32_t)n, p, allow_skip ? 1 : 0, t.skip, t.totals);
+        const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
+        if (has_w)
+            rs_downsweep_kernel<true, false><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr);
+        else
+            rs_downsweep_kernel<false, false><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr);
+    }
+    if (allow_skip) {
+        const uint32_t grid = (uint32_t)std::min<size_t>(1024, (n + RS_THREADS - 1) / RS_THREADS);
+        if (has_w) rs_finalize_kernel<true><<<dim3(grid), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, plan.npass, phase, t.skip);
+        else rs_finalize_kernel<false><<<dim3(grid), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, plan.npass, phase, t.skip);
+    }
+    if (totals_out && plan.npass == 1) *totals_out = t.totals;   // bucket sizes of the (only) digit
+    R2_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+bool sort_is_single_pass(int end_bit) { return make_plan(end_bit).npass == 1; }
+
+// Single-pass stable sort of n instances by tile id (end_bit <= 12 bits): ids_out[pos] = ids[index] (scattered),
+// inv_out[index] = pos (coalesced), *counts_out = device pointer to the per-tile instance counts.
+int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
+                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s)
+{
+    if (counts_out) *counts_out = nullptr;
+    if (n == 0) return 0;
+    const Plan plan = make_plan(end_bit);
+    if (plan.npass != 1 || n >= (size_t)1 << 31) {
+        set_error("sort_by_tile_single_pass: %d key bits / %zu instances not supported", end_bit, n);
+        return R2_ERR_INVALID;
+    }
+    const SortTemp t = SortTemp::carve(reinterpret_cast<char *>(temp), n);
+    if (t.bytes > temp_bytes) {
+        set_error("sort_by_tile_single_pass: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
+        return R2_ERR_INVALID;
+    }
+    const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    const int bits = plan.bits[0], radix = 1 << bits, phase = 1;
+    Buffers buf{tiles, nullptr, ids, nullptr, nullptr, nullptr, nullptr, nullptr, ids_out};
+    R2_HIP_TRY(hipMemsetAsync(t.skip, 0, sizeof(uint32_t) * RS_MAX_PASSES * 2, s));
+    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H);
+    rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
+        t.H, ntiles, bits, (uint32_t)n, 0, 0, t.skip, t.totals);
+    const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
+    rs_downsweep_kernel<true, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip,
+                                                                                t.H, t.totals, inv_out);
+    if (counts_out) *counts_out = t.totals;
+    R2_HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                        uint32_t *vout, size_t n, int end_bit, hipStream_t s)
 {
-    if (n == 0) return 0;
-    if (n >= (size_t)VALUE_MASK) {
-        set_error("sort_pairs_u32_u32: %zu pairs exceed the 2^30 look-back counter range", n);
-        return R2_ERR_INVALID;
-    }
-    const int ipt = items_per_thread(n);
-    const size_t tile = (size_t)PASS_THREADS * ipt;
-    const uint32_t ntiles = (uint32_t)((n + tile - 1) / tile);
-    const SortTemp t = SortTemp::carve(reinterpret_cast<char *>(temp), n, ntiles);
-    if (t.bytes > temp_bytes) {
-        set_error("sort_pairs_u32_u32: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
-        return R2_ERR_INVALID;
-    }
-    const PassPlan plan = make_plan(end_bit);
-    R2_HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(temp) + t.zero_off, 0, t.zero_bytes, s));
-    const uint32_t hist_blocks = (uint32_t)std::min<size_t>(512, (n + SORT_THREADS * 4 - 1) / (SORT_THREADS * 4));
-    radix_hist_kernel<<<dim3(hist_blocks), dim3(SORT_THREADS), 0, s>>>(kin, (uint32_t)n, plan, t.ghist);
-    const uint32_t *src_k = kin, *src_v = vin;
-    for (int p = 0; p < plan.npass; ++p) {
-        const bool to_out = ((plan.npass - p) & 1) != 0;   // the last pass lands in (kout, vout)
-        uint32_t *dst_k = to_out ? kout : t.keys_alt, *dst_v = to_out ? vout : t.vals_alt;
-        uint32_t *st = t.status + (size_t)p * ntiles * MAX_RADIX;
-        const uint32_t *gh = t.ghist + p * MAX_RADIX;
-        switch (ipt) {
-        case 2: launch_pass<2>(src_k, src_v, dst_k, dst_v, (uint32_t)n, plan.shift[p], plan.bits[p], gh, t.ticket + p, st, t.error, ntiles, s); break;
-        case 8: launch_pass<8>(src_k, src_v, dst_k, dst_v, (uint32_t)n, plan.shift[p], plan.bits[p], gh, t.ticket + p, st, t.error, ntiles, s); break;
-        default: launch_pass<16>(src_k, src_v, dst_k, dst_v, (uint32_t)n, plan.shift[p], plan.bits[p], gh, t.ticket + p, st, t.error, ntiles, s); break;
-        }
-        src_k = dst_k;
-        src_v = dst_v;
-    }
-    R2_HIP_TRY(hipGetLastError());
-    return 0;
+    return sort_pairs_ex(temp, temp_bytes, kin, kout, vin, vout, nullptr, nullptr, n, end_bit, false, nullptr, s);
 }
 
 }  // namespace r2

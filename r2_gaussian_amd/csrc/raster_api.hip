@@ -49,8 +49,8 @@ extern "C" int r2_raster_forward(
     int rc;
     // Gaussians in (depth, id) order; instance runs are then laid out in that order
     { StageScope t(ST_RAS_DEPTHSORT, s);
-    rc = sort_pairs_u32_u32(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order,
-                            (size_t)P, 32, s); }
+    rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
+                       nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "depth sort");
     { StageScope t(ST_RAS_SCAN, s);
@@ -75,20 +75,35 @@ extern "C" int r2_raster_forward(
     const RasterBinning bin = RasterBinning::carve(bchunk, R);
     const RasterImage img = RasterImage::carve(ichunk, T, N, R, debug != 0);
 
+    const uint32_t *tile_counts = nullptr;
     if (R > 0) {
         { StageScope t(ST_RAS_DUPLICATE, s);
         launch_raster_duplicate(geom, bin, P, radii, width, height, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
+        // stable sort by tile id; payloads: the emission index (-> perm, the backward's scratch row) and the Gaussian
+        // id (-> point_list)
         { StageScope t(ST_RAS_SORT, s);
-        rc = sort_pairs_u32_u32(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.iota, bin.perm, R,
-                                bit, s); }
+        if (sort_is_single_pass(bit)) {
+            rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
+                                          bin.inv, R, bit, &tile_counts, s);
+        } else {   // > 4096 tiles: general multi-pass sort, then invert its permutation (the scratch is free until backward)
+            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);
+            rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
+                               bin.point_list, R, bit, false, nullptr, s);
+            if (!rc) rc = invert_permutation(perm, bin.inv, R, s);
+        } }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_RAS_RANGES, s);
-    rc = tile_ranges(bin.tiles, bin.perm, bin.vals_unsorted, bin.point_list, R, img.ranges, T, s); }
-    if (rc) return rc;
+    if (tile_counts) {   // single-pass sort: per-tile counts are a by-product
+        launch_ranges_and_work(tile_counts, (uint32_t)T, FWD_CHUNK, img.ranges, img.chunk_base, img.work_tile, s);
+    } else {
+        rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
+        if (rc) return rc;
+        launch_build_work(img.ranges, (uint32_t)T, FWD_CHUNK, img.chunk_base, img.work_tile, s);
+    } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
     launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, s); }
@@ -104,7 +119,6 @@ extern "C" int r2_raster_backward(
     float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, void *stream)
 {
     (void)campos;
-    (void)img_buffer;   // the backward needs only the geometry and binning state
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return 0;
     if (P < 0 || R < 0 || !means3D || !radii || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
@@ -115,6 +129,16 @@ extern "C" int r2_raster_backward(
     }
     const RasterGeom geom = RasterGeom::carve(geom_buffer, P);
     const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
+    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
+    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)(gx * gy)))) {
+        // the single-pass tile sort did not scatter its keys: recover the per-instance tile ids from the ranges
+        if (!img_buffer) {
+            set_error("r2_raster_backward: image state required");
+            return R2_ERR_INVALID;
+        }
+        const RasterImage img = RasterImage::carve(img_buffer, (size_t)gx * gy, (size_t)width * height, (size_t)R, false);
+        fill_tiles_from_ranges(img.ranges, (size_t)gx * gy, bin.tiles, s);
+    }
 
     { StageScope t(ST_RAS_RENDER_BWD, s);
     launch_raster_render_backward(geom, bin, width, height, (size_t)R, dL_dpix, s); }
@@ -123,7 +147,7 @@ extern "C" int r2_raster_backward(
     { StageScope t(ST_RAS_GEOM_BWD, s);
     launch_raster_geom_backward(P, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
                                 tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D,
-                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, s); }
+                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, bin.inv, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }
@@ -165,7 +189,7 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     case 10: p = (char *)g.depth_key; buf = 0; break;
     case 12: p = (char *)g.order; buf = 0; break;
     case 11: p = (char *)g.first; buf = 0; break;
-    case 13: p = (char *)b.perm; buf = 1; break;
+    case 13: p = (char *)b.inv; buf = 1; break;
     case 14: p = (char *)g.op_mu; buf = 0; break;
     default: return -1;
     }

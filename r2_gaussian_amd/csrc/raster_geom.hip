@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 __global__ void __launch_bounds__(256) raster_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
-    uint32_t *__restrict__ vals, uint32_t *__restrict__ iota)
+    uint32_t *__restrict__ vals)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -226,7 +226,6 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
             const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
             tiles[k] = (uint32_t)(ty * gx + tx);
             vals[k] = o_id;
-            iota[k] = k;
         }
     }
 }
@@ -244,7 +243,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
     const float *__restrict__ proj, const float4 *__restrict__ rec, const float2 *__restrict__ op_mu,
-    const uint32_t *__restrict__ first_inst,
+    const uint32_t *__restrict__ first_inst, const uint32_t *__restrict__ inv,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
     float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
@@ -257,10 +256,27 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
     const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
-    for (uint32_t j = 0; j < ninst; ++j) {
-        const float4 m0 = part[2 * (size_t)(first + j)];
-        const float4 m1 = part[2 * (size_t)(first + j) + 1];
-        S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
+    // rows are gathered through the inverse permutation of the tile sort; 4 at a time so that the two dependent
+    // round trips (inv -> row) of different instances overlap.  The summation order stays j = 0, 1, 2, ...
+    for (uint32_t j = 0; j < ninst; j += 4) {
+        uint32_t row[4];
+        float4 m0[4], m1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) row[u] = (j + u < ninst) ? inv[first + j + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (j + u < ninst) {
+                m0[u] = part[2 * (size_t)row[u]];
+                m1[u] = part[2 * (size_t)row[u] + 1];
+            } else {
+                m0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                m1[u] = m0[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            S0 += m0[u].x; S1 += m0[u].y; S2 += m0[u].z; S3 += m0[u].w; S4 += m1[u].x; S5 += m1[u].y;
+        }
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
     const float2 om = op_mu[idx];
@@ -399,8 +415,7 @@ int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, 
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii, gx, gy,
-                                                                        g.first, b.tiles_unsorted, b.vals_unsorted,
-                                                                        b.iota);
+                                                                        g.first, b.tiles_unsorted, b.vals_unsorted);
     return 0;
 }
 
@@ -415,13 +430,13 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float tan_fovy, const float *view, const float *proj, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
-                                const float *part, hipStream_t s)
+                                const float *part, const uint32_t *inv, hipStream_t s)
 {
     const float h_y = H / (2.0f * tan_fovy);
     const float h_x = W / (2.0f * tan_fovx);
     raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
-        g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
+        g.op_mu, g.first, inv, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
         dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }

@@ -17,8 +17,8 @@
 //           as b128 broadcasts.  The 7 gradient sums of the reference are linear in 6 moments
 //           sum(w), sum(w dx), sum(w dy), sum(w dx^2), sum(w dx dy), sum(w dy^2), w = G*dL/dpix,
 //           accumulated in registers: no cross-lane reduction, and NO atomics -- each instance stores its
-//           moment row to scratch at its UNSORTED list position (contiguous per Gaussian), which the
-//           geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
+//           moment row to scratch at its SORTED list position (coalesced), which the geometry backward gathers
+//           per Gaussian (inverse permutation of the tile sort) and reduces in a fixed order.  Gradients are therefore bit-reproducible,
 //           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
 //           Workgroups are cut as 256 consecutive instances of the global sorted list: perfect balance.
 //           Waves that straddle many sparse tiles switch to a per-lane gather of dL/dpix instead of
@@ -382,7 +382,7 @@ __device__ __forceinline__ void tile_moments_gather(const float4 a, const float4
 }
 
 __global__ void __launch_bounds__(256) raster_render_backward_kernel(
-    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ perm,
+    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
 {
     constexpr int NB = TILE2D / SUB2D;        // blocks per tile side (2)
@@ -501,10 +501,10 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
         }
     }
     if (live) {
-        // scratch row = the instance's position in the emission list (the sort carried it as payload)
-        const uint32_t u = perm[k];
-        part[2 * (size_t)u] = make_float4(S[0], S[1], S[2], S[3]);
-        part[2 * (size_t)u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
+        // scratch row = the instance's SORTED position: coalesced stores; the geometry backward gathers each Gaussian's
+        // rows through the inverse permutation of the tile sort
+        part[2 * (size_t)k] = make_float4(S[0], S[1], S[2], S[3]);
+        part[2 * (size_t)k + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
 }
 
@@ -514,7 +514,6 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
-    launch_build_work(im.ranges, T, FWD_CHUNK, im.chunk_base, im.work_tile, s);
     if (im.NW > 0) {
         if (write_ncontrib)
             raster_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
@@ -539,7 +538,7 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, i
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, b.perm, g.rec, (uint32_t)R, W, H, gx,
+    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, (uint32_t)R, W, H, gx,
                                                                    nchunks, dL_dpix,
                                                                    reinterpret_cast<float4 *>(b.part));
     return 0;

@@ -62,12 +62,13 @@ struct RasterGeom {
 
 struct RasterBinning {
     uint32_t *tiles_unsorted; // [R]  tile id of every instance, emitted Gaussian by Gaussian in depth order
-    uint32_t *tiles;          // [R]  the same, stably sorted by tile == (tile|depth) order of the reference
+    uint32_t *tiles;          // [R]  tile id of every SORTED instance (written by the multi-pass sort, or filled from the
+                              //      ranges at the start of the backward when the single-pass sort skipped the key scatter)
     uint32_t *vals_unsorted;  // [R]  Gaussian id of every instance (emission order)
-    uint32_t *iota;           // [R]  0..R-1: the sort payload is the emission index itself ...
-    uint32_t *perm;           // [R]  ... so perm[k] = emission index of sorted position k (backward scratch row)
-    uint32_t *point_list;     // [R]  sorted Gaussian ids = vals_unsorted[perm[k]] (the reference's point_list, bit-identical)
-    float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by UNSORTED position
+    uint32_t *inv;            // [R]  sorted position of emission index u (inverse permutation of the tile sort): the
+                              //      backward writes its moment rows in sorted order, the geometry backward gathers them
+    uint32_t *point_list;     // [R]  sorted Gaussian ids (the sort's second payload; the reference's point_list, bit-identical)
+    float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by SORTED position
     char *sort_temp;
     size_t sort_bytes;
     size_t bytes;
@@ -78,8 +79,7 @@ struct RasterBinning {
         s.tiles_unsorted = b.take<uint32_t>(R);
         s.tiles = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
-        s.iota = b.take<uint32_t>(R);
-        s.perm = b.take<uint32_t>(R);
+        s.inv = b.take<uint32_t>(R);
         s.point_list = b.take<uint32_t>(R);
         s.part = b.take<float>(R * PART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);
@@ -127,7 +127,7 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float tan_fovy, const float *view, const float *proj, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
-                                const float *part, hipStream_t s);
+                                const float *part, const uint32_t *inv, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
                                  float *out_color, bool write_ncontrib, hipStream_t s);
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, int W, int H, size_t R,

@@ -57,8 +57,8 @@ extern "C" int r2_voxel_forward(
     R2_STAGE_CHECK(debug, s, "preprocess");
     int rc;
     { StageScope t(ST_VOX_DEPTHSORT, s);
-    rc = sort_pairs_u32_u32(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order,
-                            (size_t)P, 32, s); }
+    rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
+                       nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "depth sort");
     { StageScope t(ST_VOX_SCAN, s);
@@ -78,20 +78,33 @@ extern "C" int r2_voxel_forward(
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0);
+    const uint32_t *tile_counts = nullptr;
     if (R > 0) {
         { StageScope t(ST_VOX_DUPLICATE, s);
         launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         { StageScope t(ST_VOX_SORT, s);
-        rc = sort_pairs_u32_u32(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.iota, bin.perm, R,
-                                bit, s); }
+        if (sort_is_single_pass(bit)) {
+            rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
+                                          bin.inv, R, bit, &tile_counts, s);
+        } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort, then invert its permutation
+            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);
+            rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
+                               bin.point_list, R, bit, false, nullptr, s);
+            if (!rc) rc = invert_permutation(perm, bin.inv, R, s);
+        } }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_VOX_RANGES, s);
-    rc = tile_ranges(bin.tiles, bin.perm, bin.vals_unsorted, bin.point_list, R, img.ranges, T, s); }
-    if (rc) return rc;
+    if (tile_counts) {
+        launch_ranges_and_work(tile_counts, (uint32_t)T, VOX_CHUNK, img.ranges, img.chunk_base, img.work_tile, s);
+    } else {
+        rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
+        if (rc) return rc;
+        launch_build_work(img.ranges, (uint32_t)T, VOX_CHUNK, img.chunk_base, img.work_tile, s);
+    } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_VOX_RENDER_FWD, s);
     launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s); }
@@ -108,7 +121,6 @@ extern "C" int r2_voxel_backward(
     int debug, void *stream)
 {
     (void)means3D;
-    (void)img_buffer;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return 0;
     if (P < 0 || R < 0 || !radii_x || !radii_y || !radii_z || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dvol ||
@@ -120,13 +132,22 @@ extern "C" int r2_voxel_backward(
     const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
+    const size_t T = (size_t)v.gx * v.gy * v.gz;
+    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)T))) {
+        if (!img_buffer) {
+            set_error("r2_voxel_backward: image state required");
+            return R2_ERR_INVALID;
+        }
+        const VoxelImage img = VoxelImage::carve(img_buffer, T, (size_t)v.nx * v.ny * v.nz, (size_t)R, false);
+        fill_tiles_from_ranges(img.ranges, T, bin.tiles, s);
+    }
     { StageScope t(ST_VOX_RENDER_BWD, s);
     launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, s); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_VOX_GEOM_BWD, s);
     launch_voxel_geom_backward(geom, v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
-                               cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, dL_dconic3D,
+                               cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, bin.inv, dL_dconic3D,
                                dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
@@ -155,7 +176,7 @@ extern "C" long long r2_voxel_state_offset(int which, int P, long long R, int nx
     case 10: p = (char *)g.depth_key; buf = 0; break;
     case 11: p = (char *)g.first; buf = 0; break;
     case 12: p = (char *)g.order; buf = 0; break;
-    case 13: p = (char *)b.perm; buf = 1; break;
+    case 13: p = (char *)b.inv; buf = 1; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

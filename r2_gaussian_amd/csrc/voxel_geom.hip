@@ -104,8 +104,7 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
 __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
-    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
-    uint32_t *__restrict__ iota)
+    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -157,7 +156,6 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
             const int x = ox + (int)(rem % (uint32_t)orw);
             tiles[k] = (uint32_t)(z * gy * gx + y * gx + x);
             vals[k] = o_id;
-            iota[k] = k;
         }
     }
 }
@@ -171,7 +169,8 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     int P, const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
     const float *__restrict__ cov3Ds, const float *__restrict__ scales, const float *__restrict__ rotations,
     float scale_modifier, VoxelGrid v, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
-    const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float *__restrict__ dL_dconic3D,
+    const uint32_t *__restrict__ inv, const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part,
+    float *__restrict__ dL_dconic3D,
     float *__restrict__ dL_dmean3D_norm, float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans,
     float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
@@ -185,9 +184,10 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) S[k] = 0.f;
     for (uint32_t j = 0; j < ninst; ++j) {
-        const float4 m0 = part[3 * (size_t)(first + j)];
-        const float4 m1 = part[3 * (size_t)(first + j) + 1];
-        const float4 m2 = part[3 * (size_t)(first + j) + 2];
+        const size_t row = inv[first + j];   // sorted position of this Gaussian's j-th instance
+        const float4 m0 = part[3 * row];
+        const float4 m1 = part[3 * row + 1];
+        const float4 m2 = part[3 * row + 2];
         S[0] += m0.x; S[1] += m0.y; S[2] += m0.z; S[3] += m0.w;
         S[4] += m1.x; S[5] += m1.y; S[6] += m1.z; S[7] += m1.w;
         S[8] += m2.x; S[9] += m2.y;
@@ -271,18 +271,19 @@ int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const Voxe
 {
     voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii_x, radii_y,
                                                                        radii_z, v.gx, v.gy, v.gz, g.first,
-                                                                       b.tiles_unsorted, b.vals_unsorted, b.iota);
+                                                                       b.tiles_unsorted, b.vals_unsorted);
     return 0;
 }
 
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
-                               float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
+                               float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D,
+                               float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s)
 {
     voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, g.tiles_touched,
+        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, inv, g.tiles_touched,
         reinterpret_cast<const float4 *>(part), dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D,
         dL_dscale, dL_drot);
     return 0;

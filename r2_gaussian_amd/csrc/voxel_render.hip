@@ -173,7 +173,7 @@ __device__ __forceinline__ void tile_moments3_gather(const float4 p, const float
 }
 
 __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
-    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ perm,
+    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, uint32_t R, VoxelGrid v, uint32_t nchunks, const float *__restrict__ dL_dvol,
     float4 *__restrict__ part)
 {
@@ -239,10 +239,10 @@ __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
         }
     }
     if (live) {
-        const uint32_t u = perm[k];   // emission index: scratch row, contiguous per Gaussian
-        part[3 * (size_t)u] = make_float4(S[0], S[1], S[2], S[3]);
-        part[3 * (size_t)u + 1] = make_float4(S[4], S[5], S[6], S[7]);
-        part[3 * (size_t)u + 2] = make_float4(S[8], S[9], 0.f, 0.f);
+        // scratch row = sorted position (coalesced); the geometry backward gathers through the inverse permutation
+        part[3 * (size_t)k] = make_float4(S[0], S[1], S[2], S[3]);
+        part[3 * (size_t)k + 1] = make_float4(S[4], S[5], S[6], S[7]);
+        part[3 * (size_t)k + 2] = make_float4(S[8], S[9], 0.f, 0.f);
     }
 }
 
@@ -250,7 +250,6 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
                                 float *out_volume, bool write_ncontrib, hipStream_t s)
 {
     const uint32_t T = (uint32_t)v.gx * v.gy * v.gz;
-    launch_build_work(im.ranges, T, VOX_CHUNK, im.chunk_base, im.work_tile, s);
     if (im.NW > 0) {
         if (write_ncontrib)
             voxel_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
@@ -274,7 +273,7 @@ int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, cons
     if (R == 0) return 0;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    voxel_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, b.perm, g.rec, (uint32_t)R, v,
+    voxel_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, (uint32_t)R, v,
                                                                   nchunks, dL_dvol, reinterpret_cast<float4 *>(b.part));
     return 0;
 }

@@ -49,7 +49,7 @@ struct VoxelGeom {
 struct VoxelBinning {
     uint32_t *tiles_unsorted, *tiles;   // [R]
     uint32_t *vals_unsorted;            // [R] Gaussian id per instance (emission order)
-    uint32_t *iota, *perm;              // [R] sort payload = emission index
+    uint32_t *inv;                      // [R] sorted position of emission index u (inverse permutation of the tile sort)
     uint32_t *point_list;               // [R]
     float *part;                        // [R*VPART_STRIDE] backward scratch
     char *sort_temp;
@@ -62,8 +62,7 @@ struct VoxelBinning {
         s.tiles_unsorted = b.take<uint32_t>(R);
         s.tiles = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
-        s.iota = b.take<uint32_t>(R);
-        s.perm = b.take<uint32_t>(R);
+        s.inv = b.take<uint32_t>(R);
         s.point_list = b.take<uint32_t>(R);
         s.part = b.take<float>(R * VPART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);
@@ -112,7 +111,7 @@ int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const Voxe
                            const int *radii_y, const int *radii_z, hipStream_t s);
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
-                               float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
+                               float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D, float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s);
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,

@@ -9,6 +9,25 @@ from r2_gaussian_amd import scene as S
 LOG2E = 1.4426950408889634
 
 
+def tiles_from_ranges(ranges, R):
+    """Tile id of every sorted instance, from the per-tile ranges (the tile-sorted list is the concatenation of the
+    tile lists in tile order; empty tiles hold (0, 0))."""
+    lengths = (ranges[:, 1].astype(np.int64) - ranges[:, 0].astype(np.int64))
+    assert (lengths >= 0).all() and lengths.sum() == R, "ranges do not partition the sorted list"
+    nz = np.nonzero(lengths)[0]
+    starts = ranges[nz, 0].astype(np.int64)
+    assert np.array_equal(starts, np.cumsum(lengths[nz]) - lengths[nz]), "ranges out of tile order"
+    return np.repeat(np.arange(ranges.shape[0], dtype=np.uint32), lengths)
+
+
+def perm_from_inv(inv):
+    """The state holds inv[emission index] = sorted position; perm[sorted position] = emission index."""
+    perm = np.empty_like(inv)
+    assert np.array_equal(np.sort(inv), np.arange(inv.size, dtype=inv.dtype)), "inv is not a permutation"
+    perm[inv] = np.arange(inv.size, dtype=inv.dtype)
+    return perm
+
+
 def np_view(v):
     return v.world_view_transform.numpy(), v.full_proj_transform.numpy()
 
@@ -57,9 +76,9 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     out["offsets"] = read(1, np.uint32, P)
     out["tiles_unsorted"] = read(2, np.uint32, R)
     out["vals_unsorted"] = read(3, np.uint32, R)
-    out["tiles"] = read(4, np.uint32, R)
     out["point_list"] = read(5, np.uint32, R)
     out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
+    out["tiles"] = tiles_from_ranges(out["ranges"], R)
     out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
     if debug:
         out["n_contrib"] = read(8, np.uint32, H * W)
@@ -69,7 +88,8 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     out["depths"] = out["depth_key"].view(np.float32)
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
-    out["perm"] = read(13, np.uint32, R)
+    out["inv"] = read(13, np.uint32, R)
+    out["perm"] = perm_from_inv(out["inv"])
     # the reference's 64-bit sort keys, reconstructed: (tile << 32) | depth bits of the listed Gaussian
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     # decode the packed render record back to the reference's quantities
@@ -128,16 +148,17 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
     out["offsets"] = read(1, np.uint32, P)
     out["tiles_unsorted"] = read(2, np.uint32, R)
     out["vals_unsorted"] = read(3, np.uint32, R)
-    out["tiles"] = read(4, np.uint32, R)
     out["point_list"] = read(5, np.uint32, R)
     out["ranges"] = read(6, np.uint32, 2 * T).reshape(T, 2)
+    out["tiles"] = tiles_from_ranges(out["ranges"], R)
     out["cov3D"] = read(7, np.float32, 6 * P).reshape(P, 6)
     if debug:
         out["n_contrib"] = read(8, np.uint32, nx * ny * nz)
     out["depth_key"] = read(10, np.uint32, P)
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
-    out["perm"] = read(13, np.uint32, R)
+    out["inv"] = read(13, np.uint32, R)
+    out["perm"] = perm_from_inv(out["inv"])
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     rec = read(9, np.float32, 12 * P).reshape(P, 12)
     out["rec"] = rec

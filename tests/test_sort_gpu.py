@@ -12,9 +12,10 @@ from tests import helpers as Hh
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("P,hw", [(1, 32), (63, 48), (257, 64), (1025, 64), (140000, 256), (600000, 512)])
+@pytest.mark.parametrize("P,hw", [(1, 32), (63, 48), (257, 64), (1025, 64), (140000, 256), (600000, 512), (30000, 1040)])
 def test_sorted_lists_match_oracle_across_sizes(P, hw, oracle, gpu):
-    """P spans the depth-sort variants (<=512k, >512k), R the tile-sort variants (4/8/16 items per thread)."""
+    """P / R span one to hundreds of 4096-key sort tiles with ragged tails; 1040^2 has 4225 tiles = 13 key bits, i.e. the
+    two-pass tile sort + boundary-scan ranges instead of the single-pass sort whose digit totals give the ranges."""
     c = S.make_cloud(P, seed=P % 13, scale_mult=1.3 if P > 1000 else 3.0)
     v = S.make_view(0.1 * (P % 7), (hw, hw))
     o = Hh.oracle_raster(oracle, c, v, render=False)
