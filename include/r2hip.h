@@ -20,8 +20,10 @@
  *   - the library never allocates result/state memory: it asks the caller for bytes through the
  *     three r2_alloc_fn callbacks, the C form of the reference's std::function<char*(size_t)>
  *     (SUB/utility.h:7-13).  The layout inside those buffers is private to the library;
- *   - gradient outputs of the backward calls must be ZERO-INITIALISED by the caller, as the
- *     reference's torch boundary does (SUB/rasterize_points.cu:124-131, SUB/voxelize_points.cu:130-136);
+ *   - gradient outputs of the backward calls are FULLY WRITTEN by the library (all-zero rows for culled
+ *     Gaussians, for the scale/rotation gradients on the cov3D_precomp path, and the unused third component of
+ *     dL_dmean2D): the zero-initialisation the reference's torch boundary performs
+ *     (SUB/rasterize_points.cu:124-131, SUB/voxelize_points.cu:130-136) is not required;
  *   - `stream` is a hipStream_t (NULL = the null stream).  Work is enqueued on it; the forward
  *     calls synchronise that stream once to learn num_rendered (the reference's cudaMemcpy D2H,
  *     rasterizer_impl.cu:279), the backward calls do not synchronise;

@@ -37,21 +37,70 @@ def _require_gpu(t, name):
 
 
 class _State:
-    """Three growable byte tensors + the ctypes callbacks that resize them (SUB/utility.h:7-13)."""
+    """The three opaque state buffers of one forward call, filled through the allocation callbacks (SUB/utility.h:7-13).
 
+    The ctypes callback objects are expensive to create (tens of microseconds) and every forward call needs three, so
+    they are created once per device and write into whichever ``_State`` is current; a forward call is synchronous on
+    the host (it returns num_rendered), so there is exactly one current state per device at any time."""
+
+    __slots__ = ("bufs",)
+
+    def __init__(self):
+        self.bufs = [None, None, None]
+
+
+class _DeviceHooks:
     def __init__(self, device):
         self.device = device
-        self.bufs = [torch.empty(0, dtype=torch.uint8, device=device) for _ in range(3)]
+        self.current = None
+        self.empty = torch.empty(0, dtype=torch.uint8, device=device)
         self.cbs = [_lib.ALLOC_FN(self._make(i)) for i in range(3)]
 
     def _make(self, i):
         def alloc(nbytes, _user):
             try:
-                self.bufs[i] = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
-                return self.bufs[i].data_ptr()
+                t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                self.current.bufs[i] = t
+                return t.data_ptr()
             except Exception:   # out of memory etc.: report NULL, the C side turns it into R2_ERR_ALLOC
                 return None
         return alloc
+
+    def begin(self):
+        st = _State()
+        self.current = st
+        return st
+
+    def finish(self, st):
+        self.current = None
+        return [b if b is not None else self.empty for b in st.bufs]
+
+
+_HOOKS = {}
+
+
+def _hooks(device):
+    h = _HOOKS.get(device)
+    if h is None:
+        h = _HOOKS[device] = _DeviceHooks(device)
+    return h
+
+
+class _on_device:
+    """``with torch.cuda.device(dev)`` only when dev is not already current (the context manager costs ~10 us)."""
+
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == (dev.index or 0) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
 
 
 def _stream(device):
@@ -68,22 +117,28 @@ def rasterize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
-    out_color = torch.zeros((1, H, W), dtype=_F32, device=dev)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
-    st = _State(dev)
-    rendered = 0
-    if P != 0:
-        m3 = _dev_f32(means3D, means3D)
-        op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
-        vm, pm, cam = (_dev_f32(t, means3D) for t in (viewmatrix, projmatrix, campos))
-        with torch.cuda.device(dev):
+    hk = _hooks(dev)
+    if P == 0:   # SUB/rasterize_points.cu:58-70: zero image, no state
+        return 0, torch.zeros((1, H, W), dtype=_F32, device=dev), torch.zeros((0,), dtype=torch.int32, device=dev), \
+            hk.empty, hk.empty, hk.empty
+    # both outputs are written in full by the kernels (every pixel, every Gaussian): no zero-fill needed
+    out_color = torch.empty((1, H, W), dtype=_F32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    m3 = _dev_f32(means3D, means3D)
+    op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
+    vm, pm, cam = (_dev_f32(t, means3D) for t in (viewmatrix, projmatrix, campos))
+    st = hk.begin()
+    try:
+        with _on_device(dev):
             rc = _lib.lib().r2_raster_forward(
-                st.cbs[0], None, st.cbs[1], None, st.cbs[2], None, P, W, H, _ptr(m3), _ptr(op), _ptr(sc),
+                hk.cbs[0], None, hk.cbs[1], None, hk.cbs[2], None, P, W, H, _ptr(m3), _ptr(op), _ptr(sc),
                 float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm), _ptr(cam), float(tan_fovx),
                 float(tan_fovy), int(bool(prefiltered)), int(mode), out_color.data_ptr(), radii.data_ptr(),
                 int(bool(debug)), _stream(dev))
-        rendered = _lib.check(rc, "r2_raster_forward")
-    return rendered, out_color, radii, st.bufs[0], st.bufs[1], st.bufs[2]
+    finally:
+        bufs = hk.finish(st)
+    rendered = _lib.check(rc, "r2_raster_forward")
+    return rendered, out_color, radii, bufs[0], bufs[1], bufs[2]
 
 
 def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix,
@@ -95,8 +150,9 @@ def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifi
     dev = means3D.device
     P = means3D.shape[0]
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
-    # one zero-fill for all eight gradient arrays (25 floats per Gaussian); 16-byte rows first
-    flat = torch.zeros(25 * P, dtype=_F32, device=dev)
+    # one allocation for all eight gradient arrays (25 floats per Gaussian), 16-byte rows first; the kernels write
+    # every row (zeros for culled Gaussians), so no fill
+    flat = torch.empty(25 * P, dtype=_F32, device=dev)
     cuts = [4, 4, 3, 3, 1, 1, 6, 3]
     views, o = [], 0
     for c in cuts:
@@ -116,7 +172,7 @@ def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifi
         vm, pm, cam = (_dev_f32(t, means3D) for t in (viewmatrix, projmatrix, campos))
         g = _dev_f32(dL_dout_color, means3D)
         rad = radii.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().r2_raster_backward(
                 P, int(R), W, H, _ptr(m3), _ptr(sc), float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm),
                 _ptr(cam), float(tan_fovx), float(tan_fovy), rad.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer),
@@ -135,7 +191,7 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     present = torch.zeros((P,), dtype=torch.bool, device=dev)
     if P != 0:
         m3, vm, pm = (_dev_f32(t, means3D) for t in (means3D, viewmatrix, projmatrix))
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().r2_mark_visible(P, _ptr(m3), _ptr(vm), _ptr(pm), present.data_ptr(), _stream(dev))
         _lib.check(rc, "r2_mark_visible")
     return present
@@ -151,21 +207,26 @@ def voxelize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov3
     dev = means3D.device
     P = means3D.shape[0]
     nx, ny, nz = int(nVoxel_x), int(nVoxel_y), int(nVoxel_z)
-    out = torch.zeros((nx, ny, nz), dtype=_F32, device=dev)
-    radii = torch.zeros((3, P), dtype=torch.int32, device=dev)
-    st = _State(dev)
-    rendered = 0
-    if P != 0:
-        m3 = _dev_f32(means3D, means3D)
-        op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
-        with torch.cuda.device(dev):
+    hk = _hooks(dev)
+    if P == 0:
+        z = torch.zeros((0,), dtype=torch.int32, device=dev)
+        return 0, torch.zeros((nx, ny, nz), dtype=_F32, device=dev), z, z.clone(), z.clone(), hk.empty, hk.empty, hk.empty
+    out = torch.empty((nx, ny, nz), dtype=_F32, device=dev)       # written in full by the combine kernel
+    radii = torch.empty((3, P), dtype=torch.int32, device=dev)    # written in full by the preprocess kernel
+    m3 = _dev_f32(means3D, means3D)
+    op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
+    st = hk.begin()
+    try:
+        with _on_device(dev):
             rc = _lib.lib().r2_voxel_forward(
-                st.cbs[0], None, st.cbs[1], None, st.cbs[2], None, P, nx, ny, nz, float(sVoxel_x), float(sVoxel_y),
+                hk.cbs[0], None, hk.cbs[1], None, hk.cbs[2], None, P, nx, ny, nz, float(sVoxel_x), float(sVoxel_y),
                 float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(op), _ptr(sc),
                 float(scale_modifier), _ptr(ro), _ptr(cp), int(bool(prefiltered)), out.data_ptr(),
                 radii[0].data_ptr(), radii[1].data_ptr(), radii[2].data_ptr(), int(bool(debug)), _stream(dev))
-        rendered = _lib.check(rc, "r2_voxel_forward")
-    return rendered, out, radii[0], radii[1], radii[2], st.bufs[0], st.bufs[1], st.bufs[2]
+    finally:
+        bufs = hk.finish(st)
+    rendered = _lib.check(rc, "r2_voxel_forward")
+    return rendered, out, radii[0], radii[1], radii[2], bufs[0], bufs[1], bufs[2]
 
 
 def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rotations, scale_modifier,
@@ -177,7 +238,7 @@ def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rota
     _require_gpu(means3D, "means3D")
     dev = means3D.device
     P = means3D.shape[0]
-    flat = torch.zeros(26 * P, dtype=_F32, device=dev)
+    flat = torch.empty(26 * P, dtype=_F32, device=dev)   # every row is written by the kernels (zeros where culled)
     cuts = [4, 3, 3, 6, 1, 6, 3]
     views, o = [], 0
     for c in cuts:
@@ -195,7 +256,7 @@ def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rota
         sc, ro, cp = (_dev_f32(t, means3D) for t in (scales, rotations, cov3D_precomp))
         g = _dev_f32(dL_dout_color, means3D)
         rx, ry, rz = radii_x.contiguous(), radii_y.contiguous(), radii_z.contiguous()
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().r2_voxel_backward(
                 P, int(R), int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y),
                 float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(sc),
@@ -215,7 +276,7 @@ def distCUDA2(points):
     P = points.shape[0]
     out = torch.zeros((P,), dtype=_F32, device=dev)
     if P != 0:
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             rc = _lib.lib().r2_knn_dist2(P, _ptr(pts), out.data_ptr(), _stream(dev))
         _lib.check(rc, "r2_knn_dist2")
     return out

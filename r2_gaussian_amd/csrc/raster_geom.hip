@@ -250,7 +250,21 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot, int mode)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
+    if (idx >= P) return;
+    if (!(radii[idx] > 0)) {
+        // culled Gaussian: all-zero gradient rows.  The reference gets them from the torch boundary's zero-filled
+        // tensors (SUB/rasterize_points.cu:124-131); writing them here spares the caller a 100 B/Gaussian memset.
+        dL_dmean2D[3 * idx + 0] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+        dL_dopacity[idx] = 0.f;
+        dL_dmus[idx] = 0.f;
+        reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = 0.f;
+        dL_dmeans[3 * idx + 0] = 0.f; dL_dmeans[3 * idx + 1] = 0.f; dL_dmeans[3 * idx + 2] = 0.f;
+        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
 
     // ---- 1. moments of w = G * dL/dpix over all tiles of this Gaussian
     const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
@@ -288,6 +302,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float dL_dmu = op * S0;
     dL_dmean2D[3 * idx + 0] = g2x;
     dL_dmean2D[3 * idx + 1] = g2y;
+    dL_dmean2D[3 * idx + 2] = 0.f;   // RAS/backward.cu never touches the third component
     dL_dopacity[idx] = mu_f * S0;
     dL_dmus[idx] = dL_dmu;
     reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(gx_, gy_, 0.f, gz_);
@@ -392,6 +407,9 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         dL_dscale[3 * idx + 1] = ds[1];
         dL_dscale[3 * idx + 2] = ds[2];
         reinterpret_cast<float4 *>(dL_drot)[idx] = dq;
+    } else {   // cov3D_precomp path: no scale / rotation gradient
+        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 

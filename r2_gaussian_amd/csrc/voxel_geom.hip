@@ -175,7 +175,18 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || !(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) return;
+    if (idx >= P) return;
+    if (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) {
+        // culled Gaussian: all-zero gradient rows (the reference relies on zero-filled tensors, SUB/voxelize_points.cu:130-136)
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { dL_dmean3D_norm[3 * idx + k] = 0.f; dL_dmeans[3 * idx + k] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { dL_dconic3D[6 * idx + k] = 0.f; dL_dcov[6 * idx + k] = 0.f; }
+        dL_dopacity[idx] = 0.f;
+        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
     const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
 
     // ---- 1. moments: S0, (Sx,Sy,Sz), (Sxx,Sxy,Sxz,Syy,Syz,Szz)
@@ -252,6 +263,9 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
         dL_dscale[3 * idx + 1] = ds[1];
         dL_dscale[3 * idx + 2] = ds[2];
         reinterpret_cast<float4 *>(dL_drot)[idx] = dq;
+    } else {
+        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
+        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
