@@ -27,6 +27,7 @@ FAST = ["-ffp-contract=fast", "-fno-slp-vectorize"]
 SOURCES = {
     "binning.hip": FAST,
     "radix_sort.hip": FAST,
+    "depth_order.hip": FAST,
     "raster_geom.hip": EXACT,
     "raster_render.hip": FAST,
     "raster_api.hip": FAST,

@@ -1,0 +1,183 @@
+// depth_order.hip -- Gaussian ids in (depth key, id) order: the first half of the two-stage exact sort (see binning.hip).
+//
+// A general 32-bit LSD radix sort needs 2-3 digit passes of 3 kernels each and, with wide digits, pays for fully
+// scattered 4-byte stores (radix_sort.hip); for P ~ 1e5..1e6 keys that is ~90 us of launch latency.  The depth keys are
+// float bit patterns spread over a narrow range, which a ONE-LEVEL bucket sort exploits:
+//   1. min / max of the visible keys;
+//   2. bucket = (key - min) >> shift with ~P buckets (monotone in the key), counted with one global atomic per key;
+//   3. prefix sum of the bucket counts;
+//   4. each key takes a slot of its bucket (atomic ticket: order inside the bucket is arbitrary at this point);
+//   5. every slot ranks its key among the bucket's (key, id) pairs -- buckets hold ~1 key on average -- and writes the id
+//      to its final position.  Culled Gaussians (key 0xFFFFFFFF) go to the tail.
+// The result is exactly the stable sort by key.  If some bucket is too full for step 5 (many identical depths) a flag
+// is raised and the caller re-sorts with the radix sort; the flag is read at the host synchronisation the forward
+// pass has anyway.
+#include "r2_common.hpp"
+#include <algorithm>
+
+namespace r2 {
+
+namespace {
+
+constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
+constexpr uint32_t MAX_BUCKET = 48;   // a fuller bucket raises the fallback flag
+
+struct Ctrl {          // zeroed before every use
+    uint32_t kmax;     // max of visible keys
+    uint32_t nkmax;    // max of ~key  (=> min key = ~nkmax)
+    uint32_t nculled;  // ticket counter of culled Gaussians
+    uint32_t overflow; // some bucket holds more than MAX_BUCKET keys
+};
+
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax, int log_nb)
+{
+    const uint32_t range = kmax - kmin;
+    const int nbits = 32 - __clz(range | 1u);
+    const int shift = nbits > log_nb ? nbits - log_nb : 0;
+    return (key - kmin) >> shift;
+}
+
+// few, fat workgroups and ONE atomic pair per workgroup: same-address atomics retire at only ~90 per microsecond
+__global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c)
+{
+    __shared__ uint32_t smx[16], snmx[16];
+    uint32_t mx = 0, nmx = 0;
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
+        const uint32_t k = keys[i];
+        if (k != CULLED_KEY) { mx = max(mx, k); nmx = max(nmx, ~k); }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        mx = max(mx, (uint32_t)__shfl_xor(mx, d));
+        nmx = max(nmx, (uint32_t)__shfl_xor(nmx, d));
+    }
+    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; snmx[threadIdx.x >> 6] = nmx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { mx = max(mx, smx[w]); nmx = max(nmx, snmx[w]); }
+        if (mx) atomicMax(&c->kmax, mx);
+        if (nmx) atomicMax(&c->nkmax, nmx);
+    }
+}
+
+__global__ void __launch_bounds__(256) bucket_count_kernel(const uint32_t *__restrict__ keys, uint32_t n, const Ctrl *__restrict__ c,
+                                                           int log_nb, uint32_t *__restrict__ counts)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (k == CULLED_KEY) return;
+    atomicAdd(&counts[bucket_of(k, ~c->nkmax, c->kmax, log_nb)], 1u);
+}
+
+__global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c,
+                                                           int log_nb, uint32_t *__restrict__ counts,
+                                                           const uint32_t *__restrict__ incl, uint32_t *__restrict__ slot_key,
+                                                           uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    if (k == CULLED_KEY) {
+        order[n - 1u - atomicAdd(&c->nculled, 1u)] = i;   // tail, any order: culled Gaussians emit nothing
+        return;
+    }
+    const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
+    const uint32_t v = atomicSub(&counts[b], 1u);          // v in [1, count]: a unique slot inside the bucket
+    const uint32_t pos = incl[b] - v;
+    slot_key[pos] = k;
+    slot_id[pos] = i;
+}
+
+__global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__restrict__ c, int log_nb,
+                                                          const uint32_t *__restrict__ incl, const uint32_t *__restrict__ slot_key,
+                                                          const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t nvis = incl[nb - 1];
+    if (p >= nvis) return;
+    const uint32_t k = slot_key[p], id = slot_id[p];
+    const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
+    const uint32_t beg = b ? incl[b - 1] : 0u, end = incl[b];
+    const uint32_t m = end - beg;
+    if (m == 1) { order[p] = id; return; }
+    if (m > MAX_BUCKET) {   // invalid result, flagged; still leave a valid permutation behind (the scan gathers through it)
+        c->overflow = 1u;
+        order[p] = id;
+        return;
+    }
+    uint32_t rank = 0;
+    for (uint32_t q = beg; q < end; ++q) {
+        const uint32_t kq = slot_key[q], iq = slot_id[q];
+        rank += (kq < k || (kq == k && iq < id)) ? 1u : 0u;
+    }
+    order[beg + rank] = id;
+}
+
+struct Temp {
+    Ctrl *ctrl;
+    uint32_t *counts;     // [nb]   (ctrl and counts are zeroed by one memset)
+    uint32_t *incl;       // [nb]
+    uint32_t *slot_key;   // [P]
+    uint32_t *slot_id;    // [P]
+    char *scan_temp;
+    size_t scan_bytes, zero_bytes, bytes;
+    static Temp carve(char *chunk, size_t P, size_t nb)
+    {
+        Temp t;
+        Bump b(chunk);
+        t.ctrl = b.take<Ctrl>(8);               // 128 bytes: keeps counts on the next 128-byte boundary
+        t.counts = b.take<uint32_t>(nb);
+        t.zero_bytes = b.off;
+        t.incl = b.take<uint32_t>(nb);
+        t.slot_key = b.take<uint32_t>(P);
+        t.slot_id = b.take<uint32_t>(P);
+        t.scan_bytes = scan_temp_bytes((int)nb);
+        t.scan_temp = b.take<char>(t.scan_bytes);
+        t.bytes = b.total();
+        return t;
+    }
+};
+
+inline int log_buckets(size_t P)
+{
+    int l = 10;
+    while (l < 22 && ((size_t)1 << l) < P) ++l;   // ~1 bucket per key, 2^10 .. 2^22 buckets
+    return l;
+}
+
+}  // namespace
+
+size_t depth_order_temp_bytes(size_t P) { return Temp::carve(nullptr, P, (size_t)1 << log_buckets(P)).bytes; }
+
+// order[P] = Gaussian ids sorted by (key, id); culled ids (key 0xFFFFFFFF) at the tail in arbitrary order.
+// *overflow_flag receives a device pointer to a word that is non-zero when the result is INVALID (fall back to the
+// radix sort); it must be read after the stream has caught up.
+int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
+                        const uint32_t **overflow_flag, hipStream_t s)
+{
+    if (overflow_flag) *overflow_flag = nullptr;
+    if (P == 0) return 0;
+    const int log_nb = log_buckets(P);
+    const size_t nb = (size_t)1 << log_nb;
+    const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, nb);
+    if (t.bytes > temp_bytes) {
+        set_error("depth_order_buckets: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
+        return R2_ERR_INVALID;
+    }
+    const unsigned grid = (unsigned)((P + 255) / 256);
+    R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
+    minmax_kernel<<<dim3(std::min((unsigned)((P + 4095) / 4096), 64u)), dim3(1024), 0, s>>>(keys, (uint32_t)P, t.ctrl);
+    bucket_count_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts);
+    const int rc = inclusive_scan_u32(t.scan_temp, t.scan_bytes, t.counts, t.incl, (int)nb, s);
+    if (rc) return rc;
+    bucket_place_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts, t.incl, t.slot_key,
+                                                         t.slot_id, order);
+    bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, log_nb, t.incl, t.slot_key, t.slot_id, order);
+    if (overflow_flag) *overflow_flag = &t.ctrl->overflow;
+    R2_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+}  // namespace r2

@@ -87,6 +87,11 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
 int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                        uint32_t *vout, size_t n, int end_bit, hipStream_t s);
 // inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
+// depth_order.hip: ids in (key, id) order by a one-level bucket sort; *overflow_flag -> device word, non-zero = invalid
+// result (a bucket was too full), the caller must fall back to sort_pairs_ex
+size_t depth_order_temp_bytes(size_t P);
+int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
+                        const uint32_t **overflow_flag, hipStream_t s);
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
 // *counts_out = per-tile instance counts (device pointer into temp)

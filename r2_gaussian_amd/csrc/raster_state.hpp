@@ -53,7 +53,8 @@ struct RasterGeom {
         g.offsets = b.take<uint32_t>(P);
         g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
-        g.psort_bytes = sort_temp_bytes((size_t)P);
+        g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)
+                                                                                     : depth_order_temp_bytes((size_t)P);
         g.psort_temp = b.take<char>(g.psort_bytes);
         g.bytes = b.total();
         return g;
