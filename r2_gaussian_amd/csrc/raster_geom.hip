@@ -267,8 +267,20 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     }
 
     // ---- 1. moments of w = G * dL/dpix over all tiles of this Gaussian
+    // every per-Gaussian input is requested up front so that its latency overlaps the (dependent) inv -> row gathers
     const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
     const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
+    const float2 om = op_mu[idx];
+    float cov3D[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
+    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float sc_in[3] = { 0.f, 0.f, 0.f };
+    float4 rot_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scales != nullptr) {
+        sc_in[0] = scales[3 * idx]; sc_in[1] = scales[3 * idx + 1]; sc_in[2] = scales[3 * idx + 2];
+        rot_in = reinterpret_cast<const float4 *>(rotations)[idx];
+    }
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
     // rows are gathered through the inverse permutation of the tile sort; 4 at a time so that the two dependent
     // round trips (inv -> row) of different instances overlap.  The summation order stays j = 0, 1, 2, ...
@@ -293,7 +305,6 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         }
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
-    const float2 om = op_mu[idx];
     const float op = om.x, mu_f = om.y, opmu = op * mu_f;
     const float cA = ra.z * (-2.0f * LN2), cB = ra.w * (-LN2), cC = rb.x * (-2.0f * LN2);
     const float g2x = opmu * W_half * (-cA * S1 - cB * S2);
@@ -308,11 +319,6 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(gx_, gy_, 0.f, gz_);
 
     // ---- 3. geometry chain
-    float cov3D[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
-    const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-
     Cov2D c;
     cov2d_common(mean, h_x, h_y, tan_fovx, tan_fovy, cov3D, view, mode, c);
     const M3 &M = c.M;
@@ -401,8 +407,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     if (scales != nullptr) {
         float ds[3];
         float4 dq;
-        cov3d_backward(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier,
-                       reinterpret_cast<const float4 *>(rotations)[idx], o, ds, &dq);
+        cov3d_backward(sc_in[0], sc_in[1], sc_in[2], scale_modifier, rot_in, o, ds, &dq);
         dL_dscale[3 * idx + 0] = ds[0];
         dL_dscale[3 * idx + 1] = ds[1];
         dL_dscale[3 * idx + 2] = ds[2];

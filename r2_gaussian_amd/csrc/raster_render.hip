@@ -34,10 +34,10 @@ namespace r2 {
 // the 4 blocks of the tile and never synchronise with each other.
 //
 // Production kernel (item-parallel): one LANE owns one list entry and evaluates the 64 pixels of the wave's block
-// into 64 register accumulators; entries are streamed through a per-wave LDS compaction buffer (ballot + prefix
-// popcount keeps only entries whose alpha >= 1e-5 bounding box touches the block, 46 % on the benchmark scene) so that
-// all 64 lanes work on live entries; at the end one 64x64 transpose-reduction (6 butterfly steps) leaves pixel p's sum
-// in lane p.  Lane-per-entry makes the Gaussian separable along a pixel row: alpha(c+1) = alpha(c) * r(c),
+// into 64 register accumulators; the workgroup stages 256 entries at a time in LDS and every wave compacts the ones
+// whose alpha >= 1e-5 bounding box touches its block (ballot + prefix popcount, 46 % survive on the benchmark scene)
+// so that its lanes work on live entries only; at the end one 64x64 transpose-reduction (6 butterfly steps) leaves
+// pixel p's sum in lane p.  Lane-per-entry makes the Gaussian separable along a pixel row: alpha(c+1) = alpha(c) * r(c),
 // r(c+1) = r(c) * exp2(2 A2), i.e. TWO v_exp_f32 per 8-pixel row instead of 8 -- v_exp_f32 issues at ~1/8 the rate
 // of an FMA on gfx950 and was ~40 % of the pixel-parallel kernel's issue time.  Entries that are too thin for the
 // recurrence or whose conic is not safely positive definite take the exact per-pixel path (see needs_exact_row).
@@ -54,8 +54,7 @@ __device__ __forceinline__ bool needs_exact_row(float A2, float L, float hx)
     const float smax = (11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f)) * (1.0f / 7.0f);
     return !(smax > 0.f && fabsf(A2) <= smax * smax) || !(hx < 3.0e38f);
 }
-constexpr int FWD_BATCH = 128;          // list entries examined per compaction round (2 per lane)
-constexpr int FWD_BUF = FWD_BATCH + 64;   // + up to 63 carried over
+constexpr int FWD_BATCH = 256;          // list entries staged per round: one per thread of the workgroup
 
 template <bool EXACT>
 __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64])
@@ -109,65 +108,62 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
-    __shared__ float4 sA[4][FWD_BUF];   // compacted live entries of this wave: {px, py, A2, B2}
-    __shared__ float4 sB[4][FWD_BUF];   //                                       {C2, L, exact-path flag, -}
-    float4 *const mA = sA[wave];
-    float4 *const mB = sB[wave];
+    // The workgroup stages FWD_BATCH list entries at a time in LDS (one entry per thread, the next batch's gathers are
+    // already in flight while this one is evaluated); every wave then picks the entries that touch ITS block.
+    __shared__ float4 sA[FWD_BATCH];          // {px, py, A2, B2}
+    __shared__ float4 sB[FWD_BATCH];          // {C2, L, hx, hy}
+    __shared__ uint16_t sQ[4][FWD_BATCH];     // per wave: indices of its live entries, in list order
 
     float acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
 
-    int cnt = 0;   // live entries waiting in the buffer (wave-uniform)
+    float4 na, nb;   // prefetched entry of the NEXT batch
+    {
+        const uint32_t k = beg + (uint32_t)tid;
+        const uint32_t id = point_list[k < end ? k : beg];
+        na = rec[2 * id];
+        nb = rec[2 * id + 1];
+    }
     for (uint32_t base = beg; base < end; base += FWD_BATCH) {
-        float4 a[FWD_BATCH / 64], b[FWD_BATCH / 64];
-        bool cand[FWD_BATCH / 64];
-#pragma unroll
-        for (int r = 0; r < FWD_BATCH / 64; ++r) {
-            const uint32_t k = base + (uint32_t)(r * 64 + lane);
-            cand[r] = k < end;
-            const uint32_t id = cand[r] ? point_list[k] : point_list[beg];
-            a[r] = rec[2 * id];
-            b[r] = rec[2 * id + 1];
+        __syncthreads();                       // the previous batch has been consumed by all four waves
+        sA[tid] = na;
+        sB[tid] = nb;
+        __syncthreads();
+        if (base + FWD_BATCH < end) {          // start the next batch's gathers
+            const uint32_t k = base + FWD_BATCH + (uint32_t)tid;
+            const uint32_t id = point_list[k < end ? k : beg];
+            na = rec[2 * id];
+            nb = rec[2 * id + 1];
         }
+        const int nbatch = (int)min((uint32_t)FWD_BATCH, end - base);
+        // ---- this wave's live entries (ballot + prefix popcount keeps list order)
+        int cnt = 0;
 #pragma unroll
         for (int r = 0; r < FWD_BATCH / 64; ++r) {
-            const bool keep = cand[r] && block_live(a[r].x, a[r].y, b[r].z, b[r].w, x0, y0, (float)SUB2D);
+            const int e = r * 64 + lane;
+            const float4 a = sA[e], b = sB[e];
+            const bool keep = e < nbatch && block_live(a.x, a.y, b.z, b.w, x0, y0, (float)SUB2D);
             const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int pos = cnt + __popcll(m & lt_mask);
-                const float flag = needs_exact_row(a[r].z, b[r].y, b[r].z) ? 1.f : 0.f;
-                mA[pos] = a[r];
-                mB[pos] = make_float4(b[r].x, b[r].y, flag, 0.f);
-            }
+            if (keep) sQ[wave][cnt + __popcll(m & lt_mask)] = (uint16_t)e;
             cnt += __popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const bool last_batch = base + FWD_BATCH >= end;
-        int head = 0;
-        while (cnt - head >= 64 || (last_batch && cnt - head > 0)) {
-            const bool have = lane < cnt - head;
-            float4 ea = make_float4(0.f, 0.f, 0.f, 0.f), eb = make_float4(0.f, -INFINITY, 0.f, 0.f);   // dead lane: alpha = 0
-            if (have) { ea = mA[head + lane]; eb = mB[head + lane]; }
+        // ---- 64 entries per step, one per lane
+        for (int head = 0; head < cnt; head += 64) {
+            float4 ea = make_float4(0.f, 0.f, 0.f, 0.f), eb = make_float4(0.f, -INFINITY, 0.f, 0.f);   // idle lane: alpha = 0
+            if (head + lane < cnt) {
+                const int e = sQ[wave][head + lane];
+                ea = sA[e];
+                eb = sB[e];
+            }
             // recurrence path for the regular entries (flagged lanes contribute 0: L = -inf), then, only if the wave
             // holds any, the exact path for the flagged ones -- two in-place accumulations, no 64-register merge
-            const bool exact = eb.z != 0.f;
+            const bool exact = (head + lane < cnt) && needs_exact_row(ea.z, eb.y, eb.z);
             fwd_item<false>(exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
             if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
-            head += 64;
         }
-        __builtin_amdgcn_wave_barrier();
-        if (head > 0 && head < cnt) {   // carry the (< 64) unprocessed entries to the front of the buffer
-            float4 ca = make_float4(0.f, 0.f, 0.f, 0.f), cb = ca;
-            const bool mv = lane < cnt - head;
-            if (mv) { ca = mA[head + lane]; cb = mB[head + lane]; }
-            __builtin_amdgcn_wave_barrier();
-            if (mv) { mA[lane] = ca; mB[lane] = cb; }
-        }
-        cnt = max(cnt - head, 0);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
 
     // 64x64 transpose-reduction: after the step with partner distance d, acc[0..d) hold partial sums of the d pixels

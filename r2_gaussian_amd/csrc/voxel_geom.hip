@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -92,9 +92,30 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     radii_y[idx] = (int)rad.y;
     radii_z[idx] = (int)rad.z;
     tiles_touched[idx] = n;
-    rec[3 * idx] = make_float4(pv.x, pv.y, pv.z, opacities[idx]);
+    const float op = opacities[idx];
+    const float L = op > 0.0f ? log2f(op) : -INFINITY;
+    // bounding box of {alpha >= 1e-6} (VOX/forward.cu:293): q = d^T C d <= 2 ln2 (L - log2(1e-6)), half-widths
+    // sqrt(qmax * (C^-1)_kk), from the float inverse covariance the kernels evaluate, in double, padded; +inf (never
+    // cull) unless C is safely positive definite, -inf (never live) when the opacity is below the cut-off.
+    float hx = INFINITY, hy = INFINITY, hz = INFINITY;
+    {
+        const double qmax = 2.0 * (double)LN2 * ((double)L - (double)LOG2_ALPHA_MIN_3D) + 1e-3;
+        const double A = inv_a, B = inv_b, C = inv_c, D = inv_d, E = inv_e, F = inv_f;
+        const double m00 = D * F - E * E, m11 = A * F - C * C, m22 = A * D - B * B;
+        const double det3 = A * m00 - B * (B * F - C * E) + C * (B * E - C * D);
+        if (!(qmax > 0.0)) {
+            hx = hy = hz = -INFINITY;
+        } else if (A > 0.0 && m22 > 0.0 && det3 > 0.0 && m00 > 0.0 && m11 > 0.0 &&
+                   (A + D + F) * (m00 + m11 + m22) <= 1.0e4 * det3) {
+            const double ex = sqrt(qmax * m00 / det3) * 1.004 + 0.05, ey = sqrt(qmax * m11 / det3) * 1.004 + 0.05,
+                         ez = sqrt(qmax * m22 / det3) * 1.004 + 0.05;
+            if (ex < 1.0e30 && ey < 1.0e30 && ez < 1.0e30) { hx = (float)ex; hy = (float)ey; hz = (float)ez; }
+        }
+    }
+    rec[3 * idx] = make_float4(pv.x, pv.y, pv.z, op);
     rec[3 * idx + 1] = make_float4((-0.5f * LOG2E) * inv_a, (-LOG2E) * inv_b, (-LOG2E) * inv_c, (-0.5f * LOG2E) * inv_d);
-    rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, 0.f, 0.f);
+    rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, L, 0.f);
+    ext[idx] = make_float4(hx, hy, hz, 0.f);
 }
 
 // Instance emission (duplicateWithKeys, VOX/voxelizer_impl.cu:54-101) in DEPTH order: sorted position j ->
@@ -276,7 +297,7 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
                                                                         radii_z, g.rec, g.depth_key, g.iota, g.cov3D,
-                                                                        g.tiles_touched);
+                                                                        g.tiles_touched, g.ext);
     return 0;
 }
 

@@ -19,10 +19,153 @@
 
 namespace r2 {
 
-constexpr float ALPHA_MIN_3D = 0.000001f;   // VOX/forward.cu:293
+// ------------------------------------------------------------------------------------------------ forward
+// Production kernel, item-parallel like the rasterizer's (raster_render.hip): a workgroup = one work item (<= VOX_CHUNK
+// instances of one tile list), its 8 waves own the 8 x-slabs (1 x 8 x 8 voxels) of the tile and never synchronise.
+// One LANE owns one list entry and accumulates the slab's 64 voxels in registers; the workgroup stages 512 entries at a
+// time in LDS and every wave compacts those whose alpha >= 1e-6 bounding box touches its slab; along a z row the
+// Gaussian is walked with the recurrence G(c+1) = G(c) r(c), r(c+1) = r(c) exp2(2 F2), re-anchored every 4 voxels (two
+// v_exp_f32 per 4 voxels instead of four); a 64x64 transpose-reduction leaves voxel (y, z) of the slab in lane y*8+z.
+constexpr int VFWD_BATCH = 256;   // list entries staged per round: one per thread of the workgroup
 
-template <bool NCONTRIB>
-__global__ void __launch_bounds__(512) voxel_render_forward_kernel(
+__device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h, float xc, float y0, float z0)
+{
+    // slab = voxel centres x = xc, y in [y0+0.5, y0+7.5], z in [z0+0.5, z0+7.5]
+    return (fabsf(px - xc) <= h.x) && (py - h.y <= y0 + 7.5f) && (py + h.y >= y0 + 0.5f) && (pz - h.z <= z0 + 7.5f) &&
+           (pz + h.z >= z0 + 0.5f);
+}
+
+template <bool EXACT>
+__device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const float4 r, float xc, float y0, float z0,
+                                          float (&acc)[64])
+{
+    // log2(alpha) = a2 dx^2 + b2 dx dy + c2 dx dz + d2 dy^2 + e2 dy dz + f2 dz^2 + L
+    const float dx = p.x - xc;
+    const float adx2L = q.x * dx * dx + r.z;
+    const float bdx = q.y * dx, cdx = q.z * dx;
+    const float dz0 = p.z - (z0 + 0.5f);
+    const float kf1 = r.y * (1.0f - 2.0f * dz0);
+    const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * r.y);
+#pragma unroll
+    for (int iy = 0; iy < TILE3D; ++iy) {
+        const float dy = p.y - (y0 + (float)iy + 0.5f);
+        const float k0 = dy * (q.w * dy + bdx) + adx2L;
+        const float k1 = r.x * dy + cdx;
+        if (EXACT) {
+#pragma unroll
+            for (int iz = 0; iz < TILE3D; ++iz) {
+                const float dz = dz0 - (float)iz;
+                const float pl = dz * (r.y * dz + k1) + k0;
+                const float al = __builtin_amdgcn_exp2f(pl);
+                // power <= 0 (VOX/forward.cu:288) <=> pl <= L ; alpha >= 1e-6 (VOX/forward.cu:293)
+                const bool ok = (pl <= r.z) && (al >= ALPHA_MIN_3D);
+                acc[iy * TILE3D + iz] += ok ? al : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int seg = 0; seg < TILE3D; seg += VOX_RECUR_STEPS) {   // re-anchor every VOX_RECUR_STEPS voxels
+                const float dzs = dz0 - (float)seg;
+                float g = __builtin_amdgcn_exp2f(dzs * (r.y * dzs + k1) + k0);
+                float rt = __builtin_amdgcn_exp2f(fminf(kf1 + (2.0f * (float)seg) * r.y - k1, 120.0f));
+#pragma unroll
+                for (int c = 0; c < VOX_RECUR_STEPS; ++c) {
+                    acc[iy * TILE3D + seg + c] += (g >= ALPHA_MIN_3D) ? g : 0.f;   // power <= 0 holds: positive definite
+                    g *= rt;
+                    rt *= rr;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+__global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
+    VoxelGrid v, float *__restrict__ partial)
+{
+    // two workgroups of 4 waves per work item (x-slabs 0-3 and 4-7): tile lists are short (~150 entries at 256^3), so
+    // a workgroup is one dependent chain of gathers followed by 2-3 evaluation steps -- small workgroups let 4+ of them
+    // overlap on a CU
+    const uint32_t w = blockIdx.x >> 1;
+    const int half = (int)(blockIdx.x & 1u);
+    if (w >= chunk_base[T]) return;
+    const uint32_t tile = work_tile[w];
+    const uint32_t j0 = (w - chunk_base[tile]) * VOX_CHUNK;
+    const uint2 range = ranges[tile];
+    const uint32_t beg = range.x + j0, end = min(range.y, beg + VOX_CHUNK);
+    const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slab = half * 4 + wave;
+    const float xc = (float)(tx * TILE3D + slab) + 0.5f, y0 = (float)(ty * TILE3D), z0 = (float)(tz * TILE3D);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+
+    // the workgroup stages VFWD_BATCH entries at a time (one per thread); every wave then picks the entries whose
+    // bounding box touches ITS x-slab
+    __shared__ float4 s0[VFWD_BATCH], s1[VFWD_BATCH], s2[VFWD_BATCH], s3[VFWD_BATCH];   // p, q, r, extents
+    __shared__ uint16_t sQ[4][VFWD_BATCH];
+
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+
+    for (uint32_t base = beg; base < end; base += VFWD_BATCH) {
+        {
+            const uint32_t k = base + (uint32_t)tid;
+            const uint32_t id = point_list[k < end ? k : beg];
+            const float4 np = rec[3 * id], nq = rec[3 * id + 1], nr = rec[3 * id + 2], nh = ext[id];
+            __syncthreads();   // the previous batch has been consumed
+            s0[tid] = np; s1[tid] = nq; s2[tid] = nr; s3[tid] = nh;
+        }
+        __syncthreads();
+        const int nbatch = (int)min((uint32_t)VFWD_BATCH, end - base);
+        int cnt = 0;
+#pragma unroll
+        for (int r = 0; r < VFWD_BATCH / 64; ++r) {
+            const int e = r * 64 + lane;
+            const float4 p = s0[e], h = s3[e];
+            const bool keep = e < nbatch && slab_live(p.x, p.y, p.z, h, xc, y0, z0);
+            const unsigned long long m = __ballot(keep);
+            if (keep) sQ[wave][cnt + __popcll(m & lt_mask)] = (uint16_t)e;
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int head = 0; head < cnt; head += 64) {
+            float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = make_float4(0.f, 0.f, -INFINITY, 0.f);   // idle lane
+            bool exact = false;
+            if (head + lane < cnt) {
+                const int e = sQ[wave][head + lane];
+                ep = s0[e]; eq = s1[e]; er = s2[e];
+                exact = needs_exact_row3(er.y, er.z, s3[e].z);
+            }
+            const float Lr = er.z;
+            er.z = exact ? -INFINITY : Lr;
+            vfwd_item<false>(ep, eq, er, xc, y0, z0, acc);
+            if (__any(exact)) {
+                er.z = exact ? Lr : -INFINITY;
+                vfwd_item<true>(ep, eq, er, xc, y0, z0, acc);
+            }
+        }
+    }
+
+    // 64x64 transpose-reduction (see raster_render.hip): acc[0] ends up as the slab's voxel number `lane` = y*8 + z
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const bool up = (lane & d) != 0;
+#pragma unroll
+        for (int i = 0; i < d; ++i) {
+            const float keep = up ? acc[d + i] : acc[i];
+            const float send = up ? acc[i] : acc[d + i];
+            acc[i] = keep + __shfl_xor(send, d);
+            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    partial[(size_t)w * 512 + slab * 64 + lane] = acc[0];   // x*64 + y*8 + z: the layout voxel_combine_kernel expects
+}
+
+// Debug-mode kernel (voxel-parallel): also tracks n_contrib, which only `debug` callers read back.
+__global__ void __launch_bounds__(512) voxel_render_forward_debug_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, VoxelGrid v,
     float *__restrict__ partial, uint32_t *__restrict__ partial_last)
@@ -66,11 +209,11 @@ __global__ void __launch_bounds__(512) voxel_render_forward_kernel(
             const float alpha = p.w * __builtin_amdgcn_exp2f(p2);
             const bool ok = (p2 <= 0.0f) && (alpha >= ALPHA_MIN_3D);
             C += ok ? alpha : 0.f;
-            if (NCONTRIB) last = ok ? (base - range.x) + (uint32_t)j + 1u : last;
+            last = ok ? (base - range.x) + (uint32_t)j + 1u : last;
         }
     }
     partial[(size_t)w * 512 + tid] = C;
-    if (NCONTRIB) partial_last[(size_t)w * 512 + tid] = last;
+    partial_last[(size_t)w * 512 + tid] = last;
 }
 
 // adds a tile's partial sums in list order and writes the volume (zeros for empty tiles)
@@ -252,11 +395,11 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
     const uint32_t T = (uint32_t)v.gx * v.gy * v.gz;
     if (im.NW > 0) {
         if (write_ncontrib)
-            voxel_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
+            voxel_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, v, im.partial, im.partial_last);
         else
-            voxel_render_forward_kernel<false><<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, v, im.partial, im.partial_last);
+            voxel_render_forward_kernel<<<dim3((unsigned)(2 * im.NW)), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial);
     }
     if (write_ncontrib)
         voxel_combine_kernel<true><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v,

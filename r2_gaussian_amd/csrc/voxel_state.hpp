@@ -7,10 +7,25 @@ namespace r2 {
 
 constexpr uint32_t VOX_CHUNK = 1024;  // instances of one tile list evaluated by one workgroup (load balance)
 constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
+constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
+constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)
+
+// Row recurrence along z (see raster_render.hip: needs_exact_row), re-anchored every VOX_RECUR_STEPS voxels: safe unless
+// the Gaussian is so thin along z that (VOX_RECUR_STEPS - 1) steps could climb from an underflowed start (p0 < -126)
+// back above the alpha cut-off, or it has no finite culling box.  Voxel-space Gaussians are small (sigma ~ 1-3
+// voxels), hence the short segments: with 3 steps the bound is |F2| <= ~5 (sigma_z >= 0.37 voxel).
+constexpr int VOX_RECUR_STEPS = 4;
+__device__ __forceinline__ bool needs_exact_row3(float F2, float L, float hx)
+{
+    const float smax = (11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_3D, 0.f) + 1.0f)) * (1.0f / (float)(VOX_RECUR_STEPS - 1));
+    return !(smax > 0.f && fabsf(F2) <= smax * smax) || !(hx < 3.0e38f);
+}
 
 struct VoxelGeom {
-    float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,-,-}: inverse covariance
-                              //      (xx,xy,xz,yy,yz,zz) pre-scaled by -log2e/2 (diagonal) or -log2e (off-diagonal)
+    float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,L,-}: inverse covariance
+                              //      (xx,xy,xz,yy,yz,zz) pre-scaled by -log2e/2 (diagonal) or -log2e (off-diagonal),
+                              //      L = log2(opacity)
+    float4 *ext;              // [P]  {hx,hy,hz,-}: half-extents (voxels) of the bounding box of alpha >= 1e-6
     uint32_t *depth_key;      // [P]  bits of world z, the arbitrary low sort word of the reference (Q10); 
     uint32_t *iota;           // [P]
     uint32_t *depth_sorted;   // [P]
@@ -29,6 +44,7 @@ struct VoxelGeom {
         VoxelGeom g;
         Bump b(chunk);
         g.rec = b.take<float4>(3 * (size_t)P);
+        g.ext = b.take<float4>(P);
         g.depth_key = b.take<uint32_t>(P);
         g.iota = b.take<uint32_t>(P);
         g.depth_sorted = b.take<uint32_t>(P);

@@ -5,8 +5,8 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r01}
 mkdir -p gpurun_out/pmc
-CMD="python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-voxel"
-for C in FETCH_SIZE WRITE_SIZE; do
+CMD=${CMD:-"python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-voxel"}
+for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc/${TAG}_$C -o $C -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_$C.err
   tail -1 gpurun_out/pmc/${TAG}_$C.err
 done
