@@ -27,6 +27,7 @@ namespace r2 {
 // Gaussian is walked with the recurrence G(c+1) = G(c) r(c), r(c+1) = r(c) exp2(2 F2), re-anchored every 4 voxels (two
 // v_exp_f32 per 4 voxels instead of four); a 64x64 transpose-reduction leaves voxel (y, z) of the slab in lane y*8+z.
 constexpr int VFWD_BATCH = 256;   // list entries staged per round: one per thread of the workgroup
+constexpr int VFWD_MIN_STEP = 25;  // fewer live entries than this are cheaper voxel-parallel (20 vs ~500/64 instr per entry)
 
 __device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h, float xc, float y0, float z0)
 {
@@ -87,9 +88,15 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
     // two workgroups of 4 waves per work item (x-slabs 0-3 and 4-7): tile lists are short (~150 entries at 256^3), so
     // a workgroup is one dependent chain of gathers followed by 2-3 evaluation steps -- small workgroups let 4+ of them
     // overlap on a CU
-    const uint32_t w = blockIdx.x >> 1;
-    const int half = (int)(blockIdx.x & 1u);
-    if (w >= chunk_base[T]) return;
+    // XCD-aware order: workgroup b runs on XCD b % 8.  Runs of 128 consecutive half-items (64 tiles in list order:
+    // neighbours that share most of their Gaussians) go to one XCD, so their record gathers hit that XCD's L2; the
+    // runs are dealt round-robin over the 8 XCDs, which keeps the dense middle of the volume spread over all of them.
+    const uint32_t nhalf = 2u * chunk_base[T];
+    const uint32_t seq = blockIdx.x >> 3;
+    const uint32_t hb = ((seq >> 7) * 8u + (blockIdx.x & 7u)) * 128u + (seq & 127u);
+    if (hb >= nhalf) return;
+    const uint32_t w = hb >> 1;
+    const int half = (int)(hb & 1u);
     const uint32_t tile = work_tile[w];
     const uint32_t j0 = (w - chunk_base[tile]) * VOX_CHUNK;
     const uint2 range = ranges[tile];
@@ -108,6 +115,8 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
     float acc[64];
 #pragma unroll
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    float tail = 0.f;   // voxel-parallel contributions: already in the final (lane = voxel) layout
+    bool stepped = false;   // wave-uniform: did any lane-per-entry step run (else acc is still all zero)
 
     for (uint32_t base = beg; base < end; base += VFWD_BATCH) {
         {
@@ -131,7 +140,8 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        for (int head = 0; head < cnt; head += 64) {
+        int head = 0;
+        for (; cnt - head >= VFWD_MIN_STEP; head += 64) {
             float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = make_float4(0.f, 0.f, -INFINITY, 0.f);   // idle lane
             bool exact = false;
             if (head + lane < cnt) {
@@ -146,22 +156,37 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
                 er.z = exact ? Lr : -INFINITY;
                 vfwd_item<true>(ep, eq, er, xc, y0, z0, acc);
             }
+            stepped = true;
+        }
+        // a tail too short to fill a lane-per-entry step is evaluated voxel-parallel instead (lane = voxel y*8+z of the
+        // slab, entries broadcast from LDS, exact exp): ~20 instructions per entry instead of a ~500-instruction step
+        for (int j = head; j < cnt; ++j) {
+            const int e = sQ[wave][j];
+            const float4 p = s0[e], q = s1[e], r = s2[e];
+            const float dx = p.x - xc, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);
+            const float pl = dx * (q.x * dx + q.y * dy + q.z * dz) + dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
+            const float al = __builtin_amdgcn_exp2f(pl);
+            const bool ok = (pl <= r.z) && (al >= ALPHA_MIN_3D);
+            tail += ok ? al : 0.f;
         }
     }
 
-    // 64x64 transpose-reduction (see raster_render.hip): acc[0] ends up as the slab's voxel number `lane` = y*8 + z
+    // 64x64 transpose-reduction (see raster_render.hip): acc[0] ends up as the slab's voxel number `lane` = y*8 + z.
+    // Skipped when the (short) list was handled entirely by the voxel-parallel tail -- most tiles at 256^3.
+    if (stepped) {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const bool up = (lane & d) != 0;
+        for (int d = 32; d >= 1; d >>= 1) {
+            const bool up = (lane & d) != 0;
 #pragma unroll
-        for (int i = 0; i < d; ++i) {
-            const float keep = up ? acc[d + i] : acc[i];
-            const float send = up ? acc[i] : acc[d + i];
-            acc[i] = keep + __shfl_xor(send, d);
-            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < d; ++i) {
+                const float keep = up ? acc[d + i] : acc[i];
+                const float send = up ? acc[i] : acc[d + i];
+                acc[i] = keep + __shfl_xor(send, d);
+                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
-    partial[(size_t)w * 512 + slab * 64 + lane] = acc[0];   // x*64 + y*8 + z: the layout voxel_combine_kernel expects
+    partial[(size_t)w * 512 + slab * 64 + lane] = acc[0] + tail;   // x*64 + y*8 + z: the layout voxel_combine_kernel expects
 }
 
 // Debug-mode kernel (voxel-parallel): also tracks n_contrib, which only `debug` callers read back.
@@ -398,7 +423,8 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
             voxel_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, v, im.partial, im.partial_last);
         else
-            voxel_render_forward_kernel<<<dim3((unsigned)(2 * im.NW)), dim3(256), 0, s>>>(
+            // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
+            voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial);
     }
     if (write_ncontrib)
