@@ -38,6 +38,7 @@ def algorithmic_bytes(stage, P, R, T, N):
     written, the sort as ONE read + write of (key, value)."""
     table = {
         "raster.preprocess": 108 * P,            # 44 in + 64 out
+        "raster.depth_sort": 16 * P,             # depth order of the Gaussians: (key, id) read + id written
         "raster.scan": 8 * P,
         "raster.duplicate": 20 * P + 12 * R,
         "raster.sort": 24 * R,
@@ -177,8 +178,16 @@ def main():
                 _C.voxelize_gaussians(*va)
             torch.cuda.synchronize()
             tv = (time.perf_counter() - t1) / nv
+            _lib.profile_enable(None)       # per-stage breakdown of the same call (not part of the timing above)
+            for _ in range(5):
+                _C.voxelize_gaussians(*va)
+            torch.cuda.synchronize()
+            vprof = _lib.profile_read(reset=True)
+            _lib.profile_enable([])
+        vbytes = 168 * P + 88 * R3 + 16 * 32768 + 8 * 256 ** 3
         gvox = {"gvoxel_per_s": round(256 ** 3 / tv / 1e9, 3), "ms": round(tv * 1e3, 3), "R3": int(R3),
-                "alg_MB": round((168 * P + 88 * R3 + 16 * 32768 + 8 * 256 ** 3) / 1e6, 1)}
+                "alg_MB": round(vbytes / 1e6, 1), "hbm_frac": round(vbytes / tv / 1e9 / HBM_PEAK_GBS, 4),
+                "stages_us": {k: round(1e3 * ms / cnt, 1) for k, (ms, cnt) in sorted(vprof.items()) if k.startswith("voxel.")}}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, one view
     cpu = None
@@ -196,6 +205,19 @@ def main():
                "sample": "1 view fwd+bwd of the same workload (%dk Gaussians, %d^2, R=%d) by oracle/r2_oracle.c, OpenMP"
                          % (P // 1000, HW, st["num_rendered"])}
 
+    # HBM traffic of the dominant kernel from the TCC counters (FETCH_SIZE / WRITE_SIZE, one counter per rocprofv3 pass:
+    # scripts/gpu_pmc.sh; the summary it writes is committed under profiles/).  bench.py cannot collect PMCs itself.
+    traffic = None
+    pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if os.path.exists(pmc_path):
+        try:
+            pmc = json.load(open(pmc_path))
+            k = pmc.get("r2::raster_render_backward_kernel", {})
+            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
+                traffic = int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)   # counters are in KB, per launch
+        except Exception:
+            traffic = None
+
     if rank == 0:
         total_views = args.steps * world
         out = {
@@ -208,7 +230,7 @@ def main():
                        "num_rendered": R, "parallelism": "view-sharded dp%d + RCCL all-reduce of [P,11] grads" % world
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "us_per_launch": round(dom_us, 2), "alg_bytes_per_launch": dom_bytes,
                          "pipeline_frac": round(total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_alg_bytes": total_bytes},

@@ -226,7 +226,7 @@ int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_
 // work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
 __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
                                                           uint32_t *__restrict__ chunk_base,
-                                                          uint32_t *__restrict__ work_tile)
+                                                          uint4 *__restrict__ work_tile)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
@@ -254,7 +254,9 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
         const uint32_t excl = carry + woff + incl - n;
         if (t < T) {
             chunk_base[t] = excl;
-            for (uint32_t j = 0; j < n; ++j) work_tile[excl + j] = t;
+            const uint2 r = ranges[t];
+            for (uint32_t j = 0; j < n; ++j)   // work descriptor: {tile, first instance, one past the last, items of the tile}
+                work_tile[excl + j] = make_uint4(t, r.x + j * chunk, min(r.y, r.x + (j + 1) * chunk), n);
         }
         __syncthreads();
         if (tid == 1023) carry = excl + n;
@@ -263,10 +265,45 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
     if (tid == 0) chunk_base[T] = carry;
 }
 
-void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint32_t *work_tile,
-                       hipStream_t s)
+// many tiles (256^3 volume: 32768): the same in three parallel steps -- per-tile work item counts, their prefix sum
+// (own scan above), then every tile writes its base and its work items
+__global__ void __launch_bounds__(256) work_count_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
+                                                         uint32_t *__restrict__ nw)
 {
-    build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile);
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= T) return;
+    const uint2 r = ranges[t];
+    nw[t] = (r.y - r.x + chunk - 1) / chunk;
+}
+__global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict__ ranges, uint32_t chunk,
+                                                        const uint32_t *__restrict__ nw, const uint32_t *__restrict__ incl,
+                                                        uint32_t T, uint32_t *__restrict__ chunk_base,
+                                                        uint4 *__restrict__ work_tile)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= T) return;
+    const uint32_t n = nw[t], start = incl[t] - n;
+    chunk_base[t] = start;
+    const uint2 r = ranges[t];
+    for (uint32_t j = 0; j < n; ++j)
+        work_tile[start + j] = make_uint4(t, r.x + j * chunk, min(r.y, r.x + (j + 1) * chunk), n);
+    if (t == T - 1) chunk_base[T] = incl[t];
+}
+
+size_t build_work_temp_bytes(size_t T) { return T > 4096 ? sizeof(uint32_t) * 2 * T + scan_temp_bytes((int)T) + 256 : 0; }
+
+void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
+                       void *temp, hipStream_t s)
+{
+    if (T <= 4096 || temp == nullptr) {
+        build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile);
+        return;
+    }
+    uint32_t *nw = reinterpret_cast<uint32_t *>(temp), *incl = nw + T;
+    void *scan_tmp = incl + T;
+    work_count_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ranges, T, chunk, nw);
+    (void)inclusive_scan_u32(scan_tmp, scan_temp_bytes((int)T), nw, incl, (int)T, s);
+    work_fill_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ranges, chunk, nw, incl, T, chunk_base, work_tile);
 }
 
 // Single-pass tile sort: the sort's digit totals are the per-tile instance counts, so the tile ranges
@@ -275,7 +312,7 @@ void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t
 __global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *__restrict__ counts, uint32_t T,
                                                                uint32_t chunk, uint2 *__restrict__ ranges,
                                                                uint32_t *__restrict__ chunk_base,
-                                                               uint32_t *__restrict__ work_tile)
+                                                               uint4 *__restrict__ work_tile)
 {
     __shared__ uint32_t wsum[16], wsum2[16];
     __shared__ uint32_t carry, carry2;
@@ -300,7 +337,8 @@ __global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *_
         if (t < T) {
             ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles keep (0,0) like the memset
             chunk_base[t] = wstart;
-            for (uint32_t j = 0; j < nw; ++j) work_tile[wstart + j] = t;
+            for (uint32_t j = 0; j < nw; ++j)
+                work_tile[wstart + j] = make_uint4(t, start + j * chunk, min(start + c, start + (j + 1) * chunk), nw);
         }
         __syncthreads();
         if (tid == 1023) { carry = start + c; carry2 = wstart + nw; }
@@ -310,7 +348,7 @@ __global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *_
 }
 
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
-                            uint32_t *work_tile, hipStream_t s)
+                            uint4 *work_tile, hipStream_t s)
 {
     ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, T, chunk, ranges, chunk_base, work_tile);
 }

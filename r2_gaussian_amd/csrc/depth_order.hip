@@ -20,7 +20,7 @@ namespace r2 {
 namespace {
 
 constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
-constexpr uint32_t MAX_BUCKET = 48;   // a fuller bucket raises the fallback flag
+constexpr uint32_t MAX_BUCKET = 256;  // a fuller bucket raises the fallback flag (ranking costs one pass over the bucket per key)
 
 struct Ctrl {          // zeroed before every use
     uint32_t kmax;     // max of visible keys

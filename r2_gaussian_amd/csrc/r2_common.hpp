@@ -83,7 +83,7 @@ size_t sort_temp_bytes(size_t n);
 // pointer to the per-digit key counts (the bucket sizes), valid until the temp storage is reused.
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                   const uint32_t *win, uint32_t *wout, size_t n, int end_bit, bool allow_skip, const uint32_t **totals_out,
-                  hipStream_t s);
+                  hipStream_t s, uint32_t *inv_out = nullptr /* with win and no skipping: inv_out[value] = position */);
 int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                        uint32_t *vout, size_t n, int end_bit, hipStream_t s);
 // inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
@@ -109,11 +109,13 @@ int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32
                 size_t R, uint2 *ranges, size_t T, hipStream_t s);
 uint32_t higher_msb(uint32_t n);
 // forward work list: tile t owns work items [chunk_base[t], chunk_base[t+1]), one per `chunk` list entries
-void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint32_t *work_tile,
-                       hipStream_t s);
+size_t build_work_temp_bytes(size_t T);
+// work_tile[w] = {tile, first instance, one past the last instance, work items of that tile}
+void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
+                       void *temp /* build_work_temp_bytes(T) bytes, may be null for T <= 4096 */, hipStream_t s);
 // same, but the tile ranges themselves are derived from the per-tile instance counts of a single-pass tile sort
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
-                            uint32_t *work_tile, hipStream_t s);
+                            uint4 *work_tile, hipStream_t s);
 
 // XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,
 // which share Gaussian records) stay on one XCD's L2 instead of being dealt round-robin over 8.

@@ -157,7 +157,9 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
 // INV (single-pass sorts only): instead of scattering keys and the identity payload (out[pos] = index), write the INVERSE
 // permutation inv[index] = pos -- a coalesced store -- and scatter only the second payload.  Scattered 4-byte stores
 // from 8 XCDs into the same cache lines are the expensive part of a wide-digit pass; this cuts them by 3x.
-template <bool HAS_W, bool INV>
+// INVV (last pass of a multi-pass sort whose value payload is the original index): write inv[value] = pos instead of
+// out[pos] = value -- the same number of scattered stores, but it replaces a separate permutation-inversion kernel.
+template <bool HAS_W, bool INV, bool INVV = false>
 __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
                                                                   int phase, const uint32_t *__restrict__ skip,
                                                                   const uint32_t *__restrict__ H,
@@ -271,7 +273,8 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
                 inv[idx] = pos;
             } else {
                 kout[pos] = key[i];
-                vout[pos] = val[i];
+                if (INVV) inv[val[i]] = pos;
+                else vout[pos] = val[i];
             }
             if (HAS_W) wout[pos] = wal[i];
         }
@@ -325,7 +328,7 @@ size_t sort_temp_bytes(size_t n) { return SortTemp::carve(nullptr, n).bytes; }
 
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                   const uint32_t *win, uint32_t *wout, size_t n, int end_bit, bool allow_skip, const uint32_t **totals_out,
-                  hipStream_t s)
+                  hipStream_t s, uint32_t *inv_out)
 {
     if (totals_out) *totals_out = nullptr;
     if (n == 0) return 0;
@@ -351,7 +354,10 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
         rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
             t.H, ntiles, bits, (uint32_t)n, p, allow_skip ? 1 : 0, t.skip, t.totals);
         const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
-        if (has_w)
+        if (inv_out && has_w && !allow_skip && p == plan.npass - 1)   // last pass: inverse permutation instead of the values
+            rs_downsweep_kernel<true, false, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, inv_out);
+        else if (has_w)
             rs_downsweep_kernel<true, false><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
                 buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr);
         else

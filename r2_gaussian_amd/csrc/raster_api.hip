@@ -99,10 +99,9 @@ extern "C" int r2_raster_forward(
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           bin.inv, R, bit, &tile_counts, s);
         } else {   // > 4096 tiles: general multi-pass sort, then invert its permutation (the scratch is free until backward)
-            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);
+            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)
             rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
-                               bin.point_list, R, bit, false, nullptr, s);
-            if (!rc) rc = invert_permutation(perm, bin.inv, R, s);
+                               bin.point_list, R, bit, false, nullptr, s, bin.inv);
         } }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
@@ -113,7 +112,7 @@ extern "C" int r2_raster_forward(
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
         if (rc) return rc;
-        launch_build_work(img.ranges, (uint32_t)T, FWD_CHUNK, img.chunk_base, img.work_tile, s);
+        launch_build_work(img.ranges, (uint32_t)T, FWD_CHUNK, img.chunk_base, img.work_tile, img.work_temp, s);
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);

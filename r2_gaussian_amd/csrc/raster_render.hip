@@ -92,16 +92,14 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
 }
 
 __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
     float *__restrict__ partial)
 {
     const uint32_t w = blockIdx.x;
     if (w >= chunk_base[T]) return;
-    const uint32_t tile = work_tile[w];
-    const uint32_t j0 = (w - chunk_base[tile]) * FWD_CHUNK;
-    const uint2 range = ranges[tile];
-    const uint32_t beg = range.x + j0, end = min(range.y, beg + FWD_CHUNK);
+    const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
+    const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;             // this wave's block inside the tile
@@ -186,16 +184,15 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 // Debug-mode kernel (pixel-parallel): also tracks n_contrib (RAS/forward.cu:381,391), which only `debug` callers read
 // back.  One lane per pixel, the wave's live entries are compacted per 256-entry batch and broadcast from LDS.
 __global__ void __launch_bounds__(256) raster_render_forward_debug_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
     float *__restrict__ partial, uint32_t *__restrict__ partial_last)
 {
     const uint32_t w = blockIdx.x;
     if (w >= chunk_base[T]) return;
-    const uint32_t tile = work_tile[w];
-    const uint32_t j0 = (w - chunk_base[tile]) * FWD_CHUNK;
+    const uint4 wd = work_tile[w];
+    const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const uint2 range = ranges[tile];
-    const uint32_t beg = range.x + j0, end = min(range.y, beg + FWD_CHUNK);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;

@@ -93,10 +93,11 @@ struct RasterBinning {
 struct RasterImage {
     uint2 *ranges;         // [T]
     uint32_t *chunk_base;  // [T+1] exclusive scan of ceil(len/FWD_CHUNK): first work item of each tile; [T] = total
-    uint32_t *work_tile;   // [NW]  tile of each forward work item
+    uint4 *work_tile;      // [NW]  tile of each forward work item
     float *partial;        // [NW*256] per-work-item partial pixel sums, combined in list order
     uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
     uint32_t *n_contrib;   // [N]  last contributing list position per pixel; only written in debug mode
+    char *work_temp;       // scratch of the parallel work-list construction (only for > 4096 tiles)
     size_t NW;             // upper bound on work items: R/FWD_CHUNK + T
     size_t bytes;
     static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug)
@@ -106,10 +107,11 @@ struct RasterImage {
         s.NW = R / FWD_CHUNK + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 1);
-        s.work_tile = b.take<uint32_t>(s.NW);
+        s.work_tile = b.take<uint4>(s.NW);
         s.partial = b.take<float>(s.NW * 256);
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
         s.n_contrib = b.take<uint32_t>(debug ? N : 0);
+        s.work_temp = b.take<char>(build_work_temp_bytes(T));
         s.bytes = b.total();
         return s;
     }

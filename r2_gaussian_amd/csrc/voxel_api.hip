@@ -56,18 +56,28 @@ extern "C" int r2_voxel_forward(
                             radii_y, radii_z, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     int rc;
+    // order of the Gaussians by the bits of world z (the reference's low sort word, Q10): bucket sort, radix fallback
+    const uint32_t *overflow_dev = nullptr;
     { StageScope t(ST_VOX_DEPTHSORT, s);
-    rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
-                       nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s); }
+    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, &overflow_dev, s); }
     if (rc) return rc;
-    R2_STAGE_CHECK(debug, s, "depth sort");
+    R2_STAGE_CHECK(debug, s, "depth order");
     { StageScope t(ST_VOX_SCAN, s);
     rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
-    uint32_t num_rendered = 0;
+    uint32_t num_rendered = 0, overflow = 0;
     R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipMemcpyAsync(&overflow, overflow_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     R2_HIP_TRY(hipStreamSynchronize(s));
+    if (overflow) {
+        rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
+                           nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
+        if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s);
+        if (rc) return rc;
+        R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        R2_HIP_TRY(hipStreamSynchronize(s));
+    }
     const size_t R = num_rendered;
 
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
@@ -89,10 +99,9 @@ extern "C" int r2_voxel_forward(
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           bin.inv, R, bit, &tile_counts, s);
         } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort, then invert its permutation
-            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);
+            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)
             rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
-                               bin.point_list, R, bit, false, nullptr, s);
-            if (!rc) rc = invert_permutation(perm, bin.inv, R, s);
+                               bin.point_list, R, bit, false, nullptr, s, bin.inv);
         } }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
@@ -103,7 +112,7 @@ extern "C" int r2_voxel_forward(
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
         if (rc) return rc;
-        launch_build_work(img.ranges, (uint32_t)T, VOX_CHUNK, img.chunk_base, img.work_tile, s);
+        launch_build_work(img.ranges, (uint32_t)T, VOX_CHUNK, img.chunk_base, img.work_tile, img.work_temp, s);
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_VOX_RENDER_FWD, s);

@@ -80,10 +80,10 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
     }
 }
 
-__global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+__global__ void __launch_bounds__(256, 3) voxel_render_forward_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
-    VoxelGrid v, float *__restrict__ partial)
+    VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
 {
     // two workgroups of 4 waves per work item (x-slabs 0-3 and 4-7): tile lists are short (~150 entries at 256^3), so
     // a workgroup is one dependent chain of gathers followed by 2-3 evaluation steps -- small workgroups let 4+ of them
@@ -97,10 +97,8 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
     if (hb >= nhalf) return;
     const uint32_t w = hb >> 1;
     const int half = (int)(hb & 1u);
-    const uint32_t tile = work_tile[w];
-    const uint32_t j0 = (w - chunk_base[tile]) * VOX_CHUNK;
-    const uint2 range = ranges[tile];
-    const uint32_t beg = range.x + j0, end = min(range.y, beg + VOX_CHUNK);
+    const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
+    const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = half * 4 + wave;
@@ -111,6 +109,38 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
     // bounding box touches ITS x-slab
     __shared__ float4 s0[VFWD_BATCH], s1[VFWD_BATCH], s2[VFWD_BATCH], s3[VFWD_BATCH];   // p, q, r, extents
     __shared__ uint16_t sQ[4][VFWD_BATCH];
+
+    if (end - beg < (uint32_t)VFWD_MIN_STEP) {
+        // Very short list (the median tile at 256^3 holds 8 entries): no lane-per-entry step can fill up, so ONE
+        // workgroup evaluates all 8 slabs voxel-parallel (two per wave) and the second half-item exits at once.
+        if (half) return;
+        const int n = (int)(end - beg);
+        if (tid < n) {
+            const uint32_t id = point_list[beg + (uint32_t)tid];
+            s0[tid] = rec[3 * id]; s1[tid] = rec[3 * id + 1]; s2[tid] = rec[3 * id + 2]; s3[tid] = ext[id];
+        }
+        __syncthreads();
+        for (int sl = wave; sl < TILE3D; sl += 4) {
+            const float xs = (float)(tx * TILE3D + sl) + 0.5f;
+            float sum = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float4 p = s0[j], h = s3[j];
+                if (!slab_live(p.x, p.y, p.z, h, xs, y0, z0)) continue;   // wave-uniform
+                const float4 q = s1[j], r = s2[j];
+                const float dx = p.x - xs, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);
+                const float pl = dx * (q.x * dx + q.y * dy + q.z * dz) + dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
+                const float al = __builtin_amdgcn_exp2f(pl);
+                sum += ((pl <= r.z) && (al >= ALPHA_MIN_3D)) ? al : 0.f;
+            }
+            if (wd.w == 1u) {
+                const int vx = tx * TILE3D + sl, vy = ty * TILE3D + (lane >> 3), vz = tz * TILE3D + (lane & 7);
+                if (vx < v.nx && vy < v.ny && vz < v.nz) out[((size_t)vx * v.ny + vy) * v.nz + vz] = sum;
+            } else {
+                partial[(size_t)w * 512 + sl * 64 + lane] = sum;
+            }
+        }
+        return;
+    }
 
     float acc[64];
 #pragma unroll
@@ -186,21 +216,27 @@ __global__ void __launch_bounds__(256, 4) voxel_render_forward_kernel(
             }
         }
     }
-    partial[(size_t)w * 512 + slab * 64 + lane] = acc[0] + tail;   // x*64 + y*8 + z: the layout voxel_combine_kernel expects
+    const float value = acc[0] + tail;
+    if (wd.w == 1u) {
+        // the tile's only work item (almost every tile at 256^3): write the volume directly, no partial + combine pass
+        const int vx = tx * TILE3D + slab, vy = ty * TILE3D + (lane >> 3), vz = tz * TILE3D + (lane & 7);
+        if (vx < v.nx && vy < v.ny && vz < v.nz) out[((size_t)vx * v.ny + vy) * v.nz + vz] = value;
+    } else {
+        partial[(size_t)w * 512 + slab * 64 + lane] = value;   // x*64 + y*8 + z: the layout voxel_combine_kernel expects
+    }
 }
 
 // Debug-mode kernel (voxel-parallel): also tracks n_contrib, which only `debug` callers read back.
 __global__ void __launch_bounds__(512) voxel_render_forward_debug_kernel(
-    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint32_t *__restrict__ work_tile,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, VoxelGrid v,
     float *__restrict__ partial, uint32_t *__restrict__ partial_last)
 {
     const uint32_t w = blockIdx.x;
     if (w >= chunk_base[T]) return;
-    const uint32_t tile = work_tile[w];
-    const uint32_t j0 = (w - chunk_base[tile]) * VOX_CHUNK;
+    const uint4 wd = work_tile[w];
+    const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const uint2 range = ranges[tile];
-    const uint32_t beg = range.x + j0, end = min(range.y, beg + VOX_CHUNK);
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x;
     // lane = y*8+z, wave = x: z-fastest, see the header comment
@@ -252,6 +288,7 @@ __global__ void __launch_bounds__(512) voxel_combine_kernel(
     const int tid = threadIdx.x;
     const int vx = tx * TILE3D + (tid >> 6), vy = ty * TILE3D + ((tid >> 3) & 7), vz = tz * TILE3D + (tid & 7);
     const uint32_t w0 = chunk_base[tile], w1 = chunk_base[tile + 1];
+    if (!NCONTRIB && w1 - w0 == 1u) return;   // written directly by the (production) forward kernel
     float C = 0.f;
     uint32_t last = 0;
     for (uint32_t w = w0; w < w1; ++w) {
@@ -425,7 +462,7 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
         else
             // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
             voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial);
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
     }
     if (write_ncontrib)
         voxel_combine_kernel<true><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v,

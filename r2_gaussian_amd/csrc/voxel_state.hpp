@@ -55,7 +55,8 @@ struct VoxelGeom {
         g.offsets = b.take<uint32_t>(P);
         g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
-        g.psort_bytes = sort_temp_bytes((size_t)P);
+        g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)
+                                                                                     : depth_order_temp_bytes((size_t)P);
         g.psort_temp = b.take<char>(g.psort_bytes);
         g.bytes = b.total();
         return g;
@@ -91,10 +92,11 @@ struct VoxelBinning {
 struct VoxelImage {
     uint2 *ranges;          // [T3]
     uint32_t *chunk_base;   // [T3+1]
-    uint32_t *work_tile;    // [NW]
+    uint4 *work_tile;       // [NW]
     float *partial;         // [NW*512]
     uint32_t *partial_last; // [NW*512] debug only
     uint32_t *n_contrib;    // [V], debug only
+    char *work_temp;       // scratch of the parallel work-list construction
     size_t NW;
     size_t bytes;
     static VoxelImage carve(char *chunk, size_t T, size_t V, size_t R, bool debug)
@@ -104,10 +106,11 @@ struct VoxelImage {
         s.NW = R / VOX_CHUNK + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 1);
-        s.work_tile = b.take<uint32_t>(s.NW);
+        s.work_tile = b.take<uint4>(s.NW);
         s.partial = b.take<float>(s.NW * 512);
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 512 : 0);
         s.n_contrib = b.take<uint32_t>(debug ? V : 0);
+        s.work_temp = b.take<char>(build_work_temp_bytes(T));
         s.bytes = b.total();
         return s;
     }
