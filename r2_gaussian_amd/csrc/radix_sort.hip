@@ -26,7 +26,7 @@ constexpr int RS_THREADS = 512;                // 8 waves rank a tile side by si
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_IPT = 8;
 constexpr int RS_TILE = RS_THREADS * RS_IPT;   // 4096 keys per workgroup
-constexpr int RS_SCAN_THREADS = 256;
+constexpr int RS_SCAN_THREADS = 1024;             // 32 digits x 32 tile slices
 constexpr int RS_MAX_BITS = 12;
 constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 constexpr int RS_MAX_PASSES = 4;

@@ -151,13 +151,13 @@ extern "C" int r2_raster_backward(
     }
 
     { StageScope t(ST_RAS_RENDER_BWD, s);
-    launch_raster_render_backward(geom, bin, width, height, (size_t)R, dL_dpix, s); }
+    launch_raster_render_backward(geom, bin, radii, width, height, (size_t)R, dL_dpix, s); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_RAS_GEOM_BWD, s);
     launch_raster_geom_backward(P, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
                                 tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D,
-                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, bin.inv, s); }
+                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }

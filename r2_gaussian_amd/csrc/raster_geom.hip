@@ -16,15 +16,6 @@ namespace r2 {
 // pixel coordinate of an NDC coordinate, evaluated in double like the reference (RAS/auxiliary.h:45-48)
 __device__ __forceinline__ float ndc2pix(float v, int S) { return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5); }
 
-// tile rectangle of a square of half-width `rad` around p (RAS/auxiliary.h:50-60); float->int truncation
-__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
-{
-    x0 = min(gx, max(0, (int)((px - rad) / TILE2D)));
-    y0 = min(gy, max(0, (int)((py - rad) / TILE2D)));
-    x1 = min(gx, max(0, (int)((px + rad + TILE2D - 1) / TILE2D)));
-    y1 = min(gy, max(0, (int)((py + rad + TILE2D - 1) / TILE2D)));
-}
-
 struct Cov2D {
     float tx, ty, tz;
     float xmul, ymul;
@@ -243,7 +234,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
     float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
     const float *__restrict__ proj, const float4 *__restrict__ rec, const float2 *__restrict__ op_mu,
-    const uint32_t *__restrict__ first_inst, const uint32_t *__restrict__ inv,
+    const uint32_t *__restrict__ first_inst,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
     float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
@@ -282,27 +273,11 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         rot_in = reinterpret_cast<const float4 *>(rotations)[idx];
     }
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
-    // rows are gathered through the inverse permutation of the tile sort; 4 at a time so that the two dependent
-    // round trips (inv -> row) of different instances overlap.  The summation order stays j = 0, 1, 2, ...
-    for (uint32_t j = 0; j < ninst; j += 4) {
-        uint32_t row[4];
-        float4 m0[4], m1[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) row[u] = (j + u < ninst) ? inv[first + j + u] : 0u;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (j + u < ninst) {
-                m0[u] = part[2 * (size_t)row[u]];
-                m1[u] = part[2 * (size_t)row[u] + 1];
-            } else {
-                m0[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                m1[u] = m0[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            S0 += m0[u].x; S1 += m0[u].y; S2 += m0[u].z; S3 += m0[u].w; S4 += m1[u].x; S5 += m1[u].y;
-        }
+    // this Gaussian's rows are contiguous: the render backward stores each instance's row at its EMISSION index
+    for (uint32_t j = 0; j < ninst; ++j) {
+        const float4 m0 = part[2 * (size_t)(first + j)];
+        const float4 m1 = part[2 * (size_t)(first + j) + 1];
+        S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
     const float op = om.x, mu_f = om.y, opmu = op * mu_f;
@@ -453,13 +428,13 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float tan_fovy, const float *view, const float *proj, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
-                                const float *part, const uint32_t *inv, hipStream_t s)
+                                const float *part, hipStream_t s)
 {
     const float h_y = H / (2.0f * tan_fovy);
     const float h_x = W / (2.0f * tan_fovx);
     raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
-        g.op_mu, g.first, inv, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
+        g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
         dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }

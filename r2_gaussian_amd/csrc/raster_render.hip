@@ -17,8 +17,8 @@
 //           as b128 broadcasts.  The 7 gradient sums of the reference are linear in 6 moments
 //           sum(w), sum(w dx), sum(w dy), sum(w dx^2), sum(w dx dy), sum(w dy^2), w = G*dL/dpix,
 //           accumulated in registers: no cross-lane reduction, and NO atomics -- each instance stores its
-//           moment row to scratch at its SORTED list position (coalesced), which the geometry backward gathers
-//           per Gaussian (inverse permutation of the tile sort) and reduces in a fixed order.  Gradients are therefore bit-reproducible,
+//           moment row to scratch at its EMISSION index (recomputed from the Gaussian's tile rectangle; contiguous
+//           per Gaussian), which the geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
 //           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
 //           Workgroups are cut as 256 consecutive instances of the global sorted list: perfect balance.
 //           Waves that straddle many sparse tiles switch to a per-lane gather of dL/dpix instead of
@@ -375,8 +375,9 @@ __device__ __forceinline__ void tile_moments_gather(const float4 a, const float4
 }
 
 __global__ void __launch_bounds__(256) raster_render_backward_kernel(
-    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
-    const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
+    const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
+    const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
+    uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
 {
     constexpr int NB = TILE2D / SUB2D;        // blocks per tile side (2)
     constexpr int NBLK = NB * NB;             // blocks per tile (4)
@@ -494,10 +495,15 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
         }
     }
     if (live) {
-        // scratch row = the instance's SORTED position: coalesced stores; the geometry backward gathers each Gaussian's
-        // rows through the inverse permutation of the tile sort
-        part[2 * (size_t)k] = make_float4(S[0], S[1], S[2], S[3]);
-        part[2 * (size_t)k + 1] = make_float4(S[4], S[5], 0.f, 0.f);
+        // scratch row = the instance's EMISSION index, recomputed from the Gaussian's tile rectangle (the duplicate
+        // kernel emits a Gaussian's tiles y-major / x-minor from `first`): a Gaussian's rows end up contiguous, so
+        // the geometry backward streams them -- no permutation has to be carried through the sort
+        int rx0, ry0, rx1, ry1;
+        tile_rect(a.x, a.y, radii[id], gx, gy, rx0, ry0, rx1, ry1);
+        const int ttx = (int)(tile % (uint32_t)gx), tty = (int)(tile / (uint32_t)gx);
+        const size_t u = (size_t)first[id] + (size_t)((tty - ry0) * (rx1 - rx0) + (ttx - rx0));
+        part[2 * u] = make_float4(S[0], S[1], S[2], S[3]);
+        part[2 * u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
 }
 
@@ -524,14 +530,15 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
     return 0;
 }
 
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, int W, int H, size_t R,
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
                                   const float *dL_dpix, hipStream_t s)
 {
     if (R == 0) return 0;
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, (uint32_t)R, W, H, gx,
+    const int gy = (H + TILE2D - 1) / TILE2D;
+    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
                                                                    nchunks, dL_dpix,
                                                                    reinterpret_cast<float4 *>(b.part));
     return 0;

@@ -13,6 +13,16 @@ constexpr float ALPHA_MIN_2D = 0.00001f;               // RAS/forward.cu:374
 constexpr float LOG2_ALPHA_MIN_2D = -16.609640474436812f;   // log2(1e-5)
 constexpr int SUB2D = 8;              // culling granularity of the render kernels: 8x8 pixel blocks of a 16x16 tile
 
+// tile rectangle of a square of half-width `rad` around p (RAS/auxiliary.h:50-60); float->int truncation.  Used by the
+// preprocess / duplicate kernels and by the render backward, which recomputes an instance's emission index from it.
+__device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, int gy, int &x0, int &y0, int &x1, int &y1)
+{
+    x0 = min(gx, max(0, (int)((px - rad) / TILE2D)));
+    y0 = min(gy, max(0, (int)((py - rad) / TILE2D)));
+    x1 = min(gx, max(0, (int)((px + rad + TILE2D - 1) / TILE2D)));
+    y1 = min(gy, max(0, (int)((py + rad + TILE2D - 1) / TILE2D)));
+}
+
 // does the bounding box (px +- hx, py +- hy) of a Gaussian's alpha >= 1e-5 region touch the pixel block
 // [x0, x0+n) x [y0, y0+n)?  (pixel centres are the integers; +-inf half-extents mean never / always)
 __device__ __forceinline__ bool block_live(float px, float py, float hx, float hy, float x0, float y0, float n)
@@ -66,10 +76,11 @@ struct RasterBinning {
     uint32_t *tiles;          // [R]  tile id of every SORTED instance (written by the multi-pass sort, or filled from the
                               //      ranges at the start of the backward when the single-pass sort skipped the key scatter)
     uint32_t *vals_unsorted;  // [R]  Gaussian id of every instance (emission order)
-    uint32_t *inv;            // [R]  sorted position of emission index u (inverse permutation of the tile sort): the
-                              //      backward writes its moment rows in sorted order, the geometry backward gathers them
+    uint32_t *inv;            // [R]  sorted position of emission index u (inverse permutation of the tile sort; kept for
+                              //      introspection -- the backward recomputes emission indices arithmetically)
     uint32_t *point_list;     // [R]  sorted Gaussian ids (the sort's second payload; the reference's point_list, bit-identical)
-    float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by SORTED position
+    float *part;              // [R*PART_STRIDE] backward scratch: per-instance moments, indexed by EMISSION position
+                              //      (a Gaussian's rows are contiguous: [first, first + tiles_touched))
     char *sort_temp;
     size_t sort_bytes;
     size_t bytes;
@@ -130,10 +141,10 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float tan_fovy, const float *view, const float *proj, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
-                                const float *part, const uint32_t *inv, hipStream_t s);
+                                const float *part, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
                                  float *out_color, bool write_ncontrib, hipStream_t s);
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, int W, int H, size_t R,
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 
 }  // namespace r2
