@@ -56,6 +56,17 @@ void stage_end(int stage, hipStream_t s)
     g_pending.push_back({stage, g_open[stage], e});
 }
 
+int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream_t s)
+{
+    static thread_local uint32_t *pinned = nullptr;   // pageable destinations are staged (and synchronised) by the runtime
+    if (!pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
+    R2_HIP_TRY(hipMemcpyAsync(pinned, dev_pair, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipStreamSynchronize(s));
+    *a = pinned[0];
+    *b = pinned[1];
+    return 0;
+}
+
 uint32_t higher_msb(uint32_t n)
 {
     // smallest b with (n >> b) == 0, i.e. bit length of n (same value as the reference's
@@ -110,7 +121,7 @@ __global__ void __launch_bounds__(SC_THREADS) scan_reduce_kernel(const uint32_t 
 __global__ void __launch_bounds__(SC_THREADS) scan_apply_kernel(const uint32_t *__restrict__ in,
                                                                 const uint32_t *__restrict__ order, uint32_t n,
                                                                 const uint32_t *__restrict__ partial,
-                                                                uint32_t *__restrict__ out)
+                                                                uint32_t *__restrict__ out, uint32_t *__restrict__ total_out)
 {
     __shared__ uint32_t sh[SC_THREADS / 64];
     __shared__ uint32_t wsum[SC_THREADS / 64];
@@ -139,7 +150,10 @@ __global__ void __launch_bounds__(SC_THREADS) scan_apply_kernel(const uint32_t *
 #pragma unroll
     for (int i = 0; i < SC_IPT; ++i) {
         run += x[i];
-        if (base + i < n) out[base + i] = run;
+        if (base + i < n) {
+            out[base + i] = run;
+            if (total_out && base + i == n - 1) *total_out = run;   // grand total, next to the other host-read words
+        }
     }
 }
 
@@ -147,7 +161,7 @@ size_t scan_temp_bytes(int P) { return sizeof(uint32_t) * ((size_t)(P + SC_TILE 
 size_t scan_gather_temp_bytes(int P) { return scan_temp_bytes(P); }
 
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
-                              int P, hipStream_t s)
+                              int P, hipStream_t s, uint32_t *total_out)
 {
     if (P <= 0) return 0;
     if (temp_bytes < scan_temp_bytes(P)) {
@@ -157,14 +171,14 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
     const uint32_t tiles = (uint32_t)((P + SC_TILE - 1) / SC_TILE);
     uint32_t *partial = reinterpret_cast<uint32_t *>(temp);
     scan_reduce_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial);
-    scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out);
+    scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out, total_out);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s)
 {
-    return inclusive_scan_gather_u32(temp, temp_bytes, in, nullptr, out, P, s);
+    return inclusive_scan_gather_u32(temp, temp_bytes, in, nullptr, out, P, s, nullptr);
 }
 
 // One thread per sorted instance; a tile boundary writes the end of the previous tile's range and the

@@ -26,7 +26,7 @@ struct Ctrl {          // zeroed before every use
     uint32_t kmax;     // max of visible keys
     uint32_t nkmax;    // max of ~key  (=> min key = ~nkmax)
     uint32_t nculled;  // ticket counter of culled Gaussians
-    uint32_t overflow; // some bucket holds more than MAX_BUCKET keys
+    uint32_t pad;
 };
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax, int log_nb)
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__res
     slot_id[pos] = i;
 }
 
-__global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__restrict__ c, int log_nb,
+__global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__restrict__ c, uint32_t *__restrict__ overflow, int log_nb,
                                                           const uint32_t *__restrict__ incl, const uint32_t *__restrict__ slot_key,
                                                           const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
 {
@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__r
     const uint32_t m = end - beg;
     if (m == 1) { order[p] = id; return; }
     if (m > MAX_BUCKET) {   // invalid result, flagged; still leave a valid permutation behind (the scan gathers through it)
-        c->overflow = 1u;
+        *overflow = 1u;
         order[p] = id;
         return;
     }
@@ -152,12 +152,11 @@ inline int log_buckets(size_t P)
 size_t depth_order_temp_bytes(size_t P) { return Temp::carve(nullptr, P, (size_t)1 << log_buckets(P)).bytes; }
 
 // order[P] = Gaussian ids sorted by (key, id); culled ids (key 0xFFFFFFFF) at the tail in arbitrary order.
-// *overflow_flag receives a device pointer to a word that is non-zero when the result is INVALID (fall back to the
-// radix sort); it must be read after the stream has caught up.
+// *overflow_flag (a device word) is set to 0, and to 1 when the result is INVALID (fall back to the radix sort); it must
+// be read after the stream has caught up.
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        const uint32_t **overflow_flag, hipStream_t s)
+                        uint32_t *overflow_flag, hipStream_t s)
 {
-    if (overflow_flag) *overflow_flag = nullptr;
     if (P == 0) return 0;
     const int log_nb = log_buckets(P);
     const size_t nb = (size_t)1 << log_nb;
@@ -168,14 +167,15 @@ int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uin
     }
     const unsigned grid = (unsigned)((P + 255) / 256);
     R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
+    R2_HIP_TRY(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), s));
     minmax_kernel<<<dim3(std::min((unsigned)((P + 4095) / 4096), 64u)), dim3(1024), 0, s>>>(keys, (uint32_t)P, t.ctrl);
     bucket_count_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts);
     const int rc = inclusive_scan_u32(t.scan_temp, t.scan_bytes, t.counts, t.incl, (int)nb, s);
     if (rc) return rc;
     bucket_place_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts, t.incl, t.slot_key,
                                                          t.slot_id, order);
-    bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, log_nb, t.incl, t.slot_key, t.slot_id, order);
-    if (overflow_flag) *overflow_flag = &t.ctrl->overflow;
+    bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, overflow_flag, log_nb, t.incl, t.slot_key, t.slot_id,
+                                                        order);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }

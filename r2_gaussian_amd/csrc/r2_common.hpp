@@ -91,7 +91,7 @@ int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint3
 // result (a bucket was too full), the caller must fall back to sort_pairs_ex
 size_t depth_order_temp_bytes(size_t P);
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        const uint32_t **overflow_flag, hipStream_t s);
+                        uint32_t *overflow_flag /* device word, set to 0 / 1 */, hipStream_t s);
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
 // *counts_out = per-tile instance counts (device pointer into temp)
@@ -103,7 +103,9 @@ int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipSt
 int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_t s);
 size_t scan_gather_temp_bytes(int P);
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
-                              int P, hipStream_t s);
+                              int P, hipStream_t s, uint32_t *total_out = nullptr /* device word receiving out[P-1] */);
+// one 8-byte device->host read of {num_rendered, overflow flag} through a pinned staging word pair + stream sync
+int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s);

@@ -41,6 +41,7 @@ struct RasterGeom {
     uint32_t *first;          // [P]   index of the Gaussian's first instance in the unsorted (emission) list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
+    uint32_t *host_words;     // [2]   {num_rendered, depth-order overflow flag}: the only words the host reads back
     uint32_t *offsets;        // [P]   inclusive scan of tiles_touched[order[j]]: instance runs in depth order
     char *scan_temp;
     size_t scan_bytes;
@@ -61,6 +62,7 @@ struct RasterGeom {
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
+        g.host_words = b.take<uint32_t>(32);
         g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
         g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)

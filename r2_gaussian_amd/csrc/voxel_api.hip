@@ -57,26 +57,28 @@ extern "C" int r2_voxel_forward(
     R2_STAGE_CHECK(debug, s, "preprocess");
     int rc;
     // order of the Gaussians by the bits of world z (the reference's low sort word, Q10): bucket sort, radix fallback
-    const uint32_t *overflow_dev = nullptr;
+    uint32_t *host_words = geom.host_words;   // {num_rendered, overflow flag}: read back with ONE 8-byte copy
     { StageScope t(ST_VOX_DEPTHSORT, s);
-    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, &overflow_dev, s); }
+    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "depth order");
     { StageScope t(ST_VOX_SCAN, s);
-    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s); }
+    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
+                                   host_words); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "scan");
+
+    // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
     uint32_t num_rendered = 0, overflow = 0;
-    R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    R2_HIP_TRY(hipMemcpyAsync(&overflow, overflow_dev, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    R2_HIP_TRY(hipStreamSynchronize(s));
-    if (overflow) {
+    rc = read_two_words(host_words, &num_rendered, &overflow, s);
+    if (rc) return rc;
+    if (overflow) {   // a bucket of the fast depth order overflowed (many identical keys): general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
-        if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s);
+        if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
+                                                s, host_words);
+        if (!rc) rc = read_two_words(host_words, &num_rendered, &overflow, s);
         if (rc) return rc;
-        R2_HIP_TRY(hipMemcpyAsync(&num_rendered, geom.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        R2_HIP_TRY(hipStreamSynchronize(s));
     }
     const size_t R = num_rendered;
 

@@ -33,6 +33,7 @@ struct VoxelGeom {
     uint32_t *first;          // [P]  first instance of the Gaussian in the emission list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
+    uint32_t *host_words;     // [2]   {num_rendered, depth-order overflow flag}: the only words the host reads back
     uint32_t *offsets;        // [P]  inclusive scan of tiles_touched[order[j]]
     char *scan_temp;
     size_t scan_bytes;
@@ -53,6 +54,7 @@ struct VoxelGeom {
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
+        g.host_words = b.take<uint32_t>(32);
         g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
         g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)
