@@ -121,11 +121,13 @@ def main():
     _lib.profile_read(reset=True)
     _lib.profile_enable([DOMINANT])
     barrier()
+    _lib.sync_wait_stats(reset=True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k)
     barrier()
     dt = time.perf_counter() - t0
+    wait_us, wait_n = _lib.sync_wait_stats(reset=True)
     dom = _lib.profile_read(reset=True).get(DOMINANT, (0.0, 0))
     _lib.profile_enable([])
     if world > 1:
@@ -235,6 +237,8 @@ def main():
                          "pipeline_frac": round(total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_alg_bytes": total_bytes},
             "cpu_baseline": cpu,
+            # host time per step spent waiting for num_rendered at the forward's sync: large = GPU-bound step
+            "host_wait_us_per_step": round(wait_us / max(wait_n, 1), 1),
             "kernels": kernels,
             "voxelizer": gvox,
         }

@@ -150,6 +150,9 @@ R2_API void r2_profile_enable(unsigned long long stage_mask);
 R2_API int r2_profile_stage_count(void);
 R2_API const char *r2_profile_stage_name(int stage);
 R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
+/* host time spent busy-waiting at the forward passes' synchronisation point (the D2H read of num_rendered), and the
+ * number of such waits: long waits = GPU-bound, short waits = the host is the bottleneck. */
+R2_API int r2_sync_wait_stats(double *total_us, long long *calls, int reset);
 
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
 /* Byte offsets of the private arrays inside the state buffers of a forward call with the given sizes; lets

@@ -59,7 +59,14 @@ class _DeviceHooks:
     def _make(self, i):
         def alloc(nbytes, _user):
             try:
-                t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+                # the state sizes follow num_rendered, which changes from view to view: round large requests up to a
+                # coarse grid so that the caching allocator sees a handful of recurring sizes instead of a new one per
+                # view (a miss is a hipMalloc, i.e. a device synchronisation in the middle of the forward pass)
+                n = int(nbytes)
+                if n > (1 << 20):
+                    g = 1 << max(20, n.bit_length() - 4)   # 1/16 .. 1/8 of the size
+                    n = (n + g - 1) // g * g
+                t = torch.empty(n, dtype=torch.uint8, device=self.device)
                 self.current.bufs[i] = t
                 return t.data_ptr()
             except Exception:   # out of memory etc.: report NULL, the C side turns it into R2_ERR_ALLOC

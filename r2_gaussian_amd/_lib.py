@@ -35,6 +35,7 @@ _SIGNATURES = {
     "r2_profile_stage_count": (C.c_int, []),
     "r2_profile_stage_name": (C.c_char_p, [_i]),
     "r2_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
+    "r2_sync_wait_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_raster_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, C.POINTER(C.c_int)]),
     "r2_voxel_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, _i, C.POINTER(C.c_int)]),
 }
@@ -91,6 +92,13 @@ def profile_enable(stages=None):
         for s in stages:
             mask |= 1 << names.index(s)
     lib().r2_profile_enable(mask)
+
+
+def sync_wait_stats(reset=True):
+    """-> (total microseconds the host busy-waited for num_rendered, number of waits)."""
+    us, n = C.c_double(0.0), C.c_longlong(0)
+    lib().r2_sync_wait_stats(C.byref(us), C.byref(n), int(reset))
+    return us.value, n.value
 
 
 def profile_read(reset=True):

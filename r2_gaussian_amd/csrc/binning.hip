@@ -2,6 +2,7 @@
 // the rasterizer and the voxelizer.  Replaces cub::DeviceScan::InclusiveSum / identifyTileRanges of the
 // reference (RAS/rasterizer_impl.cu:116-138,275,308-316); the sort lives in radix_sort.hip.
 #include "r2_common.hpp"
+#include <chrono>
 #include <cstring>
 #include <stdarg.h>
 #include <vector>
@@ -56,12 +57,29 @@ void stage_end(int stage, hipStream_t s)
     g_pending.push_back({stage, g_open[stage], e});
 }
 
+static double g_sync_wait_us = 0.0;
+static long long g_sync_calls = 0;
+
 int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream_t s)
 {
-    static thread_local uint32_t *pinned = nullptr;   // pageable destinations are staged (and synchronised) by the runtime
+    // pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the
+    // GPU is idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency
+    // is on the critical path -- a blocking hipStreamSynchronize may sleep on an interrupt (tens of microseconds)
+    static thread_local uint32_t *pinned = nullptr;
+    static thread_local hipEvent_t ev = nullptr;
     if (!pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
+    if (!ev) R2_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     R2_HIP_TRY(hipMemcpyAsync(pinned, dev_pair, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    R2_HIP_TRY(hipStreamSynchronize(s));
+    R2_HIP_TRY(hipEventRecord(ev, s));
+    hipError_t q;
+    const auto t0 = std::chrono::steady_clock::now();
+    while ((q = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
+    g_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    g_sync_calls += 1;
+    if (q != hipSuccess) {
+        set_error("read_two_words: %s", hipGetErrorString(q));
+        return -(int)q;
+    }
     *a = pinned[0];
     *b = pinned[1];
     return 0;
@@ -171,6 +189,16 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
     const uint32_t tiles = (uint32_t)((P + SC_TILE - 1) / SC_TILE);
     uint32_t *partial = reinterpret_cast<uint32_t *>(temp);
     scan_reduce_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial);
+    scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out, total_out);
+    R2_HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
+                                hipStream_t s, uint32_t *total_out)
+{
+    if (P <= 0) return 0;
+    const uint32_t tiles = (uint32_t)((P + SC_TILE - 1) / SC_TILE);
     scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out, total_out);
     R2_HIP_TRY(hipGetLastError());
     return 0;
@@ -371,6 +399,14 @@ void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t ch
 
 extern "C" const char *r2_last_error(void) { return r2::get_error(); }
 extern "C" int r2_abi_version(void) { return R2_ABI_VERSION; }
+
+extern "C" int r2_sync_wait_stats(double *total_us, long long *calls, int reset)
+{
+    if (total_us) *total_us = r2::g_sync_wait_us;
+    if (calls) *calls = r2::g_sync_calls;
+    if (reset) { r2::g_sync_wait_us = 0.0; r2::g_sync_calls = 0; }
+    return 0;
+}
 
 extern "C" void r2_profile_enable(unsigned long long stage_mask)
 {

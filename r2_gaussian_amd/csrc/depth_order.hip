@@ -38,8 +38,10 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint3
 }
 
 // few, fat workgroups and ONE atomic pair per workgroup: same-address atomics retire at only ~90 per microsecond
-__global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c)
+__global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c,
+                                                      uint32_t *__restrict__ overflow)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // only ever set by the rank kernel, three launches later
     __shared__ uint32_t smx[16], snmx[16];
     uint32_t mx = 0, nmx = 0;
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
@@ -90,34 +92,58 @@ __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__res
     slot_id[pos] = i;
 }
 
+// `weights` (optional): the rank kernel also accumulates sum(weights[id]) per 4096-position group of the final order
+// into `partial` -- the first half of the prefix sum the caller runs over weights[order[j]] next (scan_apply_only).
 __global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__restrict__ c, uint32_t *__restrict__ overflow, int log_nb,
                                                           const uint32_t *__restrict__ incl, const uint32_t *__restrict__ slot_key,
-                                                          const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
+                                                          const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order,
+                                                          const uint32_t *__restrict__ weights, uint32_t *__restrict__ partial)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nvis = incl[nb - 1];
-    if (p >= nvis) return;
-    const uint32_t k = slot_key[p], id = slot_id[p];
-    const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
-    const uint32_t beg = b ? incl[b - 1] : 0u, end = incl[b];
-    const uint32_t m = end - beg;
-    if (m == 1) { order[p] = id; return; }
-    if (m > MAX_BUCKET) {   // invalid result, flagged; still leave a valid permutation behind (the scan gathers through it)
-        *overflow = 1u;
-        order[p] = id;
-        return;
+    uint32_t fp = 0xFFFFFFFFu, id = 0;
+    if (p < nvis) {
+        const uint32_t k = slot_key[p];
+        id = slot_id[p];
+        const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
+        const uint32_t beg = b ? incl[b - 1] : 0u, end = incl[b];
+        const uint32_t m = end - beg;
+        if (m == 1) {
+            fp = p;
+        } else if (m > MAX_BUCKET) {   // invalid result, flagged; still leave a valid permutation behind
+            *overflow = 1u;
+            fp = p;
+        } else {
+            uint32_t rank = 0;
+            for (uint32_t q = beg; q < end; ++q) {
+                const uint32_t kq = slot_key[q], iq = slot_id[q];
+                rank += (kq < k || (kq == k && iq < id)) ? 1u : 0u;
+            }
+            fp = beg + rank;
+        }
+        order[fp] = id;
     }
-    uint32_t rank = 0;
-    for (uint32_t q = beg; q < end; ++q) {
-        const uint32_t kq = slot_key[q], iq = slot_id[q];
-        rank += (kq < k || (kq == k && iq < id)) ? 1u : 0u;
+    if (weights) {
+        // one atomic per wave when the wave's final positions share a group (nearly always: fp stays inside the bucket)
+        const uint32_t wgt = p < nvis ? weights[id] : 0u;
+        const uint32_t g = fp >> 12;
+        const unsigned long long livem = __ballot(p < nvis);
+        const uint32_t g0 = livem ? (uint32_t)__shfl(g, __ffsll((long long)livem) - 1) : 0u;   // group of the first live lane
+        if (__all(p >= nvis || g == g0)) {
+            uint32_t sum = wgt;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
+            if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&partial[g0], sum);
+        } else if (p < nvis && wgt) {
+            atomicAdd(&partial[g], wgt);
+        }
     }
-    order[beg + rank] = id;
 }
 
 struct Temp {
     Ctrl *ctrl;
     uint32_t *counts;     // [nb]   (ctrl and counts are zeroed by one memset)
+    uint32_t *partial;    // [P/4096 + 1] per-group weight sums of the final order (zeroed with the counts)
     uint32_t *incl;       // [nb]
     uint32_t *slot_key;   // [P]
     uint32_t *slot_id;    // [P]
@@ -129,6 +155,7 @@ struct Temp {
         Bump b(chunk);
         t.ctrl = b.take<Ctrl>(8);               // 128 bytes: keeps counts on the next 128-byte boundary
         t.counts = b.take<uint32_t>(nb);
+        t.partial = b.take<uint32_t>(P / 4096 + 2);
         t.zero_bytes = b.off;
         t.incl = b.take<uint32_t>(nb);
         t.slot_key = b.take<uint32_t>(P);
@@ -155,8 +182,9 @@ size_t depth_order_temp_bytes(size_t P) { return Temp::carve(nullptr, P, (size_t
 // *overflow_flag (a device word) is set to 0, and to 1 when the result is INVALID (fall back to the radix sort); it must
 // be read after the stream has caught up.
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        uint32_t *overflow_flag, hipStream_t s)
+                        uint32_t *overflow_flag, hipStream_t s, const uint32_t *weights, const uint32_t **partial_out)
 {
+    if (partial_out) *partial_out = nullptr;
     if (P == 0) return 0;
     const int log_nb = log_buckets(P);
     const size_t nb = (size_t)1 << log_nb;
@@ -167,15 +195,15 @@ int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uin
     }
     const unsigned grid = (unsigned)((P + 255) / 256);
     R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
-    R2_HIP_TRY(hipMemsetAsync(overflow_flag, 0, sizeof(uint32_t), s));
-    minmax_kernel<<<dim3(std::min((unsigned)((P + 4095) / 4096), 64u)), dim3(1024), 0, s>>>(keys, (uint32_t)P, t.ctrl);
+    minmax_kernel<<<dim3(std::min((unsigned)((P + 4095) / 4096), 64u)), dim3(1024), 0, s>>>(keys, (uint32_t)P, t.ctrl, overflow_flag);
     bucket_count_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts);
     const int rc = inclusive_scan_u32(t.scan_temp, t.scan_bytes, t.counts, t.incl, (int)nb, s);
     if (rc) return rc;
     bucket_place_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts, t.incl, t.slot_key,
                                                          t.slot_id, order);
     bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, overflow_flag, log_nb, t.incl, t.slot_key, t.slot_id,
-                                                        order);
+                                                        order, weights, t.partial);
+    if (partial_out && weights) *partial_out = t.partial;
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -91,7 +91,12 @@ int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint3
 // result (a bucket was too full), the caller must fall back to sort_pairs_ex
 size_t depth_order_temp_bytes(size_t P);
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        uint32_t *overflow_flag /* device word, set to 0 / 1 */, hipStream_t s);
+                        uint32_t *overflow_flag /* device word, set to 0 / 1 */, hipStream_t s,
+                        const uint32_t *weights = nullptr, const uint32_t **partial_out = nullptr
+                        /* optional: per-4096-group sums of weights[order[j]] for inclusive_scan_gather_apply */);
+// second half of inclusive_scan_gather_u32 when the per-group partial sums already exist
+int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
+                                hipStream_t s, uint32_t *total_out);
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
 // *counts_out = per-tile instance counts (device pointer into temp)

@@ -91,13 +91,14 @@ __device__ __host__ __forceinline__ uint32_t pidx(uint32_t d) { return d + (d >>
 // ---------------------------------------------------------------------------------------------------------- upsweep
 __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
                                                                 int phase, const uint32_t *__restrict__ skip,
-                                                                uint32_t *__restrict__ H)
+                                                                uint32_t *__restrict__ H, uint32_t *__restrict__ clear_skip)
 {
     __shared__ uint32_t hist[RS_MAX_RADIX];
     const uint32_t radix = 1u << bits;
     const int e = executed_before(skip, pass);
     const uint32_t *__restrict__ keys = rd_k(buf, e == 0 ? 0 : target_of(e - 1, phase));
     for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) hist[d] = 0;
+    if (clear_skip && blockIdx.x == 0 && threadIdx.x == 0) clear_skip[0] = 0u;   // single-pass sorts: spares a memset launch
     __syncthreads();
     const uint32_t base = blockIdx.x * RS_TILE;
 #pragma unroll
@@ -350,7 +351,7 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
     for (int p = 0; p < plan.npass; ++p) {
         const int bits = plan.bits[p], radix = 1 << bits;
         rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip,
-                                                                     t.H);
+                                                                     t.H, nullptr);
         rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
             t.H, ntiles, bits, (uint32_t)n, p, allow_skip ? 1 : 0, t.skip, t.totals);
         const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
@@ -396,8 +397,7 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
     const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
     const int bits = plan.bits[0], radix = 1 << bits, phase = 1;
     Buffers buf{tiles, nullptr, ids, nullptr, nullptr, nullptr, nullptr, nullptr, ids_out};
-    R2_HIP_TRY(hipMemsetAsync(t.skip, 0, sizeof(uint32_t) * RS_MAX_PASSES * 2, s));
-    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H);
+    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.skip);
     rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
         t.H, ntiles, bits, (uint32_t)n, 0, 0, t.skip, t.totals);
     const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);

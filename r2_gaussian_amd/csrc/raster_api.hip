@@ -55,6 +55,8 @@ extern "C" int r2_raster_forward(
     rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "depth order");
+    // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
+    // 4x slower than this separate 5 us kernel: ~5k atomics on ~75 addresses serialise at the memory side)
     { StageScope t(ST_RAS_SCAN, s);
     rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
                                    host_words); }
@@ -116,7 +118,8 @@ extern "C" int r2_raster_forward(
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
-    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, s); }
+    // single-pass sort: the combine kernel (one workgroup per tile) also writes tiles[k] for the backward
+    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr, s); }
     R2_STAGE_CHECK(debug, s, "render");
     return (int)num_rendered;
 }
@@ -139,17 +142,6 @@ extern "C" int r2_raster_backward(
     }
     const RasterGeom geom = RasterGeom::carve(geom_buffer, P);
     const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
-    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
-    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)(gx * gy)))) {
-        // the single-pass tile sort did not scatter its keys: recover the per-instance tile ids from the ranges
-        if (!img_buffer) {
-            set_error("r2_raster_backward: image state required");
-            return R2_ERR_INVALID;
-        }
-        const RasterImage img = RasterImage::carve(img_buffer, (size_t)gx * gy, (size_t)width * height, (size_t)R, false);
-        fill_tiles_from_ranges(img.ranges, (size_t)gx * gy, bin.tiles, s);
-    }
-
     { StageScope t(ST_RAS_RENDER_BWD, s);
     launch_raster_render_backward(geom, bin, radii, width, height, (size_t)R, dL_dpix, s); }
     R2_STAGE_CHECK(debug, s, "render backward");

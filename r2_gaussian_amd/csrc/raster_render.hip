@@ -256,9 +256,13 @@ template <bool NCONTRIB>
 __global__ void __launch_bounds__(256) raster_combine_kernel(
     const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial,
     const uint32_t *__restrict__ partial_last, int W, int H, int gx, float *__restrict__ out_color,
-    uint32_t *__restrict__ n_contrib)
+    uint32_t *__restrict__ n_contrib, const uint2 *__restrict__ ranges, uint32_t *__restrict__ tiles)
 {
     const uint32_t tile = blockIdx.x;
+    if (tiles) {   // tile id of every sorted instance, for the backward (the single-pass sort does not scatter its keys)
+        const uint2 rg = ranges[tile];
+        for (uint32_t k = rg.x + threadIdx.x; k < rg.y; k += 256) tiles[k] = tile;
+    }
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
     const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
@@ -509,7 +513,7 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
 
 // ------------------------------------------------------------------------------------------------ launchers
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, hipStream_t s)
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
@@ -523,10 +527,10 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
     }
     if (write_ncontrib)
         raster_combine_kernel<true><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
-                                                                  out_color, im.n_contrib);
+                                                                  out_color, im.n_contrib, im.ranges, fill_tiles);
     else
         raster_combine_kernel<false><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
-                                                                   out_color, im.n_contrib);
+                                                                   out_color, im.n_contrib, im.ranges, fill_tiles);
     return 0;
 }
 

@@ -145,7 +145,7 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, hipStream_t s);
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, hipStream_t s);
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 
