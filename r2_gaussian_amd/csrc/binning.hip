@@ -60,7 +60,7 @@ void stage_end(int stage, hipStream_t s)
 static double g_sync_wait_us = 0.0;
 static long long g_sync_calls = 0;
 
-int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream_t s)
+int read_host_words(const uint32_t *dev_words, uint32_t out[3], hipStream_t s)
 {
     // pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the
     // GPU is idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency
@@ -69,7 +69,7 @@ int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream
     static thread_local hipEvent_t ev = nullptr;
     if (!pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
     if (!ev) R2_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    R2_HIP_TRY(hipMemcpyAsync(pinned, dev_pair, 2 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipMemcpyAsync(pinned, dev_words, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     R2_HIP_TRY(hipEventRecord(ev, s));
     hipError_t q;
     const auto t0 = std::chrono::steady_clock::now();
@@ -77,11 +77,12 @@ int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream
     g_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     g_sync_calls += 1;
     if (q != hipSuccess) {
-        set_error("read_two_words: %s", hipGetErrorString(q));
+        set_error("read_host_words: %s", hipGetErrorString(q));
         return -(int)q;
     }
-    *a = pinned[0];
-    *b = pinned[1];
+    out[0] = pinned[0];
+    out[1] = pinned[1];
+    out[2] = pinned[2];
     return 0;
 }
 

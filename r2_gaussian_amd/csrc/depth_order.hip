@@ -26,7 +26,8 @@ struct Ctrl {          // zeroed before every use
     uint32_t kmax;     // max of visible keys
     uint32_t nkmax;    // max of ~key  (=> min key = ~nkmax)
     uint32_t nculled;  // ticket counter of culled Gaussians
-    uint32_t pad;
+    uint32_t user;     // a word the caller's producer kernel may set (zeroed by depth_order_prepare); copied next to the
+                       // overflow flag so that the host reads it back with the same 12-byte copy
 };
 
 __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax, int log_nb)
@@ -41,7 +42,10 @@ __device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint3
 __global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c,
                                                       uint32_t *__restrict__ overflow)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *overflow = 0u;   // only ever set by the rank kernel, three launches later
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        overflow[0] = 0u;        // only ever set by the rank kernel, three launches later
+        overflow[1] = c->user;   // the producer kernel (preprocess) has finished: publish its flag
+    }
     __shared__ uint32_t smx[16], snmx[16];
     uint32_t mx = 0, nmx = 0;
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
@@ -181,8 +185,26 @@ size_t depth_order_temp_bytes(size_t P) { return Temp::carve(nullptr, P, (size_t
 // order[P] = Gaussian ids sorted by (key, id); culled ids (key 0xFFFFFFFF) at the tail in arbitrary order.
 // *overflow_flag (a device word) is set to 0, and to 1 when the result is INVALID (fall back to the radix sort); it must
 // be read after the stream has caught up.
+// zeroes the counters; may be called BEFORE the kernel that produces the keys, which can then set *depth_order_user_word
+int depth_order_prepare(void *temp, size_t temp_bytes, size_t P, hipStream_t s)
+{
+    if (P == 0) return 0;
+    const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P));
+    if (t.bytes > temp_bytes) {
+        set_error("depth_order_prepare: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
+        return R2_ERR_INVALID;
+    }
+    R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
+    return 0;
+}
+uint32_t *depth_order_user_word(void *temp, size_t P)
+{
+    return &Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P)).ctrl->user;
+}
+
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        uint32_t *overflow_flag, hipStream_t s, const uint32_t *weights, const uint32_t **partial_out)
+                        uint32_t *overflow_flag, hipStream_t s, const uint32_t *weights, const uint32_t **partial_out,
+                        bool prepared)
 {
     if (partial_out) *partial_out = nullptr;
     if (P == 0) return 0;
@@ -194,7 +216,7 @@ int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uin
         return R2_ERR_INVALID;
     }
     const unsigned grid = (unsigned)((P + 255) / 256);
-    R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
+    if (!prepared) R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
     minmax_kernel<<<dim3(std::min((unsigned)((P + 4095) / 4096), 64u)), dim3(1024), 0, s>>>(keys, (uint32_t)P, t.ctrl, overflow_flag);
     bucket_count_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts);
     const int rc = inclusive_scan_u32(t.scan_temp, t.scan_bytes, t.counts, t.incl, (int)nb, s);

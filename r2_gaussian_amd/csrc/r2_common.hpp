@@ -93,7 +93,12 @@ size_t depth_order_temp_bytes(size_t P);
 int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
                         uint32_t *overflow_flag /* device word, set to 0 / 1 */, hipStream_t s,
                         const uint32_t *weights = nullptr, const uint32_t **partial_out = nullptr
-                        /* optional: per-4096-group sums of weights[order[j]] for inclusive_scan_gather_apply */);
+                        /* optional: per-4096-group sums of weights[order[j]] for inclusive_scan_gather_apply */,
+                        bool prepared = false /* depth_order_prepare was already called on temp */);
+// overflow_flag points at TWO words: [0] the overflow flag, [1] a copy of *depth_order_user_word(temp, P), a word that is
+// zeroed by depth_order_prepare and may be set by the kernel producing the keys
+int depth_order_prepare(void *temp, size_t temp_bytes, size_t P, hipStream_t s);
+uint32_t *depth_order_user_word(void *temp, size_t P);
 // second half of inclusive_scan_gather_u32 when the per-group partial sums already exist
 int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
                                 hipStream_t s, uint32_t *total_out);
@@ -109,8 +114,8 @@ int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_
 size_t scan_gather_temp_bytes(int P);
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
                               int P, hipStream_t s, uint32_t *total_out = nullptr /* device word receiving out[P-1] */);
-// one 8-byte device->host read of {num_rendered, overflow flag} through a pinned staging word pair + stream sync
-int read_two_words(const uint32_t *dev_pair, uint32_t *a, uint32_t *b, hipStream_t s);
+// one 12-byte device->host read of {num_rendered, overflow flag, user flag} through pinned memory + busy-wait on an event
+int read_host_words(const uint32_t *dev_words, uint32_t out[3], hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s);

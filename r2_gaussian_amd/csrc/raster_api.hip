@@ -42,17 +42,20 @@ extern "C" int r2_raster_forward(
     }
     const RasterGeom geom = RasterGeom::carve(gchunk, P);
 
+    int rc = depth_order_prepare(geom.psort_temp, geom.psort_bytes, (size_t)P, s);   // zeroes the depth-order counters AND the
+    if (rc) return rc;                                                               // "thin Gaussians present" word below
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
-                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, s); }
+                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii,
+                             depth_order_user_word(geom.psort_temp, (size_t)P), s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
-    int rc;
     // Gaussians in (depth, id) order; instance runs are then laid out in that order.  Fast path: one-level bucket sort
     // (depth_order.hip); if a bucket overflowed (many identical depths) the flag read at the synchronisation below
     // sends us through the general radix sort instead.
     uint32_t *host_words = geom.host_words;   // {num_rendered, overflow flag}: read back with ONE 8-byte copy
     { StageScope t(ST_RAS_DEPTHSORT, s);
-    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s); }
+    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s, nullptr,
+                             nullptr, /*prepared=*/true); }
     if (rc) return rc;
     R2_STAGE_CHECK(debug, s, "depth order");
     // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
@@ -64,16 +67,20 @@ extern "C" int r2_raster_forward(
     R2_STAGE_CHECK(debug, s, "scan");
 
     // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
-    uint32_t num_rendered = 0, overflow = 0;
-    rc = read_two_words(host_words, &num_rendered, &overflow, s);
+    uint32_t hw[3] = { 0, 0, 0 };
+    rc = read_host_words(host_words, hw, s);
     if (rc) return rc;
+    uint32_t num_rendered = hw[0];
+    const uint32_t overflow = hw[1];
     if (overflow) {   // a bucket of the fast depth order overflowed (many identical keys): general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
                                                 s, host_words);
-        if (!rc) rc = read_two_words(host_words, &num_rendered, &overflow, s);
+        uint32_t hw2[3] = { 0, 0, 0 };
+        if (!rc) rc = read_host_words(host_words, hw2, s);
         if (rc) return rc;
+        num_rendered = hw2[0];
     }
     const size_t R = num_rendered;
 
@@ -119,7 +126,8 @@ extern "C" int r2_raster_forward(
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
     // single-pass sort: the combine kernel (one workgroup per tile) also writes tiles[k] for the backward
-    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr, s); }
+    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
+                                 /*any_thin=*/hw[2] != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     return (int)num_rendered;
 }

@@ -68,7 +68,8 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
+    uint32_t *__restrict__ thin_flag)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
@@ -145,6 +146,8 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
     rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, L, hx, hy);
     op_mu[idx] = make_float2(op, mu);
+    // tell the render kernels whether any Gaussian needs the re-anchored row recurrence (benign race: everybody stores 1)
+    if (thin_flag && row_tier((-0.5f * LOG2E) * conA, L, hx) == 1) *thin_flag = 1u;
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -397,14 +400,14 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, hipStream_t s)
+                             int mode, int *radii, uint32_t *thin_flag, hipStream_t s)
 {
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu);
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu, thin_flag);
     return 0;
 }
 

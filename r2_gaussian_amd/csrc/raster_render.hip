@@ -40,7 +40,8 @@ namespace r2 {
 // pixel p's sum in lane p.  Lane-per-entry makes the Gaussian separable along a pixel row: alpha(c+1) = alpha(c) * r(c),
 // r(c+1) = r(c) * exp2(2 A2), i.e. TWO v_exp_f32 per 8-pixel row instead of 8 -- v_exp_f32 issues at ~1/8 the rate
 // of an FMA on gfx950 and was ~40 % of the pixel-parallel kernel's issue time.  Entries that are too thin for the
-// recurrence or whose conic is not safely positive definite take the exact per-pixel path (see needs_exact_row).
+// 8-step recurrence are re-anchored at pixel 4, and those too thin even for that, or whose conic is not safely positive
+// definite, take the exact per-pixel path (see row_tier).
 // Sums are formed in a fixed order (per lane in list order, then a fixed butterfly): the image is deterministic.
 // When may a pixel row be walked with the recurrence?  The only hazard is an underflowed start: exp2(p0) = 0 for
 // p0 < -126, and 0 stays 0 however large the ratios.  Along a row p(c) = -|A2| c^2 + beta c + p0 is a concave parabola
@@ -49,15 +50,14 @@ namespace r2 {
 //     sqrt|A2| <= (sqrt(126) - sqrt(L - log2(1e-5) + 1)) / 7
 // (for opacity*mu = 0.01 that is |A2| <= 1.3, a conditional sigma of 0.75 px along x).  Gaussians beyond that, or
 // without a finite culling box (conic not safely positive definite), are evaluated exactly, pixel by pixel.
-__device__ __forceinline__ bool needs_exact_row(float A2, float L, float hx)
-{
-    const float smax = (11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f)) * (1.0f / 7.0f);
-    return !(smax > 0.f && fabsf(A2) <= smax * smax) || !(hx < 3.0e38f);
-}
 constexpr int FWD_BATCH = 256;          // list entries staged per round: one per thread of the workgroup
 
+// any4 (wave-uniform) / need4 (per lane): re-anchor the recurrence at pixel 4 for lanes whose Gaussian is too thin for 7
+// steps.  The re-anchor sits inside the row and does not touch the accumulators, so the three variants (8-step, 4-step,
+// exact) cost one shared code body + one exact body instead of three 64-accumulator bodies.
 template <bool EXACT>
-__device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64])
+__device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64],
+                                         bool any4 = false, bool need4 = false)
 {
     const float dx0 = a.x - x0;
     const float k1 = a.z * (1.0f - 2.0f * dx0);                       // log2 of alpha(1)/alpha(0), minus B2*dy
@@ -80,9 +80,19 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
         } else {
             float g = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdl);
             float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
+            float g4 = 0.f, rt4 = 0.f;
+            if (any4) {   // wave-uniform branch, outside the pixel loop (which stays one basic block)
+                const float dxs = dx0 - (float)(SUB2D / 2);
+                g4 = __builtin_amdgcn_exp2f(dxs * (a.z * dxs + bdy) + cdl);
+                rt4 = __builtin_amdgcn_exp2f(fminf(k1 + (float)SUB2D * a.z - bdy, 120.0f));
+            }
 #pragma unroll
             for (int c = 0; c < SUB2D; ++c) {
-                acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;   // power <= 0 holds for a positive definite conic
+                if (c == SUB2D / 2) {   // compile-time: two selects per row
+                    g = need4 ? g4 : g;
+                    rt = need4 ? rt4 : rt;
+                }
+                acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;   // power <= 0 holds: positive definite conic
                 g *= rt;
                 rt *= rr;
             }
@@ -91,6 +101,9 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
     }
 }
 
+// ANY4: the scene holds Gaussians that need the re-anchored recurrence (flag raised by the preprocess kernel, read by
+// the host at the forward's synchronisation point); scenes without them run the variant without re-anchoring code.
+template <bool ANY4>
 __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
@@ -158,8 +171,14 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
             }
             // recurrence path for the regular entries (flagged lanes contribute 0: L = -inf), then, only if the wave
             // holds any, the exact path for the flagged ones -- two in-place accumulations, no 64-register merge
-            const bool exact = (head + lane < cnt) && needs_exact_row(ea.z, eb.y, eb.z);
-            fwd_item<false>(exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+            // tier 0 / 1: row recurrence over 8 pixels, or re-anchored at pixel 4 (thin Gaussians; only waves holding
+            // such an entry pay for the two extra exps per row).  Tier 2 (exact) entries contribute 0
+            // here (L = -inf) and are evaluated by a second in-place pass, only if the wave holds any.
+            const int tier = (head + lane < cnt) ? row_tier(ea.z, eb.y, eb.z) : 0;
+            const bool exact = tier == 2;
+            const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
+            if (ANY4) fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc, __any(tier == 1), tier == 1);
+            else fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
             if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
         }
     }
@@ -313,7 +332,7 @@ __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, fl
 // kernel): two v_exp_f32 per row instead of one per pixel.
 template <int N, bool EXACT>
 __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b, const float *__restrict__ gt,
-                                                  float bx0, float by0, float *S)
+                                                  float bx0, float by0, float *S, bool any4 = false, bool need4 = false)
 {
     const float dx0 = a.x - bx0;
     const float lthr = LOG2_ALPHA_MIN_2D - b.y;                         // alpha >= 1e-5 <=> log2 G >= lthr
@@ -338,11 +357,21 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
         } else {
             float G = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdy2);
             float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
+            float G4 = 0.f, rt4 = 0.f;
+            if (any4) {   // wave-uniform: re-anchor values for the thin Gaussians of this wave
+                const float dxs = dx0 - (float)(N / 2);
+                G4 = __builtin_amdgcn_exp2f(dxs * (a.z * dxs + bdy) + cdy2);
+                rt4 = __builtin_amdgcn_exp2f(fminf(k1 + (float)N * a.z - bdy, 120.0f));
+            }
             // column moments t_k = sum_c c^k w_c (the c^k are literals: one FMA each), turned into moments of
             // dx = dx0 - c once per row
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int c = 0; c < N; ++c) {
+                if (c == N / 2) {
+                    G = need4 ? G4 : G;
+                    rt = need4 ? rt4 : rt;
+                }
                 const float w = (G >= gthr) ? G * g[c] : 0.f;   // power <= 0 holds for a positive definite conic
                 t0 += w;
                 t1 = fmaf(w, (float)c, t1);
@@ -381,7 +410,7 @@ __device__ __forceinline__ void tile_moments_gather(const float4 a, const float4
 __global__ void __launch_bounds__(256) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
-    uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part)
+    uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part, const uint32_t *__restrict__ thin_flag)
 {
     constexpr int NB = TILE2D / SUB2D;        // blocks per tile side (2)
     constexpr int NBLK = NB * NB;             // blocks per tile (4)
@@ -392,6 +421,7 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
     __shared__ float2 s_r1[4][64];
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
     if (chunk >= nchunks) return;
+    const bool scene_thin = *thin_flag != 0u;   // raised by the preprocess kernel (see row_tier)
     const uint32_t k = chunk * 256u + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool live = k < R;
@@ -476,8 +506,14 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
             const float by0 = (float)((int)(ot / gx) * TILE2D + (q / NB) * SUB2D);
             const float *gq = gt + sl * GT_TILE + (q / NB) * SUB2D * GT_STRIDE + (q % NB) * SUB2D;
             // exact per-pixel path for thin / not safely positive definite Gaussians, the row recurrence for the rest
-            const bool exact = needs_exact_row(oa.z, ob.y, ob.z);
-            if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M);
+            const int tier = e < total ? row_tier(oa.z, ob.y, ob.z) : 0;
+            const bool exact = tier == 2;
+            if (scene_thin) {   // scene-uniform: only scenes with thin Gaussians carry the re-anchoring code path
+                const bool any4 = __any(tier == 1);
+                if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M, any4, tier == 1);
+            } else {
+                if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M);
+            }
             if (__any(e < total && exact)) {
                 if (e < total && exact) block_moments_lds<SUB2D, true>(oa, ob, gq, bx0, by0, M);
             }
@@ -513,7 +549,7 @@ __global__ void __launch_bounds__(256) raster_render_backward_kernel(
 
 // ------------------------------------------------------------------------------------------------ launchers
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, hipStream_t s)
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
@@ -521,8 +557,11 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
         if (write_ncontrib)
             raster_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
+        else if (any_thin)
+            raster_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial);
         else
-            raster_render_forward_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+            raster_render_forward_kernel<false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial);
     }
     if (write_ncontrib)
@@ -544,7 +583,7 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     const int gy = (H + TILE2D - 1) / TILE2D;
     raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
                                                                    nchunks, dL_dpix,
-                                                                   reinterpret_cast<float4 *>(b.part));
+                                                                   reinterpret_cast<float4 *>(b.part), g.host_words + 2);
     return 0;
 }
 

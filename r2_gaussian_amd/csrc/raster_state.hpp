@@ -23,6 +23,18 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
     y1 = min(gy, max(0, (int)((py + rad + TILE2D - 1) / TILE2D)));
 }
 
+__device__ __forceinline__ int row_tier(float A2, float L, float hx)
+{
+    // 0: recurrence over the whole 8-pixel row; 1: recurrence re-anchored every 4 pixels (3 steps: safe down to a
+    // conditional sigma of ~0.33 px); 2: exact per-pixel evaluation
+    const float room = 11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
+    const float s8 = room * (1.0f / 7.0f), s4 = room * (1.0f / 3.0f);
+    const float a = fabsf(A2);
+    if (!(hx < 3.0e38f) || !(room > 0.f)) return 2;
+    return a <= s8 * s8 ? 0 : (a <= s4 * s4 ? 1 : 2);
+}
+__device__ __forceinline__ bool needs_exact_row(float A2, float L, float hx) { return row_tier(A2, L, hx) == 2; }
+
 // does the bounding box (px +- hx, py +- hy) of a Gaussian's alpha >= 1e-5 region touch the pixel block
 // [x0, x0+n) x [y0, y0+n)?  (pixel centres are the integers; +-inf half-extents mean never / always)
 __device__ __forceinline__ bool block_live(float px, float py, float hx, float hy, float x0, float y0, float n)
@@ -41,7 +53,8 @@ struct RasterGeom {
     uint32_t *first;          // [P]   index of the Gaussian's first instance in the unsorted (emission) list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
-    uint32_t *host_words;     // [2]   {num_rendered, depth-order overflow flag}: the only words the host reads back
+    uint32_t *host_words;     // [3]   {num_rendered, depth-order overflow flag, "thin Gaussians present" flag}: the only
+                              //       words the host reads back
     uint32_t *offsets;        // [P]   inclusive scan of tiles_touched[order[j]]: instance runs in depth order
     char *scan_temp;
     size_t scan_bytes;
@@ -134,7 +147,7 @@ struct RasterImage {
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, hipStream_t s);
+                             int mode, int *radii, uint32_t *thin_flag, hipStream_t s);
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
                             hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
@@ -145,7 +158,7 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, hipStream_t s);
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, hipStream_t s);
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 

@@ -71,16 +71,20 @@ extern "C" int r2_voxel_forward(
     R2_STAGE_CHECK(debug, s, "scan");
 
     // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
-    uint32_t num_rendered = 0, overflow = 0;
-    rc = read_two_words(host_words, &num_rendered, &overflow, s);
+    uint32_t hw[3] = { 0, 0, 0 };
+    rc = read_host_words(host_words, hw, s);
     if (rc) return rc;
+    uint32_t num_rendered = hw[0];
+    const uint32_t overflow = hw[1];
     if (overflow) {   // a bucket of the fast depth order overflowed (many identical keys): general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
                                                 s, host_words);
-        if (!rc) rc = read_two_words(host_words, &num_rendered, &overflow, s);
+        uint32_t hw2[3] = { 0, 0, 0 };
+        if (!rc) rc = read_host_words(host_words, hw2, s);
         if (rc) return rc;
+        num_rendered = hw2[0];
     }
     const size_t R = num_rendered;
 

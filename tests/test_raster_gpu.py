@@ -251,3 +251,23 @@ def test_culling_extent_is_conservative(seed, sm, aniso, oracle, gpu):
     assert (e_hip <= tol + 2.0 * e_oracle.max()).all(), "hip err %.3e, oracle err %.3e" % (e_hip.max(), e_oracle.max())
     if aniso == 1.0:
         assert (np.abs(h["color"][0] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
+
+
+@pytest.mark.parametrize("scale_mult", [0.25, 0.12, 0.04], ids=["sigma~0.8px", "sigma~0.4px", "sigma~0.13px"])
+def test_subpixel_gaussians_all_recurrence_tiers(scale_mult, oracle, gpu):
+    """Sub-pixel Gaussians walk through the three evaluation tiers of the render kernels (8-step recurrence, re-anchored
+    at pixel 4, exact per pixel): forward within 1e-4, backward within the usual tolerance, whatever the tier."""
+    c = S.make_cloud(4000, seed=21, scale_mult=scale_mult)
+    v = S.make_view(2.7, (96, 96))
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    assert np.array_equal(h["radii"], o["radii"]) and np.array_equal(h["point_list"], o["point_list"])
+    ref = o["color"]
+    assert (np.abs(h["color"] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
+    dL = S.make_pixel_grad(96, 96).numpy()
+    xyz, rho, sc, q = Hh.cloud_np(c)
+    vm, pm = Hh.np_view(v)
+    go = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D"):
+        Hh.assert_close_scaled(gh[k], go[k].reshape(gh[k].shape), rtol=2e-3, name=k, atol_frac=5e-5)
