@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     uint32_t dbase = incl - tsum;
     for (int w = 0; w < wave; ++w) dbase += wsum[w];
     const uint32_t *__restrict__ hrow = H + (size_t)tile * radix;
+    uint32_t mytot = 0;   // keys of this tile holding this thread's digit(s)
     for (uint32_t j = 0; j < dpt; ++j) {
         const uint32_t d = tid * dpt + j;
         if (d < radix) {
@@ -259,9 +260,58 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
             }
             digit_off[pidx(d)] = dbase + hrow[d];
             dbase += totals[d];
+            mytot += run;
         }
     }
     __syncthreads();
+
+    // Narrow digits (<= 8 bits: a 4096-key tile holds ~16 keys per digit): regroup the tile by digit in LDS first, so
+    // that a wave's stores fall into a few contiguous runs instead of 64 scattered words -- scattered 4-byte stores from
+    // 8 XCDs into shared cache lines are what a radix pass costs on this machine.
+    const bool regroup = !INV && bits <= 8;   // wave-uniform, radix <= 256 <= RS_THREADS: one digit per thread
+    if (regroup) {
+        uint32_t *tstart = digit_off + prad;              // [prad] first slot of each digit inside the regrouped tile
+        uint32_t *sK = tstart + prad, *sV = sK + RS_TILE, *sW = sV + RS_TILE;
+        uint32_t incl2 = mytot;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) {
+            const uint32_t up = __shfl_up(incl2, s2);
+            if (lane >= s2) incl2 += up;
+        }
+        if (lane == 63) wsum[wave] = incl2;
+        __syncthreads();
+        uint32_t lstart = incl2 - mytot;
+        for (int w = 0; w < wave; ++w) lstart += wsum[w];
+        if ((uint32_t)tid < radix) tstart[pidx(tid)] = lstart;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RS_IPT; ++i) {
+            const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
+            if (idx < n) {
+                const uint32_t d = (key[i] >> shift) & (radix - 1u);
+                const uint32_t li = tstart[pidx(d)] + wh[pidx(d)] + rank[i];
+                sK[li] = key[i];
+                sV[li] = val[i];
+                if (HAS_W) sW[li] = wal[i];
+            }
+        }
+        __syncthreads();
+        const uint32_t tile_n = min((uint32_t)RS_TILE, n - tile * RS_TILE);
+#pragma unroll
+        for (int i = 0; i < RS_IPT; ++i) {
+            const uint32_t j = (uint32_t)i * RS_THREADS + (uint32_t)tid;
+            if (j < tile_n) {
+                const uint32_t k = sK[j];
+                const uint32_t d = (k >> shift) & (radix - 1u);
+                const uint32_t pos = digit_off[pidx(d)] + (j - tstart[pidx(d)]);
+                kout[pos] = k;
+                if (INVV) inv[sV[j]] = pos;
+                else vout[pos] = sV[j];
+                if (HAS_W) wout[pos] = sW[j];
+            }
+        }
+        return;
+    }
 
     // ---- scatter
 #pragma unroll
@@ -354,7 +404,9 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
                                                                      t.H, nullptr);
         rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
             t.H, ntiles, bits, (uint32_t)n, p, allow_skip ? 1 : 0, t.skip, t.totals);
-        const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
+        // per-wave histograms + digit offsets (+ for narrow digits: regrouped tile starts and the staged tile itself)
+        const size_t lds = ((size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) +
+                            (bits <= 8 ? pidx((uint32_t)radix) + 3 * (size_t)RS_TILE : 0)) * sizeof(uint32_t);
         if (inv_out && has_w && !allow_skip && p == plan.npass - 1)   // last pass: inverse permutation instead of the values
             rs_downsweep_kernel<true, false, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
                 buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, inv_out);
