@@ -23,22 +23,37 @@ constexpr uint32_t CULLED_KEY = 0xFFFFFFFFu;
 constexpr uint32_t MAX_BUCKET = 256;  // a fuller bucket raises the fallback flag (ranking costs one pass over the bucket per key)
 
 struct Ctrl {          // zeroed before every use
-    uint32_t kmax;     // max of visible keys
-    uint32_t nkmax;    // max of ~key  (=> min key = ~nkmax)
+    uint32_t pmax;     // max / (complement of the) min of the keys with a clear sign bit (positive floats) ...
+    uint32_t pnmax;
+    uint32_t nmax;     // ... and of the keys with the sign bit set (negative floats: bits grow with |value|)
+    uint32_t nnmax;
     uint32_t nculled;  // ticket counter of culled Gaussians
     uint32_t user;     // a word the caller's producer kernel may set (zeroed by depth_order_prepare); copied next to the
                        // overflow flag so that the host reads it back with the same 12-byte copy
+    uint32_t pad[2];
 };
 
-__device__ __forceinline__ uint32_t bucket_of(uint32_t key, uint32_t kmin, uint32_t kmax, int log_nb)
+// Bucket of a key: monotone non-decreasing in the key's UNSIGNED bit pattern (the sort order), and roughly uniform in
+// occupancy for keys that are float bit patterns: positive floats come first (their bits grow with the value), then the
+// negative ones (bits grow with |value|); inside each class the bucket is linear in the float VALUE between the class's
+// min and max -- depths are spread evenly in value, not in bit pattern (half of all floats in (0,1) lie in [0.5,1)).
+// NaN / inf land in the last bucket of their class (fminf), which keeps the map monotone.
+__device__ __forceinline__ uint32_t bucket_of(uint32_t key, const Ctrl *__restrict__ c, int log_nb)
 {
-    const uint32_t range = kmax - kmin;
-    const int nbits = 32 - __clz(range | 1u);
-    const int shift = nbits > log_nb ? nbits - log_nb : 0;
-    return (key - kmin) >> shift;
+    const uint32_t nb = 1u << log_nb;
+    const bool has_neg = c->nmax != 0u, has_pos = c->pmax != 0u || c->pnmax != 0u;
+    const uint32_t nbp = has_neg ? (has_pos ? nb >> 1 : 0u) : nb;   // buckets given to the positive class
+    const bool neg = (key >> 31) != 0u;
+    const float v = __uint_as_float(key & 0x7FFFFFFFu);
+    const float lo = __uint_as_float((neg ? ~c->nnmax : ~c->pnmax) & 0x7FFFFFFFu);
+    const float hi = __uint_as_float((neg ? c->nmax : c->pmax) & 0x7FFFFFFFu);
+    const uint32_t cnt = neg ? nb - nbp : nbp;
+    const float scale = hi > lo ? (float)(cnt - 1u) / (hi - lo) : 0.f;
+    const uint32_t b = (uint32_t)fminf(fmaxf((v - lo) * scale, 0.f), (float)(cnt - 1u));
+    return (neg ? nbp : 0u) + b;
 }
 
-// few, fat workgroups and ONE atomic pair per workgroup: same-address atomics retire at only ~90 per microsecond
+// few, fat workgroups and ONE atomic group per workgroup: same-address atomics retire at only ~90 per microsecond
 __global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c,
                                                       uint32_t *__restrict__ overflow)
 {
@@ -46,24 +61,26 @@ __global__ void __launch_bounds__(1024) minmax_kernel(const uint32_t *__restrict
         overflow[0] = 0u;        // only ever set by the rank kernel, three launches later
         overflow[1] = c->user;   // the producer kernel (preprocess) has finished: publish its flag
     }
-    __shared__ uint32_t smx[16], snmx[16];
-    uint32_t mx = 0, nmx = 0;
+    __shared__ uint32_t sm[4][16];
+    uint32_t m[4] = { 0u, 0u, 0u, 0u };   // pmax, pnmax, nmax, nnmax
     for (uint32_t i = blockIdx.x * 1024u + threadIdx.x; i < n; i += gridDim.x * 1024u) {
         const uint32_t k = keys[i];
-        if (k != CULLED_KEY) { mx = max(mx, k); nmx = max(nmx, ~k); }
+        if (k == CULLED_KEY) continue;
+        if (k >> 31) { m[2] = max(m[2], k); m[3] = max(m[3], ~k); }
+        else { m[0] = max(m[0], k); m[1] = max(m[1], ~k); }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        mx = max(mx, (uint32_t)__shfl_xor(mx, d));
-        nmx = max(nmx, (uint32_t)__shfl_xor(nmx, d));
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) m[q] = max(m[q], (uint32_t)__shfl_xor(m[q], d));
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = m[q];
     }
-    if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; snmx[threadIdx.x >> 6] = nmx; }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 4) {
+        uint32_t r = 0;
 #pragma unroll
-        for (int w = 0; w < 16; ++w) { mx = max(mx, smx[w]); nmx = max(nmx, snmx[w]); }
-        if (mx) atomicMax(&c->kmax, mx);
-        if (nmx) atomicMax(&c->nkmax, nmx);
+        for (int w = 0; w < 16; ++w) r = max(r, sm[threadIdx.x][w]);
+        if (r) atomicMax(&c->pmax + threadIdx.x, r);
     }
 }
 
@@ -74,7 +91,7 @@ __global__ void __launch_bounds__(256) bucket_count_kernel(const uint32_t *__res
     if (i >= n) return;
     const uint32_t k = keys[i];
     if (k == CULLED_KEY) return;
-    atomicAdd(&counts[bucket_of(k, ~c->nkmax, c->kmax, log_nb)], 1u);
+    atomicAdd(&counts[bucket_of(k, c, log_nb)], 1u);
 }
 
 __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__restrict__ keys, uint32_t n, Ctrl *__restrict__ c,
@@ -89,7 +106,7 @@ __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__res
         order[n - 1u - atomicAdd(&c->nculled, 1u)] = i;   // tail, any order: culled Gaussians emit nothing
         return;
     }
-    const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
+    const uint32_t b = bucket_of(k, c, log_nb);
     const uint32_t v = atomicSub(&counts[b], 1u);          // v in [1, count]: a unique slot inside the bucket
     const uint32_t pos = incl[b] - v;
     slot_key[pos] = k;
@@ -109,7 +126,7 @@ __global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__r
     if (p < nvis) {
         const uint32_t k = slot_key[p];
         id = slot_id[p];
-        const uint32_t b = bucket_of(k, ~c->nkmax, c->kmax, log_nb);
+        const uint32_t b = bucket_of(k, c, log_nb);
         const uint32_t beg = b ? incl[b - 1] : 0u, end = incl[b];
         const uint32_t m = end - beg;
         if (m == 1) {
