@@ -51,8 +51,11 @@ def unpack_grads(flat):
 
 
 def allreduce_grads(flat, average=True, async_op=False):
-    """Sum (or mean) the packed gradients over ranks, in place.  One collective per optimiser step."""
-    if world() == 1:
+    """Sum (or mean) the packed gradients over ranks, in place.  One collective per optimiser step.
+    async_op=True returns the Work handle (call .wait() before touching ``flat``); the sum is then left un-averaged."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return None
+    if world() == 1 and not async_op:
         return None
     h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
     if average and not async_op:
