@@ -352,48 +352,15 @@ void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t
 // Single-pass tile sort: the sort's digit totals are the per-tile instance counts, so the tile ranges
 // (identifyTileRanges, RAS/rasterizer_impl.cu:116-138) are their exclusive scan -- computed here together with the
 // forward work list, by one workgroup (T <= 4096).
-__global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *__restrict__ counts, uint32_t T,
-                                                               uint32_t chunk, uint2 *__restrict__ ranges,
-                                                               uint32_t *__restrict__ chunk_base,
-                                                               uint4 *__restrict__ work_tile)
+__global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *__restrict__ counts, WorkListOut wo)
 {
-    __shared__ uint32_t wsum[16], wsum2[16];
-    __shared__ uint32_t carry, carry2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { carry = 0; carry2 = 0; }
-    __syncthreads();
-    for (uint32_t base = 0; base < T; base += 1024) {
-        const uint32_t t = base + tid;
-        const uint32_t c = t < T ? counts[t] : 0u;
-        const uint32_t nw = (c + chunk - 1) / chunk;
-        uint32_t incl = c, incl2 = nw;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d);
-            if (lane >= d) { incl += up; incl2 += up2; }
-        }
-        if (lane == 63) { wsum[wave] = incl; wsum2[wave] = incl2; }
-        __syncthreads();
-        uint32_t woff = 0, woff2 = 0;
-        for (int w = 0; w < wave; ++w) { woff += wsum[w]; woff2 += wsum2[w]; }
-        const uint32_t start = carry + woff + incl - c, wstart = carry2 + woff2 + incl2 - nw;
-        if (t < T) {
-            ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);   // empty tiles keep (0,0) like the memset
-            chunk_base[t] = wstart;
-            for (uint32_t j = 0; j < nw; ++j)
-                work_tile[wstart + j] = make_uint4(t, start + j * chunk, min(start + c, start + (j + 1) * chunk), nw);
-        }
-        __syncthreads();
-        if (tid == 1023) { carry = start + c; carry2 = wstart + nw; }
-        __syncthreads();
-    }
-    if (tid == 0) chunk_base[T] = carry2;
+    ranges_and_work_block<1024>(counts, wo);
 }
 
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
                             uint4 *work_tile, hipStream_t s)
 {
-    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, T, chunk, ranges, chunk_base, work_tile);
+    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, WorkListOut{ranges, chunk_base, work_tile, T, chunk});
 }
 
 }  // namespace r2

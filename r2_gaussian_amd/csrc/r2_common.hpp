@@ -102,11 +102,13 @@ uint32_t *depth_order_user_word(void *temp, size_t P);
 // second half of inclusive_scan_gather_u32 when the per-group partial sums already exist
 int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
                                 hipStream_t s, uint32_t *total_out);
+struct WorkListOut;
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
 // *counts_out = per-tile instance counts (device pointer into temp)
 int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
-                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s);
+                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s,
+                             const struct WorkListOut *work_out = nullptr /* also build tile ranges + work list */);
 // tiles[k] = t for k in ranges[t] (the backward's per-instance tile id when the sort did not scatter the keys);
 // inv[perm[k]] = k (inverse of a scattered permutation, for the general multi-pass sort)
 int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipStream_t s);
@@ -128,6 +130,52 @@ void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t
 // same, but the tile ranges themselves are derived from the per-tile instance counts of a single-pass tile sort
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
                             uint4 *work_tile, hipStream_t s);
+
+// Tile ranges + forward work list from the per-tile instance counts, by ONE workgroup of NT threads (T <= 4096):
+// ranges[t] = exclusive scan of counts (empty tiles keep (0,0) like the reference's memset), chunk_base[t] = exclusive
+// scan of ceil(count / chunk), one 16-byte work descriptor {tile, first, last, items of the tile} per work item.
+// Called by the standalone kernel in binning.hip and by block 0 of the single-pass tile sort's downsweep.
+struct WorkListOut {
+    uint2 *ranges;
+    uint32_t *chunk_base;
+    uint4 *work;
+    uint32_t T, chunk;
+};
+template <int NT>
+__device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict__ counts, const WorkListOut wo)
+{
+    __shared__ uint32_t rw_wsum[NT / 64], rw_wsum2[NT / 64];
+    __shared__ uint32_t rw_carry, rw_carry2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { rw_carry = 0; rw_carry2 = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < wo.T; base += NT) {
+        const uint32_t t = base + tid;
+        const uint32_t c = t < wo.T ? counts[t] : 0u;
+        const uint32_t nw = (c + wo.chunk - 1) / wo.chunk;
+        uint32_t incl = c, incl2 = nw;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d);
+            if (lane >= d) { incl += up; incl2 += up2; }
+        }
+        if (lane == 63) { rw_wsum[wave] = incl; rw_wsum2[wave] = incl2; }
+        __syncthreads();
+        uint32_t woff = 0, woff2 = 0;
+        for (int w = 0; w < wave; ++w) { woff += rw_wsum[w]; woff2 += rw_wsum2[w]; }
+        const uint32_t start = rw_carry + woff + incl - c, wstart = rw_carry2 + woff2 + incl2 - nw;
+        if (t < wo.T) {
+            wo.ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
+            wo.chunk_base[t] = wstart;
+            for (uint32_t j = 0; j < nw; ++j)
+                wo.work[wstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
+        }
+        __syncthreads();
+        if (tid == NT - 1) { rw_carry = start + c; rw_carry2 = wstart + nw; }
+        __syncthreads();
+    }
+    if (tid == 0) wo.chunk_base[wo.T] = rw_carry2;
+}
 
 // XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,
 // which share Gaussian records) stay on one XCD's L2 instead of being dealt round-robin over 8.

@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
                                                                   int phase, const uint32_t *__restrict__ skip,
                                                                   const uint32_t *__restrict__ H,
                                                                   const uint32_t *__restrict__ totals,
-                                                                  uint32_t *__restrict__ inv)
+                                                                  uint32_t *__restrict__ inv, WorkListOut wo)
 {
     extern __shared__ uint32_t smem[];
     const uint32_t radix = 1u << bits;
@@ -175,6 +175,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     __shared__ uint32_t wsum[RS_WAVES];
 
     if (skip[pass]) return;
+    // single-pass tile sort: the digit totals are the per-tile instance counts -- block 0 also turns them into the tile
+    // ranges and the render kernels' work list (one launch less on the forward's critical path)
+    if (INV && wo.ranges != nullptr && blockIdx.x == 0) ranges_and_work_block<RS_THREADS>(totals, wo);
     const int e = executed_before(skip, pass);
     const int src = e == 0 ? 0 : target_of(e - 1, phase), dst = target_of(e, phase);
     const uint32_t *__restrict__ kin = rd_k(buf, src);
@@ -409,13 +412,13 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
                             (bits <= 8 ? pidx((uint32_t)radix) + 3 * (size_t)RS_TILE : 0)) * sizeof(uint32_t);
         if (inv_out && has_w && !allow_skip && p == plan.npass - 1)   // last pass: inverse permutation instead of the values
             rs_downsweep_kernel<true, false, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
-                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, inv_out);
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, inv_out, WorkListOut{});
         else if (has_w)
             rs_downsweep_kernel<true, false><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
-                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr);
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr, WorkListOut{});
         else
             rs_downsweep_kernel<false, false><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
-                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr);
+                buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip, t.H, t.totals, nullptr, WorkListOut{});
     }
     if (allow_skip) {
         const uint32_t grid = (uint32_t)std::min<size_t>(1024, (n + RS_THREADS - 1) / RS_THREADS);
@@ -432,7 +435,8 @@ bool sort_is_single_pass(int end_bit) { return make_plan(end_bit).npass == 1; }
 // Single-pass stable sort of n instances by tile id (end_bit <= 12 bits): ids_out[pos] = ids[index] (scattered),
 // inv_out[index] = pos (coalesced), *counts_out = device pointer to the per-tile instance counts.
 int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
-                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s)
+                             uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s,
+                             const WorkListOut *work_out)
 {
     if (counts_out) *counts_out = nullptr;
     if (n == 0) return 0;
@@ -453,8 +457,8 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
     rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
         t.H, ntiles, bits, (uint32_t)n, 0, 0, t.skip, t.totals);
     const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
-    rs_downsweep_kernel<true, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip,
-                                                                                t.H, t.totals, inv_out);
+    rs_downsweep_kernel<true, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
+        buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, work_out ? *work_out : WorkListOut{});
     if (counts_out) *counts_out = t.totals;
     R2_HIP_TRY(hipGetLastError());
     return 0;

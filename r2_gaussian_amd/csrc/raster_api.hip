@@ -96,6 +96,7 @@ extern "C" int r2_raster_forward(
     const RasterImage img = RasterImage::carve(ichunk, T, N, R, debug != 0);
 
     const uint32_t *tile_counts = nullptr;
+    bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
         { StageScope t(ST_RAS_DUPLICATE, s);
         launch_raster_duplicate(geom, bin, P, radii, width, height, s); }
@@ -105,8 +106,10 @@ extern "C" int r2_raster_forward(
         // id (-> point_list)
         { StageScope t(ST_RAS_SORT, s);
         if (sort_is_single_pass(bit)) {
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
-                                          bin.inv, R, bit, &tile_counts, s);
+                                          bin.inv, R, bit, &tile_counts, s, &wo);
+            work_built = true;
         } else {   // > 4096 tiles: general multi-pass sort, then invert its permutation (the scratch is free until backward)
             uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)
             rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
@@ -116,7 +119,9 @@ extern "C" int r2_raster_forward(
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_RAS_RANGES, s);
-    if (tile_counts) {   // single-pass sort: per-tile counts are a by-product
+    if (work_built) {
+        // nothing to do
+    } else if (tile_counts) {   // single-pass sort: per-tile counts are a by-product
         launch_ranges_and_work(tile_counts, (uint32_t)T, FWD_CHUNK, img.ranges, img.chunk_base, img.work_tile, s);
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
