@@ -74,6 +74,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    all_cpus = os.sched_getaffinity(0)
+    pinned = r2dist.pin_to_gpu_numa_node(local_rank)   # one process per GPU, on a slice of the GPU's own socket
     if world > 1 or os.environ.get("R2_BENCH_FORCE_COMM", "0") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
@@ -132,6 +134,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if os.environ.get("R2_BENCH_NOGC", "0") == "1":
+        import gc
+        gc.disable()
     for k in range(args.warmup):
         step(k)
     # the dominant kernel is bracketed with HIP events on its own stream inside the timed region
@@ -212,6 +217,7 @@ def main():
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, one view
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        os.sched_setaffinity(0, all_cpus)   # the CPU baseline may use every host core again
         from oracle import oracle as O
         O.lib()
         v = views[0]
@@ -257,6 +263,7 @@ def main():
             "cpu_baseline": cpu,
             # host time per step spent waiting for num_rendered at the forward's sync: large = GPU-bound step
             "host_wait_us_per_step": round(wait_us / max(wait_n, 1), 1),
+            "host_cpus_pinned": len(pinned) if pinned else None,
             "kernels": kernels,
             "voxelizer": gvox,
         }

@@ -17,6 +17,42 @@ import torch.distributed as dist
 GRAD_WIDTH = 11   # 3 + 1 + 3 + 4
 
 
+def pin_to_gpu_numa_node(device_index=0, max_cpus=16, rank_slot=None):
+    """Restrict this process to (a compact slice of) the CPUs of the NUMA node the GPU hangs off -- one process per GPU,
+    each on its own socket's cores.  The host side of a training view is ~20 kernel launches and one busy-wait on a device->host read; on the
+    2-socket host of an MI355X node a process that lands on the remote socket runs ~20 % slower (measured).  Returns the
+    CPU set it pinned to, or None when the topology cannot be read (then nothing is changed)."""
+    import os
+    try:
+        props = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (props.pci_domain_id, props.pci_bus_id, props.pci_device_id)
+        path = "/sys/bus/pci/devices/%s/local_cpulist" % bdf
+        with open(path) as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            if "-" in part:
+                a, b = part.split("-")
+                cpus.update(range(int(a), int(b) + 1))
+            elif part:
+                cpus.add(int(part))
+        allowed = os.sched_getaffinity(0)
+        cpus = sorted(cpus & allowed)
+        if not cpus:
+            return None
+        # a compact slice of the node: the main thread, the autograd engine thread and the runtime's helpers then
+        # share caches instead of migrating over 128 hardware threads (measured: +10 % views/s over node-wide pinning);
+        # ranks of one node take disjoint slices
+        slot = device_index if rank_slot is None else rank_slot
+        nslots = max(1, len(cpus) // max_cpus)
+        lo = (slot % nslots) * max_cpus
+        pick = set(cpus[lo:lo + max_cpus]) or set(cpus)
+        os.sched_setaffinity(0, pick)
+        return pick
+    except Exception:
+        return None
+
+
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
