@@ -1,0 +1,160 @@
+// cbench.cpp -- the bench.py workload driven straight through the C ABI (no Python, no torch): a host program in the
+// style of the reference's own C++ boundary (SUB/rasterize_points.cu) for quick kernel experiments on the GPU box.
+//   python scripts/dump_scene.py && hipcc -O2 scripts/cbench.cpp -Iinclude -ldl -o scripts/cbench
+//   scripts/cbench [steps] [lib]        (default 200 steps, r2_gaussian_amd/libr2hip.so)
+// Prints views/s of forward+backward, the per-stage HIP-event breakdown, and the voxelizer's 256^3 query time.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "r2hip.h"
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+struct Slot { char *p = nullptr; size_t cap = 0; };
+static char *grow(size_t bytes, void *user)
+{
+    Slot *s = static_cast<Slot *>(user);
+    if (bytes > s->cap) {
+        if (s->p) (void)hipFree(s->p);
+        s->cap = bytes + bytes / 4 + (1u << 20);
+        if (hipMalloc(reinterpret_cast<void **>(&s->p), s->cap) != hipSuccess) return nullptr;
+    }
+    return s->p;
+}
+
+template <typename T> static T sym(void *h, const char *n)
+{
+    void *p = dlsym(h, n);
+    if (!p) { fprintf(stderr, "missing symbol %s\n", n); exit(1); }
+    return reinterpret_cast<T>(p);
+}
+
+struct ViewH { float vm[16], pm[16], cam[3], tanx, tany; int mode; };
+
+int main(int argc, char **argv)
+{
+    const int steps = argc > 1 ? atoi(argv[1]) : 200;
+    const std::string libpath = argc > 2 ? argv[2] : "r2_gaussian_amd/libr2hip.so";
+    void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
+    auto fwd = sym<decltype(&r2_raster_forward)>(h, "r2_raster_forward");
+    auto bwd = sym<decltype(&r2_raster_backward)>(h, "r2_raster_backward");
+    auto vfwd = sym<decltype(&r2_voxel_forward)>(h, "r2_voxel_forward");
+    auto prof_enable = sym<decltype(&r2_profile_enable)>(h, "r2_profile_enable");
+    auto prof_count = sym<decltype(&r2_profile_stage_count)>(h, "r2_profile_stage_count");
+    auto prof_name = sym<decltype(&r2_profile_stage_name)>(h, "r2_profile_stage_name");
+    auto prof_read = sym<decltype(&r2_profile_read)>(h, "r2_profile_read");
+    auto wait_stats = sym<decltype(&r2_sync_wait_stats)>(h, "r2_sync_wait_stats");
+    auto last_error = sym<decltype(&r2_last_error)>(h, "r2_last_error");
+
+    FILE *f = fopen("scripts/_scene/scene.bin", "rb");
+    if (!f) { fprintf(stderr, "scripts/_scene/scene.bin missing: run scripts/dump_scene.py\n"); return 1; }
+    int hdr[4];
+    if (fread(hdr, 4, 4, f) != 4) return 1;
+    const int P = hdr[0], V = hdr[1], H = hdr[2], W = hdr[3];
+    std::vector<float> host((size_t)P * 11);
+    if (fread(host.data(), 4, host.size(), f) != host.size()) return 1;
+    std::vector<ViewH> views(V);
+    for (auto &v : views)
+        if (fread(&v, sizeof(ViewH), 1, f) != 1) return 1;
+    std::vector<float> dLh((size_t)H * W);
+    if (fread(dLh.data(), 4, dLh.size(), f) != dLh.size()) return 1;
+    fclose(f);
+
+    float *d_in, *d_views, *dL, *out, *grads;
+    int *radii;
+    CHECK(hipMalloc(reinterpret_cast<void **>(&d_in), host.size() * 4));
+    CHECK(hipMemcpy(d_in, host.data(), host.size() * 4, hipMemcpyHostToDevice));
+    const float *means = d_in, *dens = d_in + (size_t)3 * P, *scal = d_in + (size_t)4 * P, *rot = d_in + (size_t)7 * P;
+    CHECK(hipMalloc(reinterpret_cast<void **>(&d_views), (size_t)V * 64 * 4));   // 64 floats per view: vm, pm, cam
+    for (int i = 0; i < V; ++i) {
+        CHECK(hipMemcpy(d_views + (size_t)i * 64, views[i].vm, 16 * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_views + (size_t)i * 64 + 16, views[i].pm, 16 * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(d_views + (size_t)i * 64 + 32, views[i].cam, 3 * 4, hipMemcpyHostToDevice));
+    }
+    CHECK(hipMalloc(reinterpret_cast<void **>(&dL), dLh.size() * 4));
+    CHECK(hipMemcpy(dL, dLh.data(), dLh.size() * 4, hipMemcpyHostToDevice));
+    CHECK(hipMalloc(reinterpret_cast<void **>(&out), (size_t)256 * 256 * 256 * 4));
+    CHECK(hipMalloc(reinterpret_cast<void **>(&radii), (size_t)3 * P * 4));
+    CHECK(hipMalloc(reinterpret_cast<void **>(&grads), (size_t)32 * P * 4));
+    float *g2d = grads, *gcon = grads + (size_t)3 * P, *gop = grads + (size_t)7 * P, *gmu = grads + (size_t)8 * P,
+          *g3d = grads + (size_t)9 * P, *gcov = grads + (size_t)12 * P, *gsc = grads + (size_t)18 * P, *grot = grads + (size_t)21 * P;
+    Slot slots[3];
+    hipStream_t s;
+    CHECK(hipStreamCreate(&s));
+
+    long long Rsum = 0;
+    auto step = [&](int k) {
+        const ViewH &v = views[k % V];
+        const float *dv = d_views + (size_t)(k % V) * 64;
+        const int R = fwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, W, H, means, dens, scal, 1.f, rot, nullptr, dv,
+                          dv + 16, dv + 32, v.tanx, v.tany, 0, v.mode, out, radii, 0, s);
+        if (R < 0) { fprintf(stderr, "forward: %d %s\n", R, last_error()); exit(1); }
+        Rsum += R;
+        const int rc = bwd(P, R, W, H, means, scal, 1.f, rot, nullptr, dv, dv + 16, dv + 32, v.tanx, v.tany, radii, slots[0].p,
+                           slots[1].p, slots[2].p, dL, g2d, gcon, gop, gmu, g3d, gcov, gsc, grot, v.mode, 0, s);
+        if (rc < 0) { fprintf(stderr, "backward: %d %s\n", rc, last_error()); exit(1); }
+    };
+    for (int k = 0; k < 20; ++k) step(k);
+    CHECK(hipStreamSynchronize(s));
+    double best = 1e30;
+    for (int rep = 0; rep < 3; ++rep) {
+        Rsum = 0;
+        wait_stats(nullptr, nullptr, 1);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < steps; ++k) step(20 + k);
+        CHECK(hipStreamSynchronize(s));
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        double wus = 0;
+        long long wn = 0;
+        wait_stats(&wus, &wn, 1);
+        printf("rep %d: %.1f views/s  %.1f us/step  (R avg %lld, host wait %.1f us/step)\n", rep, steps / dt, 1e6 * dt / steps,
+               Rsum / steps, wus / steps);
+        if (dt < best) best = dt;
+    }
+    printf("BEST %.1f views/s  %.2f us/step\n", steps / best, 1e6 * best / steps);
+
+    const int ns = prof_count();
+    std::vector<double> ms(ns);
+    std::vector<long long> cnt(ns);
+    prof_enable(~0ull);
+    for (int k = 0; k < 50; ++k) step(20 + k);
+    CHECK(hipStreamSynchronize(s));
+    prof_read(ms.data(), cnt.data(), 1);
+    double sum = 0;
+    for (int i = 0; i < ns; ++i)
+        if (cnt[i] && !strncmp(prof_name(i), "raster.", 7)) {
+            printf("  %-20s %8.2f us\n", prof_name(i), 1e3 * ms[i] / cnt[i]);
+            sum += 1e3 * ms[i] / cnt[i];
+        }
+    printf("  %-20s %8.2f us\n", "raster stage sum", sum);
+    prof_enable(0);
+
+    // voxelizer: the full 256^3 query
+    auto vox = [&]() {
+        const int R3 = vfwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, 256, 256, 256, 2.f, 2.f, 2.f, 0.f, 0.f, 0.f, means,
+                            dens, scal, 1.f, rot, nullptr, 0, out, radii, radii + P, radii + 2 * (size_t)P, 0, s);
+        if (R3 < 0) { fprintf(stderr, "voxel forward: %d %s\n", R3, last_error()); exit(1); }
+        return R3;
+    };
+    int R3 = 0;
+    for (int k = 0; k < 3; ++k) R3 = vox();
+    CHECK(hipStreamSynchronize(s));
+    const auto t1 = std::chrono::steady_clock::now();
+    for (int k = 0; k < 10; ++k) vox();
+    CHECK(hipStreamSynchronize(s));
+    const double tv = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / 10;
+    printf("voxel 256^3: %.3f ms  %.2f GVoxel/s  (R3 %d)\n", tv * 1e3, 256.0 * 256 * 256 / tv / 1e9, R3);
+    prof_enable(~0ull);
+    for (int k = 0; k < 5; ++k) vox();
+    CHECK(hipStreamSynchronize(s));
+    prof_read(ms.data(), cnt.data(), 1);
+    for (int i = 0; i < ns; ++i)
+        if (cnt[i] && !strncmp(prof_name(i), "voxel.", 6)) printf("  %-20s %8.2f us\n", prof_name(i), 1e3 * ms[i] / cnt[i]);
+    return 0;
+}

@@ -1,0 +1,165 @@
+// ubench_valu.hip -- issue cost of plain vs packed f32 VALU instructions on gfx950 (cycles per wave instruction per SIMD).
+//   hipcc --offload-arch=gfx950 -O3 scripts/ubench_valu.hip -o scripts/ubench_valu && scripts/ubench_valu
+// Every kernel runs ITER iterations of 8 independent instructions per wave; WAVES waves per SIMD; all 256 CUs.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int ITER = 4096;
+
+#define REP8(S) S(0) S(1) S(2) S(3) S(4) S(5) S(6) S(7)
+
+__global__ void k_fma(float *out, float a, float b)
+{
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (float)threadIdx.x + i;
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_mul(float *out, float a, float b)
+{
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (float)threadIdx.x + i;
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(a));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_pk_fma(float *out, float a, float b)
+{
+    float2v acc[8];
+    float2v av = { a, a + 1.f }, bv = { b, b + 1.f };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = float2v{ (float)threadIdx.x + i, 1.f };
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(av), "v"(bv));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_pk_mul(float *out, float a, float b)
+{
+    float2v acc[8];
+    float2v av = { a, a + 1.f };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = float2v{ (float)threadIdx.x + i, 1.f };
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_pk_mul_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(av));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_pk_add(float *out, float a, float b)
+{
+    float2v acc[8];
+    float2v av = { a, a + 1.f };
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = float2v{ (float)threadIdx.x + i, 1.f };
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_pk_add_f32 %0, %1, %0" : "+v"(acc[i]) : "v"(av));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i].x + acc[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// the render inner loop, scalar: G *= r; r *= q; acc += G*w   (3 instructions per pixel)
+__global__ void k_recur_scalar(float *out, float a, float b)
+{
+    float G[8], r[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { G[i] = a + i; r[i] = b; acc[i] = 0.f; }
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_mul_f32 %0, %0, %1\n v_mul_f32 %1, %1, %3\n v_add_f32 %2, %2, %0" : "+v"(G[i]), "+v"(r[i]), "+v"(acc[i]) : "v"(a));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i] + G[i] + r[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// ... and packed: two rows per instruction
+__global__ void k_recur_packed(float *out, float a, float b)
+{
+    float2v G[4], r[4], acc[4];
+    float2v q = { a, a };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { G[i] = float2v{ a + i, a - i }; r[i] = float2v{ b, b }; acc[i] = float2v{ 0.f, 0.f }; }
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_pk_mul_f32 %0, %0, %1\n v_pk_mul_f32 %1, %1, %3\n v_pk_add_f32 %2, %2, %0" : "+v"(G[i]), "+v"(r[i]), "+v"(acc[i]) : "v"(q));
+        S(0) S(1) S(2) S(3)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += acc[i].x + acc[i].y + G[i].x + G[i].y + r[i].x + r[i].y;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <typename K>
+static void run(const char *name, K kern, int waves_per_simd, double insts_per_iter, double flops_per_lane_iter, float *out)
+{
+    const int block = 256;                       // 4 waves = one per SIMD
+    const int grid = 256 * waves_per_simd;       // per CU: waves_per_simd workgroups
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    kern<<<grid, block>>>(out, 1.0001f, 0.9999f);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    kern<<<grid, block>>>(out, 1.0001f, 0.9999f);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    const double cyc = ms * 1e-3 * 2.4e9;                                     // at the 2.4 GHz peak clock
+    const double per_simd_insts = (double)ITER * insts_per_iter * waves_per_simd;
+    const double tflops = (double)grid * block * ITER * flops_per_lane_iter / (ms * 1e-3) / 1e12;
+    printf("%-16s waves/SIMD %d  %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at 2.4 GHz)  %7.1f TFLOP/s\n", name,
+           waves_per_simd, ms, cyc / per_simd_insts, tflops);
+}
+
+int main()
+{
+    float *out;
+    CHECK(hipMalloc(&out, sizeof(float) * 256 * 8 * 256));
+    for (int w : { 1, 2, 4 }) {
+        run("v_fma_f32", k_fma, w, 8, 16, out);
+        run("v_mul_f32", k_mul, w, 8, 8, out);
+        run("v_pk_fma_f32", k_pk_fma, w, 8, 32, out);
+        run("v_pk_mul_f32", k_pk_mul, w, 8, 16, out);
+        run("v_pk_add_f32", k_pk_add, w, 8, 16, out);
+        run("recur scalar", k_recur_scalar, w, 24, 24, out);
+        run("recur packed", k_recur_packed, w, 12, 24, out);
+    }
+    return 0;
+}
