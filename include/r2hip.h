@@ -154,17 +154,25 @@ R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
  * number of such waits: long waits = GPU-bound, short waits = the host is the bottleneck. */
 R2_API int r2_sync_wait_stats(double *total_us, long long *calls, int reset);
 
+/* The forward passes order the Gaussians by depth with a bucket sort whose bucket boundaries follow the depth range seen
+ * by the previous call with the same P (a per-thread hint: it saves five kernel launches and hides the num_rendered
+ * read-back).  Results never depend on it -- both paths produce the exact (depth, id) order.  mode 0: never use hints,
+ * 1: use them (default; the environment variable R2_DEPTH_HINT=0 also switches them off), 2: forget the history. */
+R2_API void r2_depth_hint_control(int mode);
+
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
 /* Byte offsets of the private arrays inside the state buffers of a forward call with the given sizes; lets
  * tests read the binning intermediates back without fixing the layout in the ABI.  which:
- *   0 tiles_touched u32[P]      1 point_offsets u32[P] (inclusive scan over Gaussians in depth order)
+ *   0 tiles_touched u32[P]      1 point_offsets u32[P] (inclusive scan over Gaussians in depth order; with a depth hint
+ *                                 only the entries of the visible Gaussians -- the first nvis -- are written)
  *   2 tiles_unsorted u32[R]     3 values_unsorted u32[R] (emission: depth-ordered Gaussians, tiles y/x-minor)
  *   4 tiles_sorted u32[R] (valid after backward, or for > 4096 tiles)   5 point_list u32[R] (== the reference's sorted point_list)
  *   6 ranges uint2[T]           7 cov3D f32[6P]
  *   8 n_contrib u32[N] (only filled when forward ran with debug != 0)
  *   9 packed render records f32[8P] (voxelizer: f32[12P])                14 {opacity, mu} f32[2P] (rasterizer)
  *  10 depth sort keys u32[P] (bits of the depth; 0xFFFFFFFF for culled Gaussians)
- *  11 first-instance index u32[P]   12 depth order u32[P] (Gaussian ids sorted by (depth, id))
+ *  11 first-instance index u32[P]   12 depth order u32[P] (ids sorted by (depth, id); culled ones behind, or unwritten with a hint)
+ *  15 host-read words u32[8]: {num_rendered, overflow, thin flag, key extrema x4, nvis}
  *  13 inv u32[R] (sorted position of every emitted instance: the inverse permutation of the tile sort)
  * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
 R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);

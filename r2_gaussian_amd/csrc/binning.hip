@@ -60,30 +60,44 @@ void stage_end(int stage, hipStream_t s)
 static double g_sync_wait_us = 0.0;
 static long long g_sync_calls = 0;
 
-int read_host_words(const uint32_t *dev_words, uint32_t out[3], hipStream_t s)
+// pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the GPU is
+// idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency is on the
+// critical path -- a blocking hipStreamSynchronize may sleep on an interrupt (tens of microseconds)
+static thread_local uint32_t *g_pinned = nullptr;
+static thread_local hipEvent_t g_read_ev = nullptr;
+
+int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s)
 {
-    // pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the
-    // GPU is idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency
-    // is on the critical path -- a blocking hipStreamSynchronize may sleep on an interrupt (tens of microseconds)
-    static thread_local uint32_t *pinned = nullptr;
-    static thread_local hipEvent_t ev = nullptr;
-    if (!pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&pinned), 64, hipHostMallocDefault));
-    if (!ev) R2_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    R2_HIP_TRY(hipMemcpyAsync(pinned, dev_words, 3 * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    R2_HIP_TRY(hipEventRecord(ev, s));
+    if (n < 1 || n > 16) {
+        set_error("read_host_words: %d words", n);
+        return R2_ERR_INVALID;
+    }
+    if (!g_pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_pinned), 64, hipHostMallocDefault));
+    if (!g_read_ev) R2_HIP_TRY(hipEventCreateWithFlags(&g_read_ev, hipEventDisableTiming));
+    R2_HIP_TRY(hipMemcpyAsync(g_pinned, dev_words, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    R2_HIP_TRY(hipEventRecord(g_read_ev, s));
+    return 0;
+}
+
+int read_host_words_wait(uint32_t *out, int n)
+{
     hipError_t q;
     const auto t0 = std::chrono::steady_clock::now();
-    while ((q = hipEventQuery(ev)) == hipErrorNotReady) __builtin_ia32_pause();
+    while ((q = hipEventQuery(g_read_ev)) == hipErrorNotReady) __builtin_ia32_pause();
     g_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     g_sync_calls += 1;
     if (q != hipSuccess) {
         set_error("read_host_words: %s", hipGetErrorString(q));
         return -(int)q;
     }
-    out[0] = pinned[0];
-    out[1] = pinned[1];
-    out[2] = pinned[2];
+    for (int i = 0; i < n; ++i) out[i] = g_pinned[i];
     return 0;
+}
+
+int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s)
+{
+    const int rc = read_host_words_begin(dev_words, n, s);
+    return rc ? rc : read_host_words_wait(out, n);
 }
 
 uint32_t higher_msb(uint32_t n)

@@ -87,18 +87,96 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
 int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
                        uint32_t *vout, size_t n, int end_bit, hipStream_t s);
 // inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
-// depth_order.hip: ids in (key, id) order by a one-level bucket sort; *overflow_flag -> device word, non-zero = invalid
-// result (a bucket was too full), the caller must fall back to sort_pairs_ex
+// depth_order.hip: ids in (key, id) order by a one-level bucket sort.  depth_order_prepare zeroes the control block + counters
+// and is called BEFORE the kernel that produces the keys (which may set the DW_USER word); depth_order_buckets is the
+// un-hinted path: it raises DW_OVERFLOW when a bucket was too full (result invalid: fall back to sort_pairs_ex).
 size_t depth_order_temp_bytes(size_t P);
-int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P,
-                        uint32_t *overflow_flag /* device word, set to 0 / 1 */, hipStream_t s,
-                        const uint32_t *weights = nullptr, const uint32_t **partial_out = nullptr
-                        /* optional: per-4096-group sums of weights[order[j]] for inclusive_scan_gather_apply */,
-                        bool prepared = false /* depth_order_prepare was already called on temp */);
-// overflow_flag points at TWO words: [0] the overflow flag, [1] a copy of *depth_order_user_word(temp, P), a word that is
-// zeroed by depth_order_prepare and may be set by the kernel producing the keys
 int depth_order_prepare(void *temp, size_t temp_bytes, size_t P, hipStream_t s);
-uint32_t *depth_order_user_word(void *temp, size_t P);
+int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uint32_t *order, size_t P, hipStream_t s);
+// ---- depth order, hinted fast path.  When the caller knows roughly where the keys lie (the range seen by its previous
+// call), the kernel that PRODUCES the keys can drop them into value-linear buckets right away: one returning 64-bit atomic per
+// key hands out a ticket inside the bucket and adds the Gaussian's instance count to the bucket's total.  One
+// dual prefix sum over the buckets then yields both the depth order (bucket base + rank inside the bucket) AND the
+// instance offsets in that order, i.e. it replaces min/max + count + scan + place + rank + the offsets scan of the
+// un-hinted path (4 launches instead of 9).  The hint only shapes the buckets (keys outside it are clamped into the end
+// buckets, which keeps the map monotone): the result is the exact (key, id) order whatever the hint; an over-full bucket
+// raises the overflow word and the caller falls back to the un-hinted path.
+constexpr uint32_t DEPTH_CULLED_KEY = 0xFFFFFFFFu;
+struct DepthHint {
+    float plo, pscale;      // keys with a clear sign bit (positive floats): bucket = (value - plo) * pscale, clamped to [0, npos)
+    float nlo, nscale;      // keys with the sign bit set (bits grow with |value|): npos + (|value| - nlo) * nscale, clamped
+    uint32_t npos, nneg;    // buckets of each class; npos + nneg = number of buckets
+};
+struct DepthReg {
+    unsigned long long *ct; // [nb] zeroed by depth_order_prepare; per bucket: (number of keys << 32) | sum of their instance
+                            //      counts, bumped by ONE 64-bit atomic per key.  nullptr = fast path off
+    uint2 *bt;              // [P]  {bucket, ticket} of every visible key
+    uint32_t *wgmm;         // [4 * producer workgroups] key extrema {pmax, ~pmin, nmax, ~nmin} per workgroup
+    DepthHint h;
+};
+__device__ __forceinline__ uint32_t hinted_bucket(uint32_t key, const DepthHint &h)
+{
+    const bool neg = (key >> 31) != 0u;
+    const uint32_t cnt = neg ? h.nneg : h.npos;
+    if (cnt == 0u) return neg ? h.npos - 1u : 0u;   // class unseen by the hint: share the neighbouring end bucket
+    const float v = __uint_as_float(key & 0x7FFFFFFFu);
+    const float x = (v - (neg ? h.nlo : h.plo)) * (neg ? h.nscale : h.pscale);
+    // NaN bit patterns are the largest keys of their class: last bucket
+    const uint32_t b = (v != v) ? cnt - 1u : (uint32_t)fminf(fmaxf(x, 0.f), (float)(cnt - 1u));
+    return (neg ? h.npos : 0u) + b;
+}
+// Producer side, in two steps so that the atomic's round trip hides behind the rest of the producer's work:
+//   depth_register_key  as soon as a visible Gaussian's key and instance count (> 0) are known (any control flow);
+//   depth_register_end  by EVERY thread of the 256-thread workgroup at the end (key = DEPTH_CULLED_KEY for threads without
+//                       a visible Gaussian): stores {bucket, ticket} and publishes the workgroup's key extrema.
+__device__ __forceinline__ uint2 depth_register_key(const DepthReg &r, uint32_t key, uint32_t n_inst)
+{
+    if (r.ct == nullptr) return make_uint2(0u, 0u);
+    const uint32_t b = hinted_bucket(key, r.h);
+    const unsigned long long old = atomicAdd(&r.ct[b], (1ull << 32) | (unsigned long long)n_inst);
+    return make_uint2(b, (uint32_t)(old >> 32));
+}
+__device__ __forceinline__ void depth_register_end(const DepthReg &r, uint32_t idx, uint32_t key, uint2 bucket_ticket)
+{
+    if (r.ct == nullptr) return;   // kernel-uniform
+    uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
+    if (key != DEPTH_CULLED_KEY) {
+        r.bt[idx] = bucket_ticket;
+        if (key >> 31) { m2 = key; m3 = ~key; }
+        else { m0 = key; m1 = ~key; }
+    }
+    __shared__ uint32_t dr_sm[4][4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        m0 = max(m0, (uint32_t)__shfl_xor(m0, d));
+        m1 = max(m1, (uint32_t)__shfl_xor(m1, d));
+        m2 = max(m2, (uint32_t)__shfl_xor(m2, d));
+        m3 = max(m3, (uint32_t)__shfl_xor(m3, d));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        const int w = threadIdx.x >> 6;
+        dr_sm[0][w] = m0; dr_sm[1][w] = m1; dr_sm[2][w] = m2; dr_sm[3][w] = m3;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+        r.wgmm[blockIdx.x * 4u + threadIdx.x] = max(max(dr_sm[threadIdx.x][0], dr_sm[threadIdx.x][1]),
+                                                    max(dr_sm[threadIdx.x][2], dr_sm[threadIdx.x][3]));
+}
+// host side of the fast path (depth_order.hip).  Words the host reads back after a forward pass, at the start of the
+// depth order's temp storage (zeroed by depth_order_prepare):
+enum { DW_TOTAL = 0, DW_OVERFLOW, DW_USER, DW_PMAX, DW_PNMAX, DW_NMAX, DW_NNMAX, DW_NVIS, DW_COUNT };
+uint32_t *depth_order_words(void *temp, size_t P);
+// which = 0 rasterizer, 1 voxelizer: separate hint histories.  Returns false when there is no usable hint for P keys (first
+// call, P changed, hints switched off): the caller then runs the un-hinted path.
+bool depth_hint_lookup(int which, size_t P, DepthHint *out);
+void depth_hint_update(int which, size_t P, const uint32_t words[DW_COUNT], bool overflowed);
+DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, uint32_t producer_workgroups);
+// after the producer kernel: dual prefix sum (-> DW_TOTAL, DW_NVIS, DW_OVERFLOW, key extrema are final after this launch
+// pair, so the host may start its read-back here) ...
+int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, hipStream_t s);
+// ... then placement + ranking: order[j] (j < nvis) = ids in (key, id) order, offsets[j] = inclusive instance offsets
+int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
+                            uint32_t *offsets, hipStream_t s);
 // second half of inclusive_scan_gather_u32 when the per-group partial sums already exist
 int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
                                 hipStream_t s, uint32_t *total_out);
@@ -116,8 +194,11 @@ int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_
 size_t scan_gather_temp_bytes(int P);
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
                               int P, hipStream_t s, uint32_t *total_out = nullptr /* device word receiving out[P-1] */);
-// one 12-byte device->host read of {num_rendered, overflow flag, user flag} through pinned memory + busy-wait on an event
-int read_host_words(const uint32_t *dev_words, uint32_t out[3], hipStream_t s);
+// one small device->host read (n <= 16 words) through pinned memory + busy-wait on an event.  begin enqueues the copy on the
+// stream, wait spins until it has landed: work enqueued between the two keeps the GPU busy while the host waits.
+int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
+int read_host_words_wait(uint32_t *out, int n);
+int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s);

@@ -42,46 +42,67 @@ extern "C" int r2_raster_forward(
     }
     const RasterGeom geom = RasterGeom::carve(gchunk, P);
 
-    int rc = depth_order_prepare(geom.psort_temp, geom.psort_bytes, (size_t)P, s);   // zeroes the depth-order counters AND the
-    if (rc) return rc;                                                               // "thin Gaussians present" word below
+    // Binning, first half: Gaussians in (depth, id) order + their instance offsets in that order.
+    //   hinted path (depth range known from the previous call with this P): preprocess registers every key in its bucket,
+    //   one dual scan + place + rank finish the job, and the host's read-back overlaps place + rank;
+    //   un-hinted path: min/max, count, scan, place, rank, then the offsets scan;
+    //   either may overflow a bucket (many identical depths / a stale hint): general radix sort + scan instead.
+    int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)P, s);   // zeroes counters + the host-read words
+    if (rc) return rc;
+    uint32_t *host_words = geom.host_words;
+    DepthHint hint;
+    const bool hinted = depth_hint_lookup(0, (size_t)P, &hint);
+    const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
+    DepthReg reg{};
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint, pre_wgs);
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
-                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii,
-                             depth_order_user_word(geom.psort_temp, (size_t)P), s); }
+                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
-    // Gaussians in (depth, id) order; instance runs are then laid out in that order.  Fast path: one-level bucket sort
-    // (depth_order.hip); if a bucket overflowed (many identical depths) the flag read at the synchronisation below
-    // sends us through the general radix sort instead.
-    uint32_t *host_words = geom.host_words;   // {num_rendered, overflow flag}: read back with ONE 8-byte copy
-    { StageScope t(ST_RAS_DEPTHSORT, s);
-    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s, nullptr,
-                             nullptr, /*prepared=*/true); }
-    if (rc) return rc;
-    R2_STAGE_CHECK(debug, s, "depth order");
-    // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
-    // 4x slower than this separate 5 us kernel: ~5k atomics on ~75 addresses serialise at the memory side)
-    { StageScope t(ST_RAS_SCAN, s);
-    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
-                                   host_words); }
-    if (rc) return rc;
-    R2_STAGE_CHECK(debug, s, "scan");
-
-    // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
-    uint32_t hw[3] = { 0, 0, 0 };
-    rc = read_host_words(host_words, hw, s);
-    if (rc) return rc;
-    uint32_t num_rendered = hw[0];
-    const uint32_t overflow = hw[1];
-    if (overflow) {   // a bucket of the fast depth order overflowed (many identical keys): general radix sort instead
+    uint32_t hw[DW_COUNT] = { 0 };
+    if (hinted) {
+        { StageScope t(ST_RAS_SCAN, s);
+        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)P, pre_wgs, s); }
+        if (rc) return rc;
+        rc = read_host_words_begin(host_words, DW_COUNT, s);   // everything the host needs is final here ...
+        if (rc) return rc;
+        { StageScope t(ST_RAS_DEPTHSORT, s);
+        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)P, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
+        if (rc) return rc;
+        rc = read_host_words_wait(hw, DW_COUNT);               // ... and the GPU places + ranks while the host waits
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "depth order (hinted)");
+    } else {
+        { StageScope t(ST_RAS_DEPTHSORT, s);
+        rc = depth_order_buckets(geom.dorder_temp, geom.dorder_bytes, geom.depth_key, geom.order, (size_t)P, s); }
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "depth order");
+        // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
+        // 4x slower than this separate 5 us kernel: ~5k atomics on ~75 addresses serialise at the memory side)
+        { StageScope t(ST_RAS_SCAN, s);
+        rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
+                                       host_words + DW_TOTAL); }
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "scan");
+        // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
+        rc = read_host_words(host_words, hw, DW_COUNT, s);
+        if (rc) return rc;
+    }
+    uint32_t num_rendered = hw[DW_TOTAL];
+    const bool overflow = hw[DW_OVERFLOW] != 0;
+    bool full_order = !hinted;   // order / offsets cover all P Gaussians (else only the visible prefix)
+    if (overflow) {   // general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
-                                                s, host_words);
-        uint32_t hw2[3] = { 0, 0, 0 };
-        if (!rc) rc = read_host_words(host_words, hw2, s);
+                                                s, host_words + DW_TOTAL);
+        uint32_t total = 0;
+        if (!rc) rc = read_host_words(host_words + DW_TOTAL, &total, 1, s);
         if (rc) return rc;
-        num_rendered = hw2[0];
+        num_rendered = total;
+        full_order = true;
     }
+    depth_hint_update(0, (size_t)P, hw, overflow);
     const size_t R = num_rendered;
 
     // both remaining state buffers are sized by R: the sorted lists (+ backward scratch) and the
@@ -99,7 +120,7 @@ extern "C" int r2_raster_forward(
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
         { StageScope t(ST_RAS_DUPLICATE, s);
-        launch_raster_duplicate(geom, bin, P, radii, width, height, s); }
+        launch_raster_duplicate(geom, bin, P, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         // stable sort by tile id; payloads: the emission index (-> perm, the backward's scratch row) and the Gaussian
@@ -132,7 +153,7 @@ extern "C" int r2_raster_forward(
     { StageScope t(ST_RAS_RENDER_FWD, s);
     // single-pass sort: the combine kernel (one workgroup per tile) also writes tiles[k] for the backward
     launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
-                                 /*any_thin=*/hw[2] != 0, s); }
+                                 /*any_thin=*/hw[DW_USER] != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     return (int)num_rendered;
 }
@@ -206,6 +227,7 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     case 11: p = (char *)g.first; buf = 0; break;
     case 13: p = (char *)b.inv; buf = 1; break;
     case 14: p = (char *)g.op_mu; buf = 0; break;
+    case 15: p = (char *)g.host_words; buf = 0; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

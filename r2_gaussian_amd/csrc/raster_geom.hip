@@ -62,17 +62,17 @@ __device__ __forceinline__ float mu_of(float circ, float diamond)
 }
 
 // ------------------------------------------------------------------ forward: one lane per Gaussian
-__global__ void __launch_bounds__(256) raster_preprocess_kernel(
-    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+// returns the Gaussian's depth key (DEPTH_CULLED_KEY if it emits nothing) and its number of tiles
+__device__ __forceinline__ void raster_preprocess_one(
+    int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
-    uint32_t *__restrict__ thin_flag)
+    uint32_t *__restrict__ thin_flag, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    key_out = DEPTH_CULLED_KEY;
     radii[idx] = 0;
     tiles_touched[idx] = 0;
     depth_key[idx] = 0xFFFFFFFFu;   // culled Gaussians sort behind every visible one
@@ -121,6 +121,9 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     depth_key[idx] = __float_as_uint(p_view.z);   // z > 0.2: float order == unsigned order of the bits
     radii[idx] = (int)my_radius;
     tiles_touched[idx] = (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0);
+    key_out = __float_as_uint(p_view.z);
+    // hinted depth order: the key goes straight into its bucket; the ticket comes back while the record is computed
+    bt_out = depth_register_key(reg, key_out, (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0));
     // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
     // alpha = opacity*mu*exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2 + L), L = log2(opacity*mu), and the
     // half-extents (hx, hy) of the bounding box of the set where alpha can reach the reference's 1e-5 cut-off
@@ -150,6 +153,25 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     if (thin_flag && row_tier((-0.5f * LOG2E) * conA, L, hx) == 1) *thin_flag = 1u;
 }
 
+__global__ void __launch_bounds__(256) raster_preprocess_kernel(
+    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
+    float focal_x, float focal_y, int mode, int gx, int gy,
+    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
+    uint32_t *__restrict__ thin_flag, DepthReg reg)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = DEPTH_CULLED_KEY;
+    uint2 bt = make_uint2(0u, 0u);
+    if (idx < P)
+        raster_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,
+                              tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, iota, cov3Ds, tiles_touched, op_mu,
+                              thin_flag, reg, key, bt);
+    depth_register_end(reg, (uint32_t)idx, key, bt);
+}
+
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
 __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *__restrict__ means3D,
                                                            const float *__restrict__ view, uint8_t *__restrict__ present)
@@ -170,8 +192,9 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 __global__ void __launch_bounds__(256) raster_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
-    uint32_t *__restrict__ vals)
+    uint32_t *__restrict__ vals, const uint32_t *__restrict__ nvis)
 {
+    if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave_first = j - lane;
@@ -400,23 +423,24 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, uint32_t *thin_flag, hipStream_t s)
+                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, hipStream_t s)
 {
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu, thin_flag);
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu, thin_flag,
+        reg);
     return 0;
 }
 
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
-                            hipStream_t s)
+                            const uint32_t *nvis, hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii, gx, gy,
-                                                                        g.first, b.tiles_unsorted, b.vals_unsorted);
+                                                                        g.first, b.tiles_unsorted, b.vals_unsorted, nvis);
     return 0;
 }
 

@@ -583,7 +583,7 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     const int gy = (H + TILE2D - 1) / TILE2D;
     raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
                                                                    nchunks, dL_dpix,
-                                                                   reinterpret_cast<float4 *>(b.part), g.host_words + 2);
+                                                                   reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
     return 0;
 }
 

@@ -53,11 +53,13 @@ struct RasterGeom {
     uint32_t *first;          // [P]   index of the Gaussian's first instance in the unsorted (emission) list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
-    uint32_t *host_words;     // [3]   {num_rendered, depth-order overflow flag, "thin Gaussians present" flag}: the only
-                              //       words the host reads back
+    uint32_t *host_words;     // [DW_COUNT] the words the host reads back (num_rendered, overflow flag, "thin Gaussians present"
+                              //       flag, key extrema, visible count): the control block at the start of psort_temp
     uint32_t *offsets;        // [P]   inclusive scan of tiles_touched[order[j]]: instance runs in depth order
     char *scan_temp;
     size_t scan_bytes;
+    char *dorder_temp;        // depth order (bucket sort) workspace; starts with the control block = host_words
+    size_t dorder_bytes;
     char *psort_temp;
     size_t psort_bytes;
     size_t bytes;
@@ -75,12 +77,13 @@ struct RasterGeom {
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
-        g.host_words = b.take<uint32_t>(32);
-        g.scan_bytes = scan_gather_temp_bytes(P);
+            g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
-        g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)
-                                                                                     : depth_order_temp_bytes((size_t)P);
-        g.psort_temp = b.take<char>(g.psort_bytes);
+        g.dorder_bytes = depth_order_temp_bytes((size_t)P);
+        g.dorder_temp = b.take<char>(g.dorder_bytes);
+        g.host_words = chunk ? depth_order_words(g.dorder_temp, (size_t)P) : nullptr;
+        g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order (kept apart: the control block at
+        g.psort_temp = b.take<char>(g.psort_bytes);   // the start of dorder_temp must survive until the backward)
         g.bytes = b.total();
         return g;
     }
@@ -147,8 +150,9 @@ struct RasterImage {
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, uint32_t *thin_flag, hipStream_t s);
+                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, hipStream_t s);
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
+                            const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,

@@ -51,41 +51,62 @@ extern "C" int r2_voxel_forward(
     }
     const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
 
+    // binning, first half (see raster_api.hip): order of the Gaussians by the bits of world z (the reference's low sort
+    // word, Q10) + instance offsets in that order; hinted / un-hinted bucket sort, radix fallback
+    int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)P, s);
+    if (rc) return rc;
+    uint32_t *host_words = geom.host_words;
+    DepthHint hint;
+    const bool hinted = depth_hint_lookup(1, (size_t)P, &hint);
+    const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
+    DepthReg reg{};
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint, pre_wgs);
     { StageScope t(ST_VOX_PREPROCESS, s);
     launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
-                            radii_y, radii_z, s); }
+                            radii_y, radii_z, reg, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
-    int rc;
-    // order of the Gaussians by the bits of world z (the reference's low sort word, Q10): bucket sort, radix fallback
-    uint32_t *host_words = geom.host_words;   // {num_rendered, overflow flag}: read back with ONE 8-byte copy
-    { StageScope t(ST_VOX_DEPTHSORT, s);
-    rc = depth_order_buckets(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.order, (size_t)P, host_words + 1, s); }
-    if (rc) return rc;
-    R2_STAGE_CHECK(debug, s, "depth order");
-    // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
-    // 4x slower than this separate 5 us kernel: ~5k atomics on ~75 addresses serialise at the memory side)
-    { StageScope t(ST_VOX_SCAN, s);
-    rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
-                                   host_words); }
-    if (rc) return rc;
-    R2_STAGE_CHECK(debug, s, "scan");
-
-    // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, RAS/rasterizer_impl.cu:279)
-    uint32_t hw[3] = { 0, 0, 0 };
-    rc = read_host_words(host_words, hw, s);
-    if (rc) return rc;
-    uint32_t num_rendered = hw[0];
-    const uint32_t overflow = hw[1];
-    if (overflow) {   // a bucket of the fast depth order overflowed (many identical keys): general radix sort instead
+    uint32_t hw[DW_COUNT] = { 0 };
+    if (hinted) {
+        { StageScope t(ST_VOX_SCAN, s);
+        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)P, pre_wgs, s); }
+        if (rc) return rc;
+        rc = read_host_words_begin(host_words, DW_COUNT, s);
+        if (rc) return rc;
+        { StageScope t(ST_VOX_DEPTHSORT, s);
+        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)P, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
+        if (rc) return rc;
+        rc = read_host_words_wait(hw, DW_COUNT);
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "depth order (hinted)");
+    } else {
+        { StageScope t(ST_VOX_DEPTHSORT, s);
+        rc = depth_order_buckets(geom.dorder_temp, geom.dorder_bytes, geom.depth_key, geom.order, (size_t)P, s); }
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "depth order");
+        { StageScope t(ST_VOX_SCAN, s);
+        rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
+                                       host_words + DW_TOTAL); }
+        if (rc) return rc;
+        R2_STAGE_CHECK(debug, s, "scan");
+        // total number of (tile, Gaussian) instances: sizes the binning state (the reference's D2H, VOX/voxelizer_impl.cu:248)
+        rc = read_host_words(host_words, hw, DW_COUNT, s);
+        if (rc) return rc;
+    }
+    uint32_t num_rendered = hw[DW_TOTAL];
+    const bool overflow = hw[DW_OVERFLOW] != 0;
+    bool full_order = !hinted;   // order / offsets cover all P Gaussians (else only the visible prefix)
+    if (overflow) {   // general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
-                                                s, host_words);
-        uint32_t hw2[3] = { 0, 0, 0 };
-        if (!rc) rc = read_host_words(host_words, hw2, s);
+                                                s, host_words + DW_TOTAL);
+        uint32_t total = 0;
+        if (!rc) rc = read_host_words(host_words + DW_TOTAL, &total, 1, s);
         if (rc) return rc;
-        num_rendered = hw2[0];
+        num_rendered = total;
+        full_order = true;
     }
+    depth_hint_update(1, (size_t)P, hw, overflow);
     const size_t R = num_rendered;
 
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
@@ -99,7 +120,7 @@ extern "C" int r2_voxel_forward(
     const uint32_t *tile_counts = nullptr;
     if (R > 0) {
         { StageScope t(ST_VOX_DUPLICATE, s);
-        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, s); }
+        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         { StageScope t(ST_VOX_SORT, s);
@@ -194,6 +215,7 @@ extern "C" long long r2_voxel_state_offset(int which, int P, long long R, int nx
     case 11: p = (char *)g.first; buf = 0; break;
     case 12: p = (char *)g.order; buf = 0; break;
     case 13: p = (char *)b.inv; buf = 1; break;
+    case 15: p = (char *)g.host_words; buf = 0; break;
     default: return -1;
     }
     if (buffer_id) *buffer_id = buf;

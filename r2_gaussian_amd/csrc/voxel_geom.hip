@@ -29,15 +29,15 @@ __device__ __forceinline__ void voxel_cov(const float *cov3D, float dvx, float d
     h[3] = cov.m[1][1]; h[4] = cov.m[1][2]; h[5] = cov.m[2][2];
 }
 
-__global__ void __launch_bounds__(256) voxel_preprocess_kernel(
-    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+// n_out = the Gaussian's number of tiles (0: it emits nothing)
+__device__ __forceinline__ void voxel_preprocess_one(
+    int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
-    VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
+    const VoxelGrid &v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
+    key_out = DEPTH_CULLED_KEY;
     radii_x[idx] = 0;
     radii_y[idx] = 0;
     radii_z[idx] = 0;
@@ -92,6 +92,8 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     radii_y[idx] = (int)rad.y;
     radii_z[idx] = (int)rad.z;
     tiles_touched[idx] = n;
+    key_out = __float_as_uint(p.z);   // visible: hinted depth order, the key goes straight into its bucket
+    bt_out = depth_register_key(reg, key_out, n);
     const float op = opacities[idx];
     const float L = op > 0.0f ? log2f(op) : -INFINITY;
     // bounding box of {alpha >= 1e-6} (VOX/forward.cu:293): q = d^T C d <= 2 ln2 (L - log2(1e-6)), half-widths
@@ -118,6 +120,22 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     ext[idx] = make_float4(hx, hy, hz, 0.f);
 }
 
+__global__ void __launch_bounds__(256) voxel_preprocess_kernel(
+    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    uint32_t key = DEPTH_CULLED_KEY;
+    uint2 bt = make_uint2(0u, 0u);
+    if (idx < P)
+        voxel_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z,
+                             rec, depth_key, iota, cov3Ds, tiles_touched, ext, reg, key, bt);
+    depth_register_end(reg, (uint32_t)idx, key, bt);
+}
+
 // Instance emission (duplicateWithKeys, VOX/voxelizer_impl.cu:54-101) in DEPTH order: sorted position j ->
 // Gaussian order[j] -> its tiles z-major / y / x-minor.  Only the tile id is the sort key (see binning.hip).
 // One wave serves 64 consecutive sorted positions and walks their contiguous output span with coalesced
@@ -125,8 +143,10 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
 __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
-    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals)
+    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
+    const uint32_t *__restrict__ nvis)
 {
+    if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const int wave_first = j - lane;
@@ -292,21 +312,22 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
-                            const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, hipStream_t s)
+                            const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
+                            hipStream_t s)
 {
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
                                                                         radii_z, g.rec, g.depth_key, g.iota, g.cov3D,
-                                                                        g.tiles_touched, g.ext);
+                                                                        g.tiles_touched, g.ext, reg);
     return 0;
 }
 
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
-                           const int *radii_y, const int *radii_z, hipStream_t s)
+                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s)
 {
     voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii_x, radii_y,
                                                                        radii_z, v.gx, v.gy, v.gz, g.first,
-                                                                       b.tiles_unsorted, b.vals_unsorted);
+                                                                       b.tiles_unsorted, b.vals_unsorted, nvis);
     return 0;
 }
 

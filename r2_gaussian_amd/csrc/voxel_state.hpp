@@ -33,10 +33,12 @@ struct VoxelGeom {
     uint32_t *first;          // [P]  first instance of the Gaussian in the emission list
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
-    uint32_t *host_words;     // [2]   {num_rendered, depth-order overflow flag}: the only words the host reads back
+    uint32_t *host_words;     // [DW_COUNT] the words the host reads back: the control block at the start of dorder_temp
     uint32_t *offsets;        // [P]  inclusive scan of tiles_touched[order[j]]
     char *scan_temp;
     size_t scan_bytes;
+    char *dorder_temp;        // depth order (bucket sort) workspace; starts with the control block = host_words
+    size_t dorder_bytes;
     char *psort_temp;
     size_t psort_bytes;
     size_t bytes;
@@ -54,11 +56,12 @@ struct VoxelGeom {
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
-        g.host_words = b.take<uint32_t>(32);
         g.scan_bytes = scan_gather_temp_bytes(P);
         g.scan_temp = b.take<char>(g.scan_bytes);
-        g.psort_bytes = sort_temp_bytes((size_t)P) > depth_order_temp_bytes((size_t)P) ? sort_temp_bytes((size_t)P)
-                                                                                     : depth_order_temp_bytes((size_t)P);
+        g.dorder_bytes = depth_order_temp_bytes((size_t)P);
+        g.dorder_temp = b.take<char>(g.dorder_bytes);
+        g.host_words = chunk ? depth_order_words(g.dorder_temp, (size_t)P) : nullptr;
+        g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order
         g.psort_temp = b.take<char>(g.psort_bytes);
         g.bytes = b.total();
         return g;
@@ -127,9 +130,10 @@ struct VoxelGrid {
 
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
-                            const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
+                            const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
+                            hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
-                           const int *radii_y, const int *radii_z, hipStream_t s);
+                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
                                float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D, float *dL_dmean3D_norm,

@@ -125,6 +125,76 @@ __global__ void k_recur_packed(float *out, float a, float b)
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// thresholded accumulate, two ways: v_cmp + v_cndmask + v_add  vs  v_cmpx + v_add under the EXEC mask + s_mov exec
+__global__ void k_thr_select(float *out, float a, float b)
+{
+    float G[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { G[i] = a + i + threadIdx.x * 1e-6f; acc[i] = 0.f; }
+    float t;
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_cmp_le_f32_e32 vcc, %3, %0\n s_nop 1\n v_cndmask_b32_e32 %2, 0, %0, vcc\n v_add_f32 %1, %1, %2\n v_mul_f32 %0, %0, %4" : "+v"(G[i]), "+v"(acc[i]), "=&v"(t) : "s"(b), "v"(a) : "vcc");
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i] + G[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+__global__ void k_thr_cmpx(float *out, float a, float b)
+{
+    float G[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { G[i] = a + i + threadIdx.x * 1e-6f; acc[i] = 0.f; }
+    unsigned long long ex;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(ex));
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_cmpx_le_f32_e32 %2, %0\n v_add_f32 %1, %1, %0\n s_mov_b64 exec, %3\n v_mul_f32 %0, %0, %4" : "+v"(G[i]), "+v"(acc[i]) : "s"(b), "s"(ex), "v"(a) : "vcc");
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i] + G[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// same without the EXEC restore between pixels (lower bound: what the SALU write costs)
+__global__ void k_thr_cmpx_norestore(float *out, float a, float b)
+{
+    float G[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { G[i] = a + i + threadIdx.x * 1e-6f; acc[i] = 0.f; }
+    unsigned long long ex;
+    asm volatile("s_mov_b64 %0, exec" : "=s"(ex));
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_cmpx_le_f32_e32 %2, %0\n v_add_f32 %1, %1, %0\n v_mul_f32 %0, %0, %4" : "+v"(G[i]), "+v"(acc[i]) : "s"(b), "s"(ex), "v"(a) : "vcc");
+        REP8(S)
+#undef S
+    }
+    asm volatile("s_mov_b64 exec, %0" : : "s"(ex));
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i] + G[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// v_exp_f32 issue cost
+__global__ void k_exp(float *out, float a, float b)
+{
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = (float)threadIdx.x * 1e-3f + i;
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_exp_f32 %0, %0" : "+v"(acc[i]));
+        REP8(S)
+#undef S
+    }
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 template <typename K>
 static void run(const char *name, K kern, int waves_per_simd, double insts_per_iter, double flops_per_lane_iter, float *out)
 {
@@ -144,7 +214,7 @@ static void run(const char *name, K kern, int waves_per_simd, double insts_per_i
     const double cyc = ms * 1e-3 * 2.4e9;                                     // at the 2.4 GHz peak clock
     const double per_simd_insts = (double)ITER * insts_per_iter * waves_per_simd;
     const double tflops = (double)grid * block * ITER * flops_per_lane_iter / (ms * 1e-3) / 1e12;
-    printf("%-16s waves/SIMD %d  %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at 2.4 GHz)  %7.1f TFLOP/s\n", name,
+    printf("%-26s waves/SIMD %d  %8.3f ms  %6.2f cycles per wave-instruction per SIMD (at 2.4 GHz)  %7.1f TFLOP/s\n", name,
            waves_per_simd, ms, cyc / per_simd_insts, tflops);
 }
 
@@ -160,6 +230,10 @@ int main()
         run("v_pk_add_f32", k_pk_add, w, 8, 16, out);
         run("recur scalar", k_recur_scalar, w, 24, 24, out);
         run("recur packed", k_recur_packed, w, 12, 24, out);
+        run("thr select (4 VALU+nop)", k_thr_select, w, 32, 8, out);
+        run("thr cmpx (3 VALU+SALU)", k_thr_cmpx, w, 24, 8, out);
+        run("thr cmpx, no restore", k_thr_cmpx_norestore, w, 24, 8, out);
+        run("v_exp_f32", k_exp, w, 8, 8, out);
     }
     return 0;
 }

@@ -88,6 +88,7 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     out["depths"] = out["depth_key"].view(np.float32)
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
+    out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
     out["inv"] = read(13, np.uint32, R)
     out["perm"] = perm_from_inv(out["inv"])
     # the reference's 64-bit sort keys, reconstructed: (tile << 32) | depth bits of the listed Gaussian
@@ -157,6 +158,7 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
     out["depth_key"] = read(10, np.uint32, P)
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
+    out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
     out["inv"] = read(13, np.uint32, R)
     out["perm"] = perm_from_inv(out["inv"])
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
@@ -212,13 +214,22 @@ def check_binning(h, o):
     tt = o["tiles_touched"].astype(np.int64)
     # depth order: stable argsort of the depth bits; culled Gaussians emit nothing so only visible order matters
     vis = tt > 0
+    # (with a depth hint only the visible prefix of order / offsets is written -- the host words then carry nvis;
+    # without one `order` is a full permutation, Gaussians that emit nothing sit wherever their key puts them)
+    nvis = int(vis.sum())
     order = h["order"].astype(np.int64)
-    assert np.array_equal(np.sort(order), np.arange(P))
-    ov = order[vis[order]]
     dk = o["depths"].view(np.uint32)
     ref_ov = np.nonzero(vis)[0][np.argsort(dk[vis], kind="stable")]
-    assert np.array_equal(ov, ref_ov), "depth order differs"
-    assert np.array_equal(h["offsets"].astype(np.int64), np.cumsum(tt[order]))
+    if int(h["host_words"][7]) != 0 or nvis == 0:
+        assert int(h["host_words"][7]) == nvis
+        ov = order[:nvis]
+        assert np.array_equal(ov, ref_ov), "depth order differs (hinted path)"
+        assert np.array_equal(h["offsets"][:nvis].astype(np.int64), np.cumsum(tt[ov]))
+    else:
+        assert np.array_equal(np.sort(order), np.arange(P))
+        ov = order[vis[order]]
+        assert np.array_equal(ov, ref_ov), "depth order differs"
+        assert np.array_equal(h["offsets"].astype(np.int64), np.cumsum(tt[order]))
     # per-Gaussian runs: same tiles in the same (y-major / x-minor) order as the reference's emission
     o_start = o["offsets"].astype(np.int64) - tt
     h_start = h["first"].astype(np.int64)

@@ -120,8 +120,9 @@ def test_large_sizes_properties(gpu):
     tiles = h1["tiles"].astype(np.int64)
     nz = rg[:, 1] > rg[:, 0]
     assert (tiles[rg[nz, 0]] == np.nonzero(nz)[0]).all() and (tiles[rg[nz, 1] - 1] == np.nonzero(nz)[0]).all()
-    assert h1["offsets"][-1] == R
-    assert (np.diff(h1["offsets"].astype(np.int64)) == h1["tiles_touched"][h1["order"]][1:]).all()
+    nvis = int((h1["tiles_touched"] > 0).sum())
+    assert h1["offsets"][nvis - 1] == R
+    assert (np.diff(h1["offsets"][:nvis].astype(np.int64)) == h1["tiles_touched"][h1["order"][:nvis]][1:]).all()
     # doubling the density doubles every alpha: pairs above the 1e-5 cut-off scale exactly, pairs in
     # [0.5e-5, 1e-5) newly pass it -> the image is >= 2x, by at most (list length) * 1e-5 per pixel
     d = h2["color"].astype(np.float64) - 2.0 * h1["color"].astype(np.float64)
