@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_reduce_kernel(const uint2 *_
 __global__ void __launch_bounds__(S2_THREADS) scan2_apply_kernel(const uint2 *__restrict__ ct, uint32_t nb,
                                                                  const uint2 *__restrict__ partial,
                                                                  uint32_t *__restrict__ incl_c, uint32_t *__restrict__ incl_t,
-                                                                 Ctrl *__restrict__ c)
+                                                                 Ctrl *__restrict__ c, uint32_t *__restrict__ mailbox, uint32_t seq)
 {
     __shared__ uint2 sh[S2_THREADS / 64];
     __shared__ uint2 wsum[S2_THREADS / 64];
@@ -265,7 +265,23 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_apply_kernel(const uint2 *__
     if (base + S2_IPT == nb) {
         c->nvis = oc.w;
         c->total = ot.w;
+        if (mailbox) {   // post the host-read words (the others were written by earlier kernels) straight to pinned host memory
+            mailbox[DW_TOTAL] = ot.w;
+            mailbox[DW_OVERFLOW] = c->overflow;
+            mailbox[DW_USER] = c->user;
+            mailbox[DW_PMAX] = c->pmax;
+            mailbox[DW_PNMAX] = c->pnmax;
+            mailbox[DW_NMAX] = c->nmax;
+            mailbox[DW_NNMAX] = c->nnmax;
+            mailbox[DW_NVIS] = oc.w;
+            __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
+}
+
+__global__ void __launch_bounds__(256) zero_kernel(uint4 *__restrict__ p, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // every visible key takes its slot: bucket base + ticket.  One 16-byte record {key, id, instances, bucket} per slot.
@@ -333,7 +349,7 @@ struct Temp {
         t.ct = b.take<unsigned long long>(nb);
         t.counts = reinterpret_cast<uint32_t *>(t.ct);
         t.partial = b.take<uint32_t>(P / 4096 + 2);
-        t.zero_bytes = b.off;
+        t.zero_bytes = b.offset_of_next();
         t.incl = b.take<uint32_t>(nb);
         t.incl_t = b.take<uint32_t>(nb);
         t.slot_key = b.take<uint32_t>(P);
@@ -352,8 +368,8 @@ struct Temp {
 inline int log_buckets(size_t P)
 {
     int l = 12;
-    while (l < 22 && ((size_t)1 << l) < P) ++l;   // ~1 bucket per key, 2^12 .. 2^22 buckets (a multiple of the scan tile)
-    return l;
+    while (l < 22 && ((size_t)4 << l) < P) ++l;   // 2-4 keys per bucket, 2^12 .. 2^22 buckets (a multiple of the scan tile):
+    return l;                                     // the counters have to be zeroed and scanned on every call
 }
 
 }  // namespace
@@ -370,7 +386,10 @@ int depth_order_prepare(void *temp, size_t temp_bytes, size_t P, hipStream_t s)
         set_error("depth_order_prepare: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
         return R2_ERR_INVALID;
     }
-    R2_HIP_TRY(hipMemsetAsync(temp, 0, t.zero_bytes, s));
+    // one launch (hipMemsetAsync splits a fill of this size into two ~5 us kernels); zero_bytes is a multiple of 128
+    const size_t n16 = t.zero_bytes / 16;
+    zero_kernel<<<dim3((unsigned)std::min<size_t>((n16 + 255) / 256, 2048)), dim3(256), 0, s>>>(reinterpret_cast<uint4 *>(temp), n16);
+    R2_HIP_TRY(hipGetLastError());
     return 0;
 }
 uint32_t *depth_order_words(void *temp, size_t P)
@@ -413,7 +432,7 @@ DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, uint32_t prod
     return DepthReg{t.ct, t.bt, t.wgmm, h};
 }
 
-int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, hipStream_t s)
+int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s)
 {
     const size_t nb = (size_t)1 << log_buckets(P);
     const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, nb);
@@ -421,7 +440,7 @@ int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, hi
     scan2_reduce_kernel<<<dim3(tiles + 1), dim3(S2_THREADS), 0, s>>>(reinterpret_cast<const uint2 *>(t.ct), (uint32_t)nb, t.partial2, t.ctrl,
                                                                       t.wgmm, producer_workgroups);
     scan2_apply_kernel<<<dim3(tiles), dim3(S2_THREADS), 0, s>>>(reinterpret_cast<const uint2 *>(t.ct), (uint32_t)nb, t.partial2, t.incl, t.incl_t,
-                                                                t.ctrl);
+                                                                t.ctrl, mailbox, seq);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -172,8 +172,8 @@ bool depth_hint_lookup(int which, size_t P, DepthHint *out);
 void depth_hint_update(int which, size_t P, const uint32_t words[DW_COUNT], bool overflowed);
 DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, uint32_t producer_workgroups);
 // after the producer kernel: dual prefix sum (-> DW_TOTAL, DW_NVIS, DW_OVERFLOW, key extrema are final after this launch
-// pair, so the host may start its read-back here) ...
-int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, hipStream_t s);
+// pair: its last workgroup posts all DW_COUNT words + seq to the host mailbox, see host_mailbox_arm) ...
+int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s);
 // ... then placement + ranking: order[j] (j < nvis) = ids in (key, id) order, offsets[j] = inclusive instance offsets
 int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
                             uint32_t *offsets, hipStream_t s);
@@ -199,6 +199,9 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
 int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
 int read_host_words_wait(uint32_t *out, int n);
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);
+// zero-copy variant: a kernel stores the words and then `seq` (release, system scope) at mailbox[15]; the host spins on it
+int host_mailbox_arm(uint32_t **mailbox /* device-visible pinned host memory, 16 words */, uint32_t *seq);
+int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s);

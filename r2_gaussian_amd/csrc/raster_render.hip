@@ -20,7 +20,7 @@
 //           moment row to scratch at its EMISSION index (recomputed from the Gaussian's tile rectangle; contiguous
 //           per Gaussian), which the geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
 //           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
-//           Workgroups are cut as 256 consecutive instances of the global sorted list: perfect balance.
+//           Workgroups (one wave each) are cut as 64 consecutive instances of the global sorted list: perfect balance.
 //           Waves that straddle many sparse tiles switch to a per-lane gather of dL/dpix instead of
 //           re-walking 256 pixels once per tile.
 //           The reference's n_contrib skip (RAS/backward.cu:523-525) only prunes pairs that failed the
@@ -312,6 +312,10 @@ __global__ void __launch_bounds__(256) raster_combine_kernel(
 constexpr int GT_STRIDE = 20;                       // floats per staged tile row (16 + pad: the two block rows of a
 constexpr int GT_TILE = TILE2D * GT_STRIDE + 4;     // tile and the tile slots land on different LDS banks)
 constexpr int MAX_WAVE_TILES = 3;
+// One wave per workgroup: the waves never synchronise with each other, and a wave that finishes early (few live blocks)
+// frees its slot and its 8 KB of LDS at once instead of waiting for its three siblings (-3 % kernel time).  Walking the
+// chunks with a grid-stride loop from a few resident workgroups per CU was measured too: no gain.
+constexpr int BWD_WAVES = 1, BWD_THREADS = 64 * BWD_WAVES;
 
 __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, float bdy, float cdy2, float g, float &r0,
                                               float &r1, float &r3)
@@ -407,23 +411,23 @@ __device__ __forceinline__ void tile_moments_gather(const float4 a, const float4
     }
 }
 
-__global__ void __launch_bounds__(256) raster_render_backward_kernel(
+__global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
     uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part, const uint32_t *__restrict__ thin_flag)
 {
     constexpr int NB = TILE2D / SUB2D;        // blocks per tile side (2)
     constexpr int NBLK = NB * NB;             // blocks per tile (4)
-    __shared__ float s_gt[4][MAX_WAVE_TILES * GT_TILE];   // dL/dpix of the wave's tiles
-    __shared__ float4 s_pa[4][64], s_pb[4][64];           // the wave's 64 instance records
-    __shared__ uint16_t s_q[4][64 * NBLK];                // item queue: (owner lane << 4) | (tile slot << 2) | block
-    __shared__ float4 s_r0[4][64];                        // moment rows of the current round of 64 items
-    __shared__ float2 s_r1[4][64];
+    __shared__ float s_gt[BWD_WAVES][MAX_WAVE_TILES * GT_TILE];   // dL/dpix of the wave's tiles
+    __shared__ float4 s_pa[BWD_WAVES][64], s_pb[BWD_WAVES][64];           // the wave's 64 instance records
+    __shared__ uint16_t s_q[BWD_WAVES][64 * NBLK];                // item queue: (owner lane << 4) | (tile slot << 2) | block
+    __shared__ float4 s_r0[BWD_WAVES][64];                        // moment rows of the current round of 64 items
+    __shared__ float2 s_r1[BWD_WAVES][64];
+    const bool scene_thin = *thin_flag != 0u;   // raised by the preprocess kernel (see row_tier)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
     if (chunk >= nchunks) return;
-    const bool scene_thin = *thin_flag != 0u;   // raised by the preprocess kernel (see row_tier)
-    const uint32_t k = chunk * 256u + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t k = chunk * (uint32_t)BWD_THREADS + threadIdx.x;
     const bool live = k < R;
     uint32_t tile = 0xffffffffu, id = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
@@ -578,10 +582,10 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
 {
     if (R == 0) return 0;
     const int gx = (W + TILE2D - 1) / TILE2D;
-    const uint32_t nchunks = (uint32_t)((R + 255) / 256);
+    const uint32_t nchunks = (uint32_t)((R + BWD_THREADS - 1) / BWD_THREADS);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
     const int gy = (H + TILE2D - 1) / TILE2D;
-    raster_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
+    raster_render_backward_kernel<<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
                                                                    nchunks, dL_dpix,
                                                                    reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
     return 0;

@@ -67,15 +67,16 @@ extern "C" int r2_voxel_forward(
     R2_STAGE_CHECK(debug, s, "preprocess");
     uint32_t hw[DW_COUNT] = { 0 };
     if (hinted) {
-        { StageScope t(ST_VOX_SCAN, s);
-        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)P, pre_wgs, s); }
+        uint32_t *mailbox = nullptr, mailbox_seq = 0;
+        rc = host_mailbox_arm(&mailbox, &mailbox_seq);
         if (rc) return rc;
-        rc = read_host_words_begin(host_words, DW_COUNT, s);
+        { StageScope t(ST_VOX_SCAN, s);
+        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)P, pre_wgs, mailbox, mailbox_seq, s); }
         if (rc) return rc;
         { StageScope t(ST_VOX_DEPTHSORT, s);
         rc = depth_order_fast_finish(geom.dorder_temp, (size_t)P, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
         if (rc) return rc;
-        rc = read_host_words_wait(hw, DW_COUNT);
+        rc = host_mailbox_wait(mailbox_seq, hw, DW_COUNT, s);   // the GPU places + ranks while the host waits for the words
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "depth order (hinted)");
     } else {
