@@ -53,8 +53,8 @@ def algorithmic_bytes(stage, P, R, T, N):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--detector", type=int, default=512)
     ap.add_argument("--views", type=int, default=50)

@@ -153,6 +153,9 @@ R2_API int r2_profile_read(double *total_ms, long long *counts, int reset);
 /* host time spent busy-waiting at the forward passes' synchronisation point (the D2H read of num_rendered), and the
  * number of such waits: long waits = GPU-bound, short waits = the host is the bottleneck. */
 R2_API int r2_sync_wait_stats(double *total_us, long long *calls, int reset);
+/* host time the forward passes spent before that wait (launching the first kernels) and after it (allocation callbacks +
+ * launching the rest), accumulated over `calls` forward passes */
+R2_API int r2_profile_host(double *pre_sync_us, double *post_sync_us, long long *calls, int reset);
 
 /* The forward passes order the Gaussians by depth with a bucket sort whose bucket boundaries follow the depth range seen
  * by the previous call with the same P (a per-thread hint: it saves five kernel launches and hides the num_rendered

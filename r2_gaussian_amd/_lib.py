@@ -37,6 +37,7 @@ _SIGNATURES = {
     "r2_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_sync_wait_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_depth_hint_control": (None, [_i]),
+    "r2_profile_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_raster_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, C.POINTER(C.c_int)]),
     "r2_voxel_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, _i, C.POINTER(C.c_int)]),
 }
@@ -100,6 +101,13 @@ def sync_wait_stats(reset=True):
     us, n = C.c_double(0.0), C.c_longlong(0)
     lib().r2_sync_wait_stats(C.byref(us), C.byref(n), int(reset))
     return us.value, n.value
+
+
+def profile_host(reset=True):
+    """-> (host microseconds per forward before its synchronisation wait, after it, number of forwards)."""
+    a, b, n = C.c_double(0.0), C.c_double(0.0), C.c_longlong(0)
+    lib().r2_profile_host(C.byref(a), C.byref(b), C.byref(n), int(reset))
+    return a.value / max(n.value, 1), b.value / max(n.value, 1), n.value
 
 
 def profile_read(reset=True):

@@ -59,6 +59,18 @@ void stage_end(int stage, hipStream_t s)
 
 static double g_sync_wait_us = 0.0;
 static long long g_sync_calls = 0;
+// host time of the forward passes around their synchronisation point (r2_profile_host)
+static double g_pre_sync_us = 0.0, g_post_sync_us = 0.0;
+static long long g_fwd_calls = 0;
+static thread_local std::chrono::steady_clock::time_point g_fwd_t0, g_fwd_t1;
+void host_mark_forward_begin() { g_fwd_t0 = std::chrono::steady_clock::now(); }
+void host_mark_wait_begin() { g_pre_sync_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_fwd_t0).count(); }
+void host_mark_wait_end() { g_fwd_t1 = std::chrono::steady_clock::now(); }
+void host_mark_forward_end()
+{
+    g_post_sync_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - g_fwd_t1).count();
+    g_fwd_calls += 1;
+}
 
 // pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the GPU is
 // idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency is on the
@@ -82,10 +94,12 @@ int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s)
 int read_host_words_wait(uint32_t *out, int n)
 {
     hipError_t q;
+    host_mark_wait_begin();
     const auto t0 = std::chrono::steady_clock::now();
     while ((q = hipEventQuery(g_read_ev)) == hipErrorNotReady) __builtin_ia32_pause();
     g_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     g_sync_calls += 1;
+    host_mark_wait_end();
     if (q != hipSuccess) {
         set_error("read_host_words: %s", hipGetErrorString(q));
         return -(int)q;
@@ -115,6 +129,7 @@ int host_mailbox_arm(uint32_t **mailbox, uint32_t *seq)
 
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
 {
+    host_mark_wait_begin();
     const auto t0 = std::chrono::steady_clock::now();
     volatile uint32_t *mb = g_mailbox;
     unsigned spins = 0;
@@ -138,6 +153,7 @@ int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
     }
     g_sync_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
     g_sync_calls += 1;
+    host_mark_wait_end();
     for (int i = 0; i < n; ++i) out[i] = mb[i];
     return 0;
 }
@@ -428,6 +444,7 @@ void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t ch
 }  // namespace r2
 
 extern "C" const char *r2_last_error(void) { return r2::get_error(); }
+
 extern "C" int r2_abi_version(void) { return R2_ABI_VERSION; }
 
 extern "C" int r2_sync_wait_stats(double *total_us, long long *calls, int reset)
@@ -435,6 +452,15 @@ extern "C" int r2_sync_wait_stats(double *total_us, long long *calls, int reset)
     if (total_us) *total_us = r2::g_sync_wait_us;
     if (calls) *calls = r2::g_sync_calls;
     if (reset) { r2::g_sync_wait_us = 0.0; r2::g_sync_calls = 0; }
+    return 0;
+}
+
+extern "C" int r2_profile_host(double *pre_sync_us, double *post_sync_us, long long *calls, int reset)
+{
+    if (pre_sync_us) *pre_sync_us = r2::g_pre_sync_us;
+    if (post_sync_us) *post_sync_us = r2::g_post_sync_us;
+    if (calls) *calls = r2::g_fwd_calls;
+    if (reset) { r2::g_pre_sync_us = r2::g_post_sync_us = 0.0; r2::g_fwd_calls = 0; }
     return 0;
 }
 

@@ -200,6 +200,9 @@ int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
 int read_host_words_wait(uint32_t *out, int n);
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);
 // zero-copy variant: a kernel stores the words and then `seq` (release, system scope) at mailbox[15]; the host spins on it
+// host-side timing of a forward pass around its synchronisation point (r2_profile_host)
+void host_mark_forward_begin();
+void host_mark_forward_end();
 int host_mailbox_arm(uint32_t **mailbox /* device-visible pinned host memory, 16 words */, uint32_t *seq);
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass

@@ -14,6 +14,7 @@ extern "C" int r2_raster_forward(
     (void)cam_pos;
     (void)prefiltered;   // the reference only uses it to trap on an impossible state (RAS/auxiliary.h:160-164)
     hipStream_t s = (hipStream_t)stream;
+    host_mark_forward_begin();
     if (P < 0 || width <= 0 || height <= 0 || !geometryBuffer || !binningBuffer || !imageBuffer || !out_color) {
         set_error("r2_raster_forward: invalid argument");
         return R2_ERR_INVALID;
@@ -156,6 +157,7 @@ extern "C" int r2_raster_forward(
     launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
                                  /*any_thin=*/hw[DW_USER] != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
+    host_mark_forward_end();
     return (int)num_rendered;
 }
 

@@ -431,11 +431,15 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
     const bool live = k < R;
     uint32_t tile = 0xffffffffu, id = 0;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    int rad = 0;
+    uint32_t first_row = 0;
     if (live) {
         tile = tiles[k];
         id = point_list[k];
         a = rec[2 * id];
         b = rec[2 * id + 1];
+        rad = radii[id];          // only needed for the final store's address: requested now, with the other gathers,
+        first_row = first[id];    // instead of as a fresh dependent round trip at the end of the wave's life
     }
     float S[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 
@@ -543,9 +547,9 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
         // kernel emits a Gaussian's tiles y-major / x-minor from `first`): a Gaussian's rows end up contiguous, so
         // the geometry backward streams them -- no permutation has to be carried through the sort
         int rx0, ry0, rx1, ry1;
-        tile_rect(a.x, a.y, radii[id], gx, gy, rx0, ry0, rx1, ry1);
+        tile_rect(a.x, a.y, rad, gx, gy, rx0, ry0, rx1, ry1);
         const int ttx = (int)(tile % (uint32_t)gx), tty = (int)(tile / (uint32_t)gx);
-        const size_t u = (size_t)first[id] + (size_t)((tty - ry0) * (rx1 - rx0) + (ttx - rx0));
+        const size_t u = (size_t)first_row + (size_t)((tty - ry0) * (rx1 - rx0) + (ttx - rx0));
         part[2 * u] = make_float4(S[0], S[1], S[2], S[3]);
         part[2 * u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }

@@ -26,6 +26,7 @@ extern "C" int r2_voxel_forward(
 {
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream;
+    host_mark_forward_begin();
     if (P < 0 || nVoxel_x <= 0 || nVoxel_y <= 0 || nVoxel_z <= 0 || !geometryBuffer || !binningBuffer ||
         !imageBuffer || !out_volume) {
         set_error("r2_voxel_forward: invalid argument");
@@ -148,6 +149,7 @@ extern "C" int r2_voxel_forward(
     { StageScope t(ST_VOX_RENDER_FWD, s);
     launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
+    host_mark_forward_end();
     return (int)num_rendered;
 }
 

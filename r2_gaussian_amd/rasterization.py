@@ -61,12 +61,17 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer,
                               imgBuffer)
         ctx.mark_non_differentiable(radii)
+        # the gradient slot of `radii` is never used: do not let autograd materialise a zero int tensor (one fill kernel
+        # per backward) for it
+        ctx.set_materialize_grads(False)
         return color, radii
 
     @staticmethod
     def backward(ctx, grad_out_color, _):
         rs = ctx.raster_settings
         means3D, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer, imgBuffer = ctx.saved_tensors
+        if grad_out_color is None:   # the image did not take part in the loss
+            return None, None, None, None, None, None, None
         args = (means3D, radii, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
                 rs.tanfovx, rs.tanfovy, grad_out_color, rs.campos, geomBuffer, ctx.num_rendered, binningBuffer,
                 imgBuffer, ctx.mode, rs.debug)

@@ -42,6 +42,7 @@ class _VoxelizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii_x, radii_y, radii_z, geomBuffer,
                               binningBuffer, imgBuffer)
         ctx.mark_non_differentiable(radii_x, radii_y, radii_z)
+        ctx.set_materialize_grads(False)   # no zero tensors for the unused radii gradient slots
         return fields, radii_x, radii_y, radii_z
 
     @staticmethod
@@ -49,6 +50,8 @@ class _VoxelizeGaussians(torch.autograd.Function):
         vs = ctx.voxel_settings
         (means3D, scales, rotations, cov3Ds_precomp, radii_x, radii_y, radii_z, geomBuffer, binningBuffer,
          imgBuffer) = ctx.saved_tensors
+        if grad_out_color is None:   # the volume did not take part in the loss
+            return None, None, None, None, None, None
         args = (means3D, radii_x, radii_y, radii_z, scales, rotations, vs.scale_modifier, cov3Ds_precomp,
                 grad_out_color, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, vs.nVoxel_x, vs.nVoxel_y,
                 vs.nVoxel_z, vs.sVoxel_x, vs.sVoxel_y, vs.sVoxel_z, vs.center_x, vs.center_y, vs.center_z, vs.debug)
