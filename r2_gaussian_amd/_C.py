@@ -5,11 +5,44 @@ SUB/rasterize_points.cu / SUB/voxelize_points.cu: it owns tensor allocation (out
 buffers, the three opaque uint8 state tensors handed to the kernels through allocation callbacks) and passes
 raw device pointers + the current HIP stream down.
 """
+import os
+
 import torch
 
 from . import _lib
 
 _F32 = torch.float32
+
+# The same torch boundary compiled (csrc/torch_shim.cpp -> _r2shim.so, built by r2_gaussian_amd.build): ~70 us less
+# interpreter time per training view than the ctypes path below.  Both drive the same libr2hip.so; R2_SHIM=0 forces ctypes.
+_SHIM = None
+_SHIM_TRIED = False
+
+
+def _shim():
+    """The compiled boundary, loaded on first use; None when it is not built, switched off, or an experiment library is
+    selected with R2HIP_LIB (the module is linked against the product libr2hip.so)."""
+    global _SHIM, _SHIM_TRIED
+    if not _SHIM_TRIED:
+        _SHIM_TRIED = True
+        here = os.path.dirname(os.path.abspath(__file__))
+        if (os.environ.get("R2_SHIM", "1") != "0" and not os.environ.get("R2HIP_LIB")
+                and os.path.exists(os.path.join(here, "_r2shim.so"))):
+            _lib.lib()   # load libr2hip.so first (and fail loudly if it is missing)
+            from . import _r2shim
+            _SHIM = _r2shim
+    return _SHIM
+
+
+def _raw_stream(dev):
+    return torch._C._cuda_getCurrentRawStream(dev.index if dev.index is not None else torch.cuda.current_device())
+
+
+def _shim_call(fn, *args):
+    try:
+        return fn(*args)
+    except RuntimeError as e:   # the library's error text, as the ctypes path raises it
+        raise _lib.R2HipError(str(e)) from None
 
 
 def _ptr(t):
@@ -123,6 +156,11 @@ def rasterize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    sh = _shim()
+    if sh is not None:
+        return _shim_call(sh.rasterize_gaussians, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                          viewmatrix, projmatrix, tan_fovx, tan_fovy, int(image_height), int(image_width), campos,
+                          bool(prefiltered), int(mode), bool(debug), _raw_stream(dev))
     P, H, W = means3D.shape[0], int(image_height), int(image_width)
     hk = _hooks(dev)
     if P == 0:   # SUB/rasterize_points.cu:58-70: zero image, no state
@@ -155,6 +193,11 @@ def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifi
     dL_drotations[P,4])  (SUB/rasterize_points.cu:99-164)."""
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    sh = _shim()
+    if sh is not None:
+        return _shim_call(sh.rasterize_gaussians_backward, means3D, radii, scales, rotations, scale_modifier,
+                          cov3D_precomp, viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, campos, geomBuffer,
+                          int(R), binningBuffer, imageBuffer, int(mode), bool(debug), _raw_stream(dev))
     P = means3D.shape[0]
     H, W = int(dL_dout_color.shape[1]), int(dL_dout_color.shape[2])
     # one allocation for all eight gradient arrays (25 floats per Gaussian), 16-byte rows first; the kernels write
@@ -210,6 +253,11 @@ def voxelize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov3
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    sh = _shim()
+    if sh is not None:
+        return _shim_call(sh.voxelize_gaussians, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                          int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y), float(sVoxel_z),
+                          float(center_x), float(center_y), float(center_z), bool(prefiltered), bool(debug), _raw_stream(dev))
     P = means3D.shape[0]
     nx, ny, nz = int(nVoxel_x), int(nVoxel_y), int(nVoxel_z)
     hk = _hooks(dev)
@@ -242,6 +290,12 @@ def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rota
     (SUB/voxelize_points.cu:102-167)."""
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    sh = _shim()
+    if sh is not None:
+        return _shim_call(sh.voxelize_gaussians_backward, means3D, radii_x, radii_y, radii_z, scales, rotations,
+                          scale_modifier, cov3D_precomp, dL_dout_color, geomBuffer, int(R), binningBuffer, imageBuffer,
+                          int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y), float(sVoxel_z),
+                          float(center_x), float(center_y), float(center_z), bool(debug), _raw_stream(dev))
     P = means3D.shape[0]
     flat = torch.empty(26 * P, dtype=_F32, device=dev)   # every row is written by the kernels (zeros where culled)
     cuts = [4, 3, 3, 6, 1, 6, 3]

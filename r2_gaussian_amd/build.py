@@ -93,7 +93,39 @@ def build(force=False, verbose=False, extra_flags=None, out=None):
     return LIB
 
 
+SHIM = os.path.join(HERE, "_r2shim.so")
+
+
+def build_shim(force=False, verbose=False):
+    """r2_gaussian_amd/_r2shim.so: the torch boundary (csrc/torch_shim.cpp) as a compiled pybind11 module, plain g++
+    against the installed torch headers, linked to libr2hip.so next to it.  Host code only (no GPU needed to build)."""
+    import sysconfig
+    import torch
+    from torch.utils import cpp_extension as ce
+    src = os.path.join(CSRC, "torch_shim.cpp")
+    hdr = os.path.join(HERE, "..", "include", "r2hip.h")
+    if not os.path.exists(LIB):
+        raise RuntimeError("build libr2hip.so first")
+    newest = max(os.path.getmtime(src), os.path.getmtime(hdr), os.path.getmtime(os.path.abspath(__file__)))
+    if not force and os.path.exists(SHIM) and os.path.getmtime(SHIM) >= newest:
+        return SHIM
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+           "-Wno-unused-function", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch.compiled_with_cxx11_abi()),
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-DTORCH_EXTENSION_NAME=_r2shim", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1"]
+    cmd += ["-I" + d for d in ce.include_paths()] + ["-I" + sysconfig.get_paths()["include"]]
+    cmd += [src, "-o", SHIM] + ["-L" + d for d in ce.library_paths()] + ["-Wl,-rpath," + d for d in ce.library_paths()]
+    cmd += ["-ltorch", "-ltorch_cpu", "-ltorch_python", "-lc10", "-L" + HERE, "-l:libr2hip.so", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("torch shim build failed:\n%s\n%s" % (" ".join(cmd), r.stderr[-8000:]))
+    if verbose:
+        print("built", SHIM)
+    return SHIM
+
+
 if __name__ == "__main__":
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
     outs = [a[len("--out="):] for a in sys.argv[1:] if a.startswith("--out=")]
     print(build(force="--force" in sys.argv, verbose=True, extra_flags=extra or None, out=outs[0] if outs else None))
+    if not extra and not outs:
+        print(build_shim(force="--force" in sys.argv, verbose=True))

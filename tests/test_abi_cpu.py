@@ -92,3 +92,19 @@ def test_product_does_not_import_the_oracle():
                     if re.search(r"^\s*(from|import)\s+oracle\b|r2_oracle|libr2oracle|oracle/_ref", txt, flags=re.M):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_compiled_torch_boundary_loads_and_refuses_cpu_tensors():
+    """_r2shim.so (csrc/torch_shim.cpp) is the compiled twin of _C.py's ctypes glue: it must import against the installed
+    torch, report the library's ABI version, and refuse CPU tensors like the ctypes path does."""
+    import torch
+    from r2_gaussian_amd import _C, _lib
+    sh = _C._shim()
+    if sh is None:
+        pytest.skip("_r2shim.so not built (python -m r2_gaussian_amd.build)")
+    assert sh.abi_version() == _lib.R2_ABI_VERSION
+    for name in ("rasterize_gaussians", "rasterize_gaussians_backward", "voxelize_gaussians", "voxelize_gaussians_backward"):
+        assert hasattr(sh, name)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sh.rasterize_gaussians(torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 3), torch.zeros(4, 4), 1.0,
+                               torch.Tensor([]), torch.eye(4), torch.eye(4), 1.0, 1.0, 8, 8, torch.zeros(3), False, 0, False, 0)
