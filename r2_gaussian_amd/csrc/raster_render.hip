@@ -21,8 +21,7 @@
 //           per Gaussian), which the geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
 //           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
 //           Workgroups (one wave each) are cut as 64 consecutive instances of the global sorted list: perfect balance.
-//           Waves that straddle many sparse tiles switch to a per-lane gather of dL/dpix instead of
-//           re-walking 256 pixels once per tile.
+//           Waves that straddle many sparse tiles (image borders) take their tiles three at a time.
 //           The reference's n_contrib skip (RAS/backward.cu:523-525) only prunes pairs that failed the
 //           forward tests; re-evaluating the tests prunes the same pairs, so n_contrib is not needed.
 #include "raster_state.hpp"
@@ -307,8 +306,10 @@ __global__ void __launch_bounds__(256) raster_combine_kernel(
 // A wave takes 64 consecutive instances, expands them into items through a small LDS queue (wave prefix sum of
 // the per-instance block counts), processes the queue 64 items at a time, and each instance then adds up the
 // moment rows of its own items in a fixed order -- still no atomics, still bit-reproducible.
-// dL/dpix of the (<= 3) tiles a wave touches is staged once in LDS; waves that straddle more tiles (sparse
-// image regions) gather dL/dpix per lane over the whole tile instead.
+// dL/dpix of the tiles a wave touches is staged in LDS, three tiles per pass (97 % of the waves touch one tile).  An
+// earlier version sent waves with more than three tiles through a per-lane whole-tile gather: only 0.3 % of the waves,
+// but each ran for ~25 us, and they belong to the sparse tiles at the END of the list -- a third of the kernel's time
+// was that tail (74 -> 50 us).
 constexpr int GT_STRIDE = 20;                       // floats per staged tile row (16 + pad: the two block rows of a
 constexpr int GT_TILE = TILE2D * GT_STRIDE + 4;     // tile and the tile slots land on different LDS banks)
 constexpr int MAX_WAVE_TILES = 3;
@@ -392,25 +393,6 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
     }
 }
 
-// whole-tile moments for a wave whose lanes sit in MANY different (sparse) tiles: every lane gathers the dL/dpix of
-// its own tile straight from memory, one pass for the whole wave instead of one pass per tile.
-__device__ __forceinline__ void tile_moments_gather(const float4 a, const float4 b, const float *__restrict__ dL, int W,
-                                                    int H, int x0, int y0, float *S)
-{
-    const float dx0 = a.x - (float)x0;
-    const float lthr = LOG2_ALPHA_MIN_2D - b.y;
-    const int nrows = min(TILE2D, H - y0), ncols = min(TILE2D, W - x0);
-    for (int r = 0; r < nrows; ++r) {
-        const float dy = a.y - (float)(y0 + r);
-        const float bdy = a.w * dy, cdy2 = (b.x * dy) * dy;
-        const float *__restrict__ row = dL + (size_t)(y0 + r) * W + x0;
-        float r0 = 0.f, r1 = 0.f, r3 = 0.f;
-        for (int c = 0; c < ncols; ++c) pixel_moments(a.z, lthr, dx0 - (float)c, bdy, cdy2, row[c], r0, r1, r3);
-        S[0] += r0; S[1] += r1; S[3] += r3;
-        S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
-    }
-}
-
 __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
@@ -447,13 +429,18 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
     const uint32_t prev_tile = __shfl_up(tile, 1);
     const unsigned long long heads = __ballot(live && (lane == 0 || tile != prev_tile));
     const int ntiles = __popcll(heads);
-    if (ntiles > MAX_WAVE_TILES) {
-        if (live) tile_moments_gather(a, b, dL_dpix, W, H, (int)(tile % gx) * TILE2D, (int)(tile / gx) * TILE2D, S);
-    } else if (ntiles > 0) {
+    const int my_slot = __popcll(heads & ((2ull << lane) - 1ull)) - 1;   // rank of this lane's tile among the heads
+    // The wave's tiles are handled MAX_WAVE_TILES at a time (nearly always one pass: 97 % of the waves sit inside a
+    // single tile list; waves over sparse border tiles, with up to 64 different tiles, take several cheap passes).
+    unsigned long long hh = heads;
+    for (int slot0 = 0; slot0 < ntiles; slot0 += MAX_WAVE_TILES) {
         float *gt = s_gt[wave];
-        // ---- stage dL/dpix of the wave's tiles: lane -> (row = lane/4, 4 columns), zero outside the image
-        unsigned long long hh = heads;
-        for (int slot = 0; slot < ntiles; ++slot) {
+        const int npass = min(MAX_WAVE_TILES, ntiles - slot0);
+        const bool mine = live && my_slot >= slot0 && my_slot < slot0 + npass;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the previous pass is done with the LDS buffers
+        // ---- stage dL/dpix of this pass's tiles: lane -> (row = lane/4, 4 columns), zero outside the image
+        for (int slot = 0; slot < npass; ++slot) {
             const int leader = __ffsll((long long)hh) - 1;
             hh &= hh - 1;
             const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
@@ -473,10 +460,10 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
             *reinterpret_cast<float4 *>(gt + slot * GT_TILE + (lane >> 2) * GT_STRIDE + (lane & 3) * 4) = v;
         }
         // ---- expand instances into block items
-        const int slot = __popcll(heads & ((2ull << lane) - 1ull)) - 1;   // rank of this lane's tile among the heads
+        const int slot = my_slot - slot0;
         const float tx0 = (float)((int)(tile % gx) * TILE2D), ty0 = (float)((int)(tile / gx) * TILE2D);
         uint32_t mask = 0;
-        if (live) {
+        if (mine) {
 #pragma unroll
             for (int q = 0; q < NBLK; ++q)
                 if (block_live(a.x, a.y, b.z, b.w, tx0 + (float)((q % NB) * SUB2D), ty0 + (float)((q / NB) * SUB2D), (float)SUB2D))
