@@ -317,6 +317,7 @@ constexpr int MAX_WAVE_TILES = 3;
 // frees its slot and its 8 KB of LDS at once instead of waiting for its three siblings (-3 % kernel time).  Walking the
 // chunks with a grid-stride loop from a few resident workgroups per CU was measured too: no gain.
 constexpr int BWD_WAVES = 1, BWD_THREADS = 64 * BWD_WAVES;
+constexpr int BWD_OCC = 4;   // waves per SIMD the kernel is compiled for (121 VGPRs with the pipeline registers)
 
 __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, float bdy, float cdy2, float g, float &r0,
                                               float &r1, float &r3)
@@ -393,7 +394,7 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
     }
 }
 
-__global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
+__global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
     uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part, const uint32_t *__restrict__ thin_flag)
@@ -407,57 +408,116 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
     __shared__ float2 s_r1[BWD_WAVES][64];
     const bool scene_thin = *thin_flag != 0u;   // raised by the preprocess kernel (see row_tier)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
-    if (chunk >= nchunks) return;
-    const uint32_t k = chunk * (uint32_t)BWD_THREADS + threadIdx.x;
-    const bool live = k < R;
-    uint32_t tile = 0xffffffffu, id = 0;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    int rad = 0;
-    uint32_t first_row = 0;
-    if (live) {
-        tile = tiles[k];
-        id = point_list[k];
+    float *const gt = s_gt[wave];
+
+    // ---- software pipeline over this wave's chunks (64 consecutive instances each, grid-stride).  A chunk needs two
+    // dependent rounds of loads before it can compute: (1) tile + Gaussian id of its instances, (2) the gathers those ids
+    // address (32-byte record, radius, first-instance index) and dL/dpix of its tiles.  With one chunk per wave those
+    // round trips were ~60 % of the wave's life and the occupancy (5 waves/SIMD) could not cover them.  Here round (1) of
+    // chunk i+2 and round (2) of chunk i+1 are in flight while chunk i computes; the loads are issued in the order in
+    // which they are consumed, because vmcnt retires in order.
+    const uint32_t nslots = ((nchunks + 7u) >> 3) << 3;
+    const uint32_t G = gridDim.x;
+    // All pipeline loads are BRANCH-FREE (clamped addresses; dead lanes carry valid-but-unused data and are masked where
+    // the data is consumed): hipcc only emits counted s_waitcnt vmcnt(N) for loads in straight-line code -- behind a
+    // per-lane branch it falls back to vmcnt(0), which would drain the whole pipeline at the first use.
+    auto load1 = [&](uint32_t v, uint32_t &tile, uint32_t &id, bool &live) {
+        const uint32_t chunk = v < nslots ? xcd_remap(v, nchunks) : nchunks;
+        const uint32_t k = chunk * 64u + (uint32_t)lane;
+        live = chunk < nchunks && k < R;
+        const uint32_t kc = min(k, R - 1u);
+        tile = tiles[kc];
+        id = point_list[kc];
+    };
+    auto load2 = [&](uint32_t id, float4 &a, float4 &b, int &rad, uint32_t &first_row) {
         a = rec[2 * id];
         b = rec[2 * id + 1];
-        rad = radii[id];          // only needed for the final store's address: requested now, with the other gathers,
-        first_row = first[id];    // instead of as a fresh dependent round trip at the end of the wave's life
-    }
-    float S[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+        rad = radii[id];          // only needed for the final store's address
+        first_row = first[id];
+    };
+    // dL/dpix of one tile: lane -> (row = lane/4, 4 columns), zero outside the image
+    const bool aligned = (W & 15) == 0;   // kernel-uniform: every tile column lies inside the image
+    auto load_tile = [&](uint32_t t) -> float4 {
+        const int tx0 = (int)(t % gx) * TILE2D, ty0 = (int)(t / gx) * TILE2D;
+        const int ry = ty0 + (lane >> 2), cx = tx0 + (lane & 3) * 4;
+        if (aligned)   // rows below the image are clamped here and zeroed by tile_row_ok() when the data is used
+            return *reinterpret_cast<const float4 *>(dL_dpix + (size_t)min(ry, H - 1) * W + cx);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ry < H) {
+            const float *__restrict__ src = dL_dpix + (size_t)ry * W + cx;
+            if (cx + 0 < W) v.x = src[0];
+            if (cx + 1 < W) v.y = src[1];
+            if (cx + 2 < W) v.z = src[2];
+            if (cx + 3 < W) v.w = src[3];
+        }
+        return v;
+    };
+    auto tile_row_ok = [&](uint32_t t) -> bool { return (int)(t / gx) * TILE2D + (lane >> 2) < H; };
 
-    // distinct tiles in this wave (the list is tile-sorted: count the run starts)
+    uint32_t tile, id, tile1, id1;
+    bool live, live1;
+    float4 a, b;
+    int rad;
+    uint32_t first_row;
+    load1(blockIdx.x, tile, id, live);
+    load1(blockIdx.x + G, tile1, id1, live1);
+    load2(id, a, b, rad, first_row);
+
+    for (uint32_t v = blockIdx.x; v < nslots; v += G) {
+    // distinct tiles in this chunk (the list is tile-sorted: count the run starts)
     const uint32_t prev_tile = __shfl_up(tile, 1);
     const unsigned long long heads = __ballot(live && (lane == 0 || tile != prev_tile));
     const int ntiles = __popcll(heads);
     const int my_slot = __popcll(heads & ((2ull << lane) - 1ull)) - 1;   // rank of this lane's tile among the heads
-    // The wave's tiles are handled MAX_WAVE_TILES at a time (nearly always one pass: 97 % of the waves sit inside a
-    // single tile list; waves over sparse border tiles, with up to 64 different tiles, take several cheap passes).
     unsigned long long hh = heads;
+    // (a) dL/dpix of the first pass's tiles, into registers
+    float4 stage[MAX_WAVE_TILES];
+    uint32_t stage_tile[MAX_WAVE_TILES];
+#pragma unroll
+    for (int slot = 0; slot < MAX_WAVE_TILES; ++slot) {
+        stage[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+        stage_tile[slot] = 0u;
+        if (slot < ntiles) {   // wave-uniform
+            const int leader = __ffsll((long long)hh) - 1;
+            hh &= hh - 1;
+            stage_tile[slot] = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
+            stage[slot] = load_tile(stage_tile[slot]);
+        }
+    }
+    // (b) round (1) of the chunk after next, (c) round (2) of the next chunk
+    uint32_t tile2, id2;
+    bool live2;
+    load1(v + 2u * G, tile2, id2, live2);
+    float4 a1, b1;
+    int rad1;
+    uint32_t first_row1;
+    load2(id1, a1, b1, rad1, first_row1);
+
+    float S[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    // The chunk's tiles are handled MAX_WAVE_TILES at a time (nearly always one pass: 97 % of the waves sit inside a
+    // single tile list; waves over sparse border tiles, with up to 64 different tiles, take several cheap passes).
     for (int slot0 = 0; slot0 < ntiles; slot0 += MAX_WAVE_TILES) {
-        float *gt = s_gt[wave];
         const int npass = min(MAX_WAVE_TILES, ntiles - slot0);
         const bool mine = live && my_slot >= slot0 && my_slot < slot0 + npass;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();   // the previous pass is done with the LDS buffers
-        // ---- stage dL/dpix of this pass's tiles: lane -> (row = lane/4, 4 columns), zero outside the image
-        for (int slot = 0; slot < npass; ++slot) {
-            const int leader = __ffsll((long long)hh) - 1;
-            hh &= hh - 1;
-            const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
-            const int tx0 = (int)(t % gx) * TILE2D, ty0 = (int)(t / gx) * TILE2D;
-            const int ry = ty0 + (lane >> 2), cx = tx0 + (lane & 3) * 4;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ry < H) {
-                const float *__restrict__ src = dL_dpix + (size_t)ry * W + cx;
-                if (cx + 3 < W && (W & 3) == 0) v = *reinterpret_cast<const float4 *>(src);
-                else {
-                    if (cx + 0 < W) v.x = src[0];
-                    if (cx + 1 < W) v.y = src[1];
-                    if (cx + 2 < W) v.z = src[2];
-                    if (cx + 3 < W) v.w = src[3];
+        __builtin_amdgcn_wave_barrier();   // the previous pass / chunk is done with the LDS buffers
+        // ---- stage dL/dpix of this pass's tiles
+        if (slot0 == 0) {
+#pragma unroll
+            for (int slot = 0; slot < MAX_WAVE_TILES; ++slot)
+                if (slot < npass) {
+                    const float4 tv = (!aligned || tile_row_ok(stage_tile[slot])) ? stage[slot] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4 *>(gt + slot * GT_TILE + (lane >> 2) * GT_STRIDE + (lane & 3) * 4) = tv;
                 }
+        } else {   // further passes of a chunk over sparse border tiles: loaded on demand
+            for (int slot = 0; slot < npass; ++slot) {
+                const int leader = __ffsll((long long)hh) - 1;
+                hh &= hh - 1;
+                const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
+                float4 tv = load_tile(t);
+                if (aligned && !tile_row_ok(t)) tv = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(gt + slot * GT_TILE + (lane >> 2) * GT_STRIDE + (lane & 3) * 4) = tv;
             }
-            *reinterpret_cast<float4 *>(gt + slot * GT_TILE + (lane >> 2) * GT_STRIDE + (lane & 3) * 4) = v;
         }
         // ---- expand instances into block items
         const int slot = my_slot - slot0;
@@ -540,6 +600,11 @@ __global__ void __launch_bounds__(BWD_THREADS, 5) raster_render_backward_kernel(
         part[2 * u] = make_float4(S[0], S[1], S[2], S[3]);
         part[2 * u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
+    // rotate the pipeline registers
+    tile = tile1; id = id1; live = live1;
+    tile1 = tile2; id1 = id2; live1 = live2;
+    a = a1; b = b1; rad = rad1; first_row = first_row1;
+    }   // chunk loop
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
@@ -574,7 +639,19 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     if (R == 0) return 0;
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + BWD_THREADS - 1) / BWD_THREADS);
-    const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
+    // Grid = a whole number of "rounds" of resident waves (CUs x 4 SIMDs x BWD_OCC); the chunks beyond it are second chunks
+    // of the first waves (pipelined, see the kernel).  Chunks cost about the same, so with one wave per chunk the last,
+    // partly filled round ran at low occupancy for a full wave lifetime: 18068 chunks on 4096 slots = 4.4 rounds took as
+    // long as 5 (69 us); 4 full rounds + 1684 second chunks take 58 us.
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    const uint32_t slots = (uint32_t)cus * 4u * (uint32_t)BWD_OCC;   // a multiple of 8 (XCD-aware chunk order)
+    const uint32_t nslots = ((nchunks + 7u) >> 3) << 3;
+    const uint32_t grid = (nslots <= slots || (slots & 7u)) ? nslots : (nslots / slots) * slots;
     const int gy = (H + TILE2D - 1) / TILE2D;
     raster_render_backward_kernel<<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
                                                                    nchunks, dL_dpix,
