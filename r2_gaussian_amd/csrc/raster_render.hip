@@ -184,15 +184,27 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 
     // 64x64 transpose-reduction: after the step with partner distance d, acc[0..d) hold partial sums of the d pixels
     // whose index agrees with this lane's bits >= d; after d = 1, acc[0] is the block's pixel number `lane`.
+    // The two widest steps use gfx950's v_permlane32_swap / v_permlane16_swap: swapping the upper half (odd 16-lane rows)
+    // of acc[i] with the lower half (even rows) of acc[d + i] leaves, in every lane, exactly the two addends that lane
+    // keeps -- one instruction + one add per exchange instead of two selects, a ds_bpermute and an add.
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int i = 0; i < 32; ++i) {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[32 + i]), false, false);
+        acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[16 + i]), false, false);
+        acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) {
         const bool up = (lane & d) != 0;
 #pragma unroll
         for (int i = 0; i < d; ++i) {
             const float keep = up ? acc[d + i] : acc[i];
             const float send = up ? acc[i] : acc[d + i];
             acc[i] = keep + __shfl_xor(send, d);
-            if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // bound the exchange's register footprint
         }
     }
     const int ly = by + (lane >> 3), lx = bx + (lane & 7);

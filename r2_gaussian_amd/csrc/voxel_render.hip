@@ -204,15 +204,25 @@ __global__ void __launch_bounds__(256, 3) voxel_render_forward_kernel(
     // 64x64 transpose-reduction (see raster_render.hip): acc[0] ends up as the slab's voxel number `lane` = y*8 + z.
     // Skipped when the (short) list was handled entirely by the voxel-parallel tail -- most tiles at 256^3.
     if (stepped) {
+        // widest two steps: v_permlane32_swap / v_permlane16_swap (see raster_render.hip)
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
+        for (int i = 0; i < 32; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[32 + i]), false, false);
+            acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[16 + i]), false, false);
+            acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
             const bool up = (lane & d) != 0;
 #pragma unroll
             for (int i = 0; i < d; ++i) {
                 const float keep = up ? acc[d + i] : acc[i];
                 const float send = up ? acc[i] : acc[d + i];
                 acc[i] = keep + __shfl_xor(send, d);
-                if ((i & 7) == 7) __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
