@@ -300,10 +300,21 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     }
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
     // this Gaussian's rows are contiguous: the render backward stores each instance's row at its EMISSION index
-    for (uint32_t j = 0; j < ninst; ++j) {
-        const float4 m0 = part[2 * (size_t)(first + j)];
-        const float4 m1 = part[2 * (size_t)(first + j) + 1];
-        S0 += m0.x; S1 += m0.y; S2 += m0.z; S3 += m0.w; S4 += m1.x; S5 += m1.y;
+    // four rows per trip, all eight loads in flight before the first add (the adds keep the row order: bit-reproducible);
+    // the trip count of a wave is that of its widest Gaussian, so cutting it 4x cuts the wave's dependent round trips 4x
+    for (uint32_t j = 0; j < ninst; j += 4) {
+        float4 m0[4], m1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t row = (size_t)first + min(j + (uint32_t)i, ninst - 1u);   // clamped: branch-free loads
+            m0[i] = part[2 * row];
+            m1[i] = part[2 * row + 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (j + (uint32_t)i < ninst) {
+                S0 += m0[i].x; S1 += m0[i].y; S2 += m0[i].z; S3 += m0[i].w; S4 += m1[i].x; S5 += m1[i].y;
+            }
     }
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
     const float op = om.x, mu_f = om.y, opmu = op * mu_f;
