@@ -438,7 +438,7 @@ __global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *_
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
                             uint4 *work_tile, hipStream_t s)
 {
-    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, WorkListOut{ranges, chunk_base, work_tile, T, chunk});
+    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, WorkListOut{ranges, chunk_base, work_tile, T, chunk, nullptr});
 }
 
 }  // namespace r2

@@ -227,6 +227,9 @@ struct WorkListOut {
     uint32_t *chunk_base;
     uint4 *work;
     uint32_t T, chunk;
+    // optional (rasterizer, fused combine): per-tile arrival counters to zero, and EMPTY tiles appended to the work list as
+    // items {tile, 0, 0, 0} behind the real ones (somebody has to write their zeros); chunk_base[T + 1] = real + empty items
+    uint32_t *tile_done;
 };
 template <int NT>
 __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict__ counts, const WorkListOut wo)
@@ -262,6 +265,33 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
         __syncthreads();
     }
     if (tid == 0) wo.chunk_base[wo.T] = rw_carry2;
+    if (wo.tile_done == nullptr) return;
+    // second sweep: zero the arrival counters, append the empty tiles
+    const uint32_t nreal = rw_carry2;
+    __syncthreads();
+    if (tid == 0) rw_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < wo.T; base += NT) {
+        const uint32_t t = base + tid;
+        const uint32_t empty = (t < wo.T && counts[t] == 0u) ? 1u : 0u;
+        if (t < wo.T) wo.tile_done[t] = 0u;
+        uint32_t incl = empty;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) rw_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += rw_wsum[w];
+        const uint32_t pos = rw_carry + woff + incl - empty;
+        if (empty) wo.work[nreal + pos] = make_uint4(t, 0u, 0u, 0u);
+        __syncthreads();
+        if (tid == NT - 1) rw_carry = pos + empty;
+        __syncthreads();
+    }
+    if (tid == 0) wo.chunk_base[wo.T + 1] = nreal + rw_carry;
 }
 
 // XCD-aware remap of a linear block id: consecutive work items (neighbouring tiles / list chunks,

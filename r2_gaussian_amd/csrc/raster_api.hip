@@ -129,7 +129,8 @@ extern "C" int r2_raster_forward(
         // id (-> point_list)
         { StageScope t(ST_RAS_SORT, s);
         if (sort_is_single_pass(bit)) {
-            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK};
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK,
+                                 debug ? nullptr : img.tile_done};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           bin.inv, R, bit, &tile_counts, s, &wo);
             work_built = true;
@@ -155,7 +156,7 @@ extern "C" int r2_raster_forward(
     { StageScope t(ST_RAS_RENDER_FWD, s);
     // single-pass sort: the combine kernel (one workgroup per tile) also writes tiles[k] for the backward
     launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
-                                 /*any_thin=*/hw[DW_USER] != 0, s); }
+                                 /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     host_mark_forward_end();
     return (int)num_rendered;

@@ -102,18 +102,27 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
 
 // ANY4: the scene holds Gaussians that need the re-anchored recurrence (flag raised by the preprocess kernel, read by
 // the host at the forward's synchronisation point); scenes without them run the variant without re-anchoring code.
-template <bool ANY4>
+// FUSED: the work item that is the LAST of its tile to finish adds the tile's partial images in list order and writes the
+// image (and the backward's per-instance tile ids), instead of a separate combine launch; empty tiles are extra work items
+// {tile, 0, 0, 0} that just write zeros.
+template <bool ANY4, bool FUSED>
 __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
-    float *__restrict__ partial)
+    float *__restrict__ partial, uint32_t *__restrict__ tile_done, float *__restrict__ out_color, int W, int H,
+    uint32_t *__restrict__ tiles)
 {
     const uint32_t w = blockIdx.x;
-    if (w >= chunk_base[T]) return;
+    if (w >= chunk_base[FUSED ? T + 1 : T]) return;
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (FUSED && wd.w == 0u) {   // empty tile
+        const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
+        if (px < W && py < H) out_color[py * W + px] = 0.f;
+        return;
+    }
     const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;             // this wave's block inside the tile
     const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -208,7 +217,39 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
         }
     }
     const int ly = by + (lane >> 3), lx = bx + (lane & 7);
-    partial[(size_t)w * 256 + (ly * TILE2D + lx)] = acc[0];
+    if (!FUSED) {
+        partial[(size_t)w * 256 + (ly * TILE2D + lx)] = acc[0];
+        return;
+    }
+    if (wd.w == 1u) {   // the tile's only work item: the image pixel itself
+        const int px = tx * TILE2D + lx, py = ty * TILE2D + ly;
+        if (px < W && py < H) out_color[py * W + px] = acc[0];
+        if (tiles)
+            for (uint32_t k = beg + (uint32_t)tid; k < end; k += 256u) tiles[k] = tile;
+        return;
+    }
+    // The partial image travels between workgroups on different XCDs (non-coherent L2s).  A release/acquire fence pair
+    // would do it, but at agent scope a release is a write-back of the XCD's whole L2 (buffer_wbl2) -- measured: the
+    // kernel went from 42 to 370 us.  Instead the partials themselves are written and read with agent-scope (sc1) atomic
+    // stores / loads, which go past the L2s; a store that has been acknowledged (vmcnt) is visible device-wide, so the
+    // arrival counter needs no fence.
+    __hip_atomic_store(&partial[(size_t)w * 256 + (ly * TILE2D + lx)], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ uint32_t s_arrived;
+    if (tid == 0) s_arrived = atomicAdd(&tile_done[tile], 1u);
+    __syncthreads();
+    if (s_arrived != wd.w - 1u) return;
+    const uint32_t w0 = chunk_base[tile];
+    float C = 0.f;
+    for (uint32_t i = 0; i < wd.w; ++i)   // list order: deterministic image
+        C += __hip_atomic_load(&partial[(size_t)(w0 + i) * 256 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
+    if (px < W && py < H) out_color[py * W + px] = C;
+    if (tiles) {
+        const uint2 rg = ranges[tile];
+        for (uint32_t k = rg.x + (uint32_t)tid; k < rg.y; k += 256u) tiles[k] = tile;
+    }
 }
 
 // Debug-mode kernel (pixel-parallel): also tracks n_contrib (RAS/forward.cu:381,391), which only `debug` callers read
@@ -621,20 +662,33 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
 
 // ------------------------------------------------------------------------------------------------ launchers
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, hipStream_t s)
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
+                                 hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy;
+    if (fused_combine && !write_ncontrib && im.NW > 0) {
+        // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
+        if (any_thin)
+            raster_render_forward_kernel<true, true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles);
+        else
+            raster_render_forward_kernel<false, true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles);
+        return 0;
+    }
     if (im.NW > 0) {
         if (write_ncontrib)
             raster_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
         else if (any_thin)
-            raster_render_forward_kernel<true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial);
+            raster_render_forward_kernel<true, false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, nullptr, nullptr, W, H, nullptr);
         else
-            raster_render_forward_kernel<false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial);
+            raster_render_forward_kernel<false, false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, nullptr, nullptr, W, H, nullptr);
     }
     if (write_ncontrib)
         raster_combine_kernel<true><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,

@@ -124,7 +124,9 @@ struct RasterBinning {
 
 struct RasterImage {
     uint2 *ranges;         // [T]
-    uint32_t *chunk_base;  // [T+1] exclusive scan of ceil(len/FWD_CHUNK): first work item of each tile; [T] = total
+    uint32_t *chunk_base;  // [T+2] exclusive scan of ceil(len/FWD_CHUNK): first work item of each tile; [T] = total,
+                           //       [T+1] = total + empty tiles (appended to the work list when the combine is fused)
+    uint32_t *tile_done;   // [T]  work items of the tile that have stored their partial image (fused combine)
     uint4 *work_tile;      // [NW]  tile of each forward work item
     float *partial;        // [NW*256] per-work-item partial pixel sums, combined in list order
     uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
@@ -138,7 +140,8 @@ struct RasterImage {
         Bump b(chunk);
         s.NW = R / FWD_CHUNK + T;
         s.ranges = b.take<uint2>(T);
-        s.chunk_base = b.take<uint32_t>(T + 1);
+        s.chunk_base = b.take<uint32_t>(T + 2);
+        s.tile_done = b.take<uint32_t>(T);
         s.work_tile = b.take<uint4>(s.NW);
         s.partial = b.take<float>(s.NW * 256);
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
@@ -165,7 +168,8 @@ int launch_raster_geom_backward(int P, const float *means3D, const int *radii, c
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s);
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, hipStream_t s);
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
+                                 hipStream_t s);
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 
