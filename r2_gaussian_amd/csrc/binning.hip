@@ -347,7 +347,7 @@ int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_
 // work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
 __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
                                                           uint32_t *__restrict__ chunk_base,
-                                                          uint4 *__restrict__ work_tile)
+                                                          uint4 *__restrict__ work_tile, uint32_t min_len)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry;
@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
         uint32_t n = 0;
         if (t < T) {
             const uint2 r = ranges[t];
-            n = (r.y - r.x + chunk - 1) / chunk;
+            n = (r.y - r.x) < min_len ? 0u : (r.y - r.x + chunk - 1) / chunk;
         }
         // inclusive scan inside the wave, then across the 16 waves
         uint32_t incl = n;
@@ -389,12 +389,12 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
 // many tiles (256^3 volume: 32768): the same in three parallel steps -- per-tile work item counts, their prefix sum
 // (own scan above), then every tile writes its base and its work items
 __global__ void __launch_bounds__(256) work_count_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
-                                                         uint32_t *__restrict__ nw)
+                                                         uint32_t *__restrict__ nw, uint32_t min_len)
 {
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= T) return;
     const uint2 r = ranges[t];
-    nw[t] = (r.y - r.x + chunk - 1) / chunk;
+    nw[t] = (r.y - r.x) < min_len ? 0u : (r.y - r.x + chunk - 1) / chunk;
 }
 __global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict__ ranges, uint32_t chunk,
                                                         const uint32_t *__restrict__ nw, const uint32_t *__restrict__ incl,
@@ -414,15 +414,15 @@ __global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict_
 size_t build_work_temp_bytes(size_t T) { return T > 4096 ? sizeof(uint32_t) * 2 * T + scan_temp_bytes((int)T) + 256 : 0; }
 
 void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
-                       void *temp, hipStream_t s)
+                       void *temp, hipStream_t s, uint32_t min_len)
 {
     if (T <= 4096 || temp == nullptr) {
-        build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile);
+        build_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(ranges, T, chunk, chunk_base, work_tile, min_len);
         return;
     }
     uint32_t *nw = reinterpret_cast<uint32_t *>(temp), *incl = nw + T;
     void *scan_tmp = incl + T;
-    work_count_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ranges, T, chunk, nw);
+    work_count_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ranges, T, chunk, nw, min_len);
     (void)inclusive_scan_u32(scan_tmp, scan_temp_bytes((int)T), nw, incl, (int)T, s);
     work_fill_kernel<<<dim3((T + 255) / 256), dim3(256), 0, s>>>(ranges, chunk, nw, incl, T, chunk_base, work_tile);
 }
@@ -436,9 +436,9 @@ __global__ void __launch_bounds__(1024) ranges_and_work_kernel(const uint32_t *_
 }
 
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
-                            uint4 *work_tile, hipStream_t s)
+                            uint4 *work_tile, hipStream_t s, uint32_t min_len)
 {
-    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, WorkListOut{ranges, chunk_base, work_tile, T, chunk, nullptr});
+    ranges_and_work_kernel<<<dim3(1), dim3(1024), 0, s>>>(tile_counts, WorkListOut{ranges, chunk_base, work_tile, T, chunk, nullptr, min_len});
 }
 
 }  // namespace r2

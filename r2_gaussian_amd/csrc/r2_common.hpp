@@ -213,10 +213,11 @@ uint32_t higher_msb(uint32_t n);
 size_t build_work_temp_bytes(size_t T);
 // work_tile[w] = {tile, first instance, one past the last instance, work items of that tile}
 void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
-                       void *temp /* build_work_temp_bytes(T) bytes, may be null for T <= 4096 */, hipStream_t s);
+                       void *temp /* build_work_temp_bytes(T) bytes, may be null for T <= 4096 */, hipStream_t s,
+                       uint32_t min_len = 0 /* tiles with fewer instances get no work item */);
 // same, but the tile ranges themselves are derived from the per-tile instance counts of a single-pass tile sort
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
-                            uint4 *work_tile, hipStream_t s);
+                            uint4 *work_tile, hipStream_t s, uint32_t min_len = 0);
 
 // Tile ranges + forward work list from the per-tile instance counts, by ONE workgroup of NT threads (T <= 4096):
 // ranges[t] = exclusive scan of counts (empty tiles keep (0,0) like the reference's memset), chunk_base[t] = exclusive
@@ -230,6 +231,8 @@ struct WorkListOut {
     // optional (rasterizer, fused combine): per-tile arrival counters to zero, and EMPTY tiles appended to the work list as
     // items {tile, 0, 0, 0} behind the real ones (somebody has to write their zeros); chunk_base[T + 1] = real + empty items
     uint32_t *tile_done;
+    // optional (voxelizer): tiles with fewer than min_len instances get NO work item (a light kernel renders them)
+    uint32_t min_len;
 };
 template <int NT>
 __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict__ counts, const WorkListOut wo)
@@ -242,7 +245,7 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
     for (uint32_t base = 0; base < wo.T; base += NT) {
         const uint32_t t = base + tid;
         const uint32_t c = t < wo.T ? counts[t] : 0u;
-        const uint32_t nw = (c + wo.chunk - 1) / wo.chunk;
+        const uint32_t nw = c < wo.min_len ? 0u : (c + wo.chunk - 1) / wo.chunk;
         uint32_t incl = c, incl2 = nw;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

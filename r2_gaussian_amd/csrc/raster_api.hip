@@ -130,7 +130,7 @@ extern "C" int r2_raster_forward(
         { StageScope t(ST_RAS_SORT, s);
         if (sort_is_single_pass(bit)) {
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK,
-                                 debug ? nullptr : img.tile_done};
+                                 debug ? nullptr : img.tile_done, 0u};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           bin.inv, R, bit, &tile_counts, s, &wo);
             work_built = true;

@@ -236,6 +236,64 @@ __global__ void __launch_bounds__(256, 3) voxel_render_forward_kernel(
     }
 }
 
+// Short tile lists (fewer than VFWD_MIN_STEP entries: 71 % of the non-empty tiles of a 256^3 query, 3 % of the instances).
+// They get no work item of the kernel above (launch_build_work(min_len)); here ONE WAVE renders a whole tile with no
+// accumulators and no LDS: lane j gathers entry j's record, the wave then takes the entries in list order, pulls an
+// entry's 16 scalars out of lane j with v_readlane (-> SGPRs), tests each of the 8 x-slabs (wave-uniform) and evaluates
+// the live ones voxel-parallel (lane = voxel y*8+z).  ~45 VGPRs, so 8 waves/SIMD cover the range -> ids -> records
+// round trips that dominated when these tiles went through the item kernel (they cost 150 of its 680 us).
+__device__ __forceinline__ float lane_bcast(float x, int j)
+{
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), j));
+}
+__global__ void __launch_bounds__(256) voxel_render_short_kernel(
+    const uint2 *__restrict__ ranges, uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+    const float4 *__restrict__ ext, VoxelGrid v, float *__restrict__ out)
+{
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (tile >= T) return;
+    const uint2 rg = ranges[tile];
+    const int n = (int)(rg.y - rg.x);
+    if (n == 0 || n >= VFWD_MIN_STEP) return;   // empty: the combine kernel writes zeros; long: the item kernel
+    const int lane = threadIdx.x & 63;
+    const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
+    const float y0 = (float)(ty * TILE3D), z0 = (float)(tz * TILE3D);
+    float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = ep, eh = ep;
+    if (lane < n) {
+        const uint32_t id = point_list[rg.x + (uint32_t)lane];
+        ep = rec[3 * id]; eq = rec[3 * id + 1]; er = rec[3 * id + 2]; eh = ext[id];
+    }
+    const float vy = y0 + (float)(lane >> 3) + 0.5f, vz = z0 + (float)(lane & 7) + 0.5f;
+    float sum[TILE3D];
+#pragma unroll
+    for (int sl = 0; sl < TILE3D; ++sl) sum[sl] = 0.f;
+    for (int j = 0; j < n; ++j) {
+        const float4 p = make_float4(lane_bcast(ep.x, j), lane_bcast(ep.y, j), lane_bcast(ep.z, j), 0.f);
+        const float4 q = make_float4(lane_bcast(eq.x, j), lane_bcast(eq.y, j), lane_bcast(eq.z, j), lane_bcast(eq.w, j));
+        const float4 r = make_float4(lane_bcast(er.x, j), lane_bcast(er.y, j), lane_bcast(er.z, j), 0.f);
+        const float4 h = make_float4(lane_bcast(eh.x, j), lane_bcast(eh.y, j), lane_bcast(eh.z, j), 0.f);
+        const float dy = p.y - vy, dz = p.z - vz;
+        const float kyz = dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
+        const float kx = q.y * dy + q.z * dz;
+#pragma unroll
+        for (int sl = 0; sl < TILE3D; ++sl) {
+            const float xs = (float)(tx * TILE3D + sl) + 0.5f;
+            if (!slab_live(p.x, p.y, p.z, h, xs, y0, z0)) continue;   // wave-uniform (scalar operands)
+            const float dx = p.x - xs;
+            // same expression tree as the item kernel's voxel-parallel paths
+            const float pl = dx * (q.x * dx + kx) + kyz;
+            const float al = __builtin_amdgcn_exp2f(pl);
+            sum[sl] += ((pl <= r.z) && (al >= ALPHA_MIN_3D)) ? al : 0.f;
+        }
+    }
+    const int oy = ty * TILE3D + (lane >> 3), oz = tz * TILE3D + (lane & 7);
+#pragma unroll
+    for (int sl = 0; sl < TILE3D; ++sl) {
+        const int ox = tx * TILE3D + sl;
+        if (ox < v.nx && oy < v.ny && oz < v.nz) out[((size_t)ox * v.ny + oy) * v.nz + oz] = sum[sl];
+    }
+}
+
 // Debug-mode kernel (voxel-parallel): also tracks n_contrib, which only `debug` callers read back.
 __global__ void __launch_bounds__(512) voxel_render_forward_debug_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
@@ -291,9 +349,14 @@ __global__ void __launch_bounds__(512) voxel_render_forward_debug_kernel(
 template <bool NCONTRIB>
 __global__ void __launch_bounds__(512) voxel_combine_kernel(
     const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial,
-    const uint32_t *__restrict__ partial_last, VoxelGrid v, float *__restrict__ out, uint32_t *__restrict__ n_contrib)
+    const uint32_t *__restrict__ partial_last, VoxelGrid v, float *__restrict__ out, uint32_t *__restrict__ n_contrib,
+    const uint2 *__restrict__ ranges, uint32_t short_min)
 {
     const uint32_t tile = blockIdx.x;
+    if (!NCONTRIB && short_min) {   // tiles with a short list were rendered by voxel_render_short_kernel
+        const uint2 rg = ranges[tile];
+        if (rg.y != rg.x && rg.y - rg.x < short_min) return;
+    }
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x;
     const int vx = tx * TILE3D + (tid >> 6), vy = ty * TILE3D + ((tid >> 3) & 7), vz = tz * TILE3D + (tid & 7);
@@ -465,23 +528,27 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
                                 float *out_volume, bool write_ncontrib, hipStream_t s)
 {
     const uint32_t T = (uint32_t)v.gx * v.gy * v.gz;
-    if (im.NW > 0) {
-        if (write_ncontrib)
+    if (write_ncontrib) {
+        if (im.NW > 0)
             voxel_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, v, im.partial, im.partial_last);
-        else
-            // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
-            voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+        voxel_combine_kernel<true><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
+                                                                 im.n_contrib, im.ranges, 0u);
+        return 0;
     }
-    if (write_ncontrib)
-        voxel_combine_kernel<true><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v,
-                                                                 out_volume, im.n_contrib);
-    else
-        voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v,
-                                                                  out_volume, im.n_contrib);
+    if (im.NW > 0) {
+        // short lists: one wave per tile (the work list holds no item for them, see voxel_short_list_min())
+        voxel_render_short_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(im.ranges, T, b.point_list, g.rec, g.ext, v, out_volume);
+        // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
+        voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
+            im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+    }
+    voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
+                                                              im.n_contrib, im.ranges, im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u);
     return 0;
 }
+
+uint32_t voxel_short_list_min(bool debug) { return debug ? 0u : (uint32_t)VFWD_MIN_STEP; }
 
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
                                  const float *dL_dvol, hipStream_t s)

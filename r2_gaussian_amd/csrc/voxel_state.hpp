@@ -139,6 +139,8 @@ int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, co
                                float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D, float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s);
+// tile lists shorter than this get no forward work item (a light kernel renders them); 0 in debug mode
+uint32_t voxel_short_list_min(bool debug);
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,
                                 float *out_volume, bool write_ncontrib, hipStream_t s);
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
