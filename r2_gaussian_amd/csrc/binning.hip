@@ -273,16 +273,6 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
     return 0;
 }
 
-int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
-                                hipStream_t s, uint32_t *total_out)
-{
-    if (P <= 0) return 0;
-    const uint32_t tiles = (uint32_t)((P + SC_TILE - 1) / SC_TILE);
-    scan_apply_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(in, order, (uint32_t)P, partial, out, total_out);
-    R2_HIP_TRY(hipGetLastError());
-    return 0;
-}
-
 int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s)
 {
     return inclusive_scan_gather_u32(temp, temp_bytes, in, nullptr, out, P, s, nullptr);
@@ -331,18 +321,6 @@ int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipSt
     if (T > 0) fill_tiles_kernel<<<dim3((unsigned)T), dim3(256), 0, s>>>(ranges, tiles);
     return 0;
 }
-__global__ void __launch_bounds__(256) invert_permutation_kernel(const uint32_t *__restrict__ perm, uint32_t *__restrict__ inv,
-                                                                 uint32_t n)
-{
-    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
-    if (k < n) inv[perm[k]] = k;
-}
-int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_t s)
-{
-    if (n > 0) invert_permutation_kernel<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(perm, inv, (uint32_t)n);
-    return 0;
-}
-
 // The tile lists are cut into work items of `chunk` instances for the render kernels (load balance).
 // work list: tile t owns work items [chunk_base[t], chunk_base[t+1]).  One workgroup, T is small (<= 2^20).
 __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,

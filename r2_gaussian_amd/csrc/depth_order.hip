@@ -101,12 +101,19 @@ __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__res
                                                            uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t k = keys[i];
-    if (k == CULLED_KEY) {
-        order[n - 1u - atomicAdd(&c->nculled, 1u)] = i;   // tail, any order: culled Gaussians emit nothing
-        return;
+    const uint32_t k = i < n ? keys[i] : 0u;
+    // culled Gaussians go to the tail in any order (they emit nothing); ONE ticket atomic per wave -- same-address atomics
+    // retire at ~90 per microsecond, a scene with 100 k culled Gaussians would otherwise spend a millisecond here
+    const bool culled = i < n && k == CULLED_KEY;
+    const unsigned long long cm = __ballot(culled);
+    if (cm) {
+        const int lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == __ffsll((long long)cm) - 1) base = atomicAdd(&c->nculled, (uint32_t)__popcll(cm));
+        base = __shfl(base, __ffsll((long long)cm) - 1);
+        if (culled) order[n - 1u - (base + (uint32_t)__popcll(cm & ((1ull << lane) - 1ull)))] = i;
     }
+    if (i >= n || culled) return;
     const uint32_t b = bucket_of(k, c, log_nb);
     const uint32_t v = atomicSub(&counts[b], 1u);          // v in [1, count]: a unique slot inside the bucket
     const uint32_t pos = incl[b] - v;
@@ -114,12 +121,9 @@ __global__ void __launch_bounds__(256) bucket_place_kernel(const uint32_t *__res
     slot_id[pos] = i;
 }
 
-// `weights` (optional): the rank kernel also accumulates sum(weights[id]) per 4096-position group of the final order
-// into `partial` -- the first half of the prefix sum the caller runs over weights[order[j]] next (scan_apply_only).
 __global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__restrict__ c, int log_nb,
                                                           const uint32_t *__restrict__ incl, const uint32_t *__restrict__ slot_key,
-                                                          const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order,
-                                                          const uint32_t *__restrict__ weights, uint32_t *__restrict__ partial)
+                                                          const uint32_t *__restrict__ slot_id, uint32_t *__restrict__ order)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t nvis = incl[nb - 1];
@@ -144,21 +148,6 @@ __global__ void __launch_bounds__(256) bucket_rank_kernel(uint32_t nb, Ctrl *__r
             fp = beg + rank;
         }
         order[fp] = id;
-    }
-    if (weights) {
-        // one atomic per wave when the wave's final positions share a group (nearly always: fp stays inside the bucket)
-        const uint32_t wgt = p < nvis ? weights[id] : 0u;
-        const uint32_t g = fp >> 12;
-        const unsigned long long livem = __ballot(p < nvis);
-        const uint32_t g0 = livem ? (uint32_t)__shfl(g, __ffsll((long long)livem) - 1) : 0u;   // group of the first live lane
-        if (__all(p >= nvis || g == g0)) {
-            uint32_t sum = wgt;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d);
-            if ((threadIdx.x & 63) == 0 && sum) atomicAdd(&partial[g0], sum);
-        } else if (p < nvis && wgt) {
-            atomicAdd(&partial[g], wgt);
-        }
     }
 }
 
@@ -328,9 +317,8 @@ __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, co
 
 struct Temp {
     Ctrl *ctrl;
-    uint32_t *counts;     // [nb]   un-hinted path (ctrl, counts / ct and partial are zeroed by one memset)
+    uint32_t *counts;     // [nb]   un-hinted path (ctrl and counts / ct are zeroed by one launch)
     unsigned long long *ct; // [nb] hinted path: (keys << 32) | instances per bucket; shares its memory with counts
-    uint32_t *partial;    // [P/4096 + 1] per-group weight sums of the final order (zeroed with the counts)
     uint32_t *incl;       // [nb]
     uint32_t *incl_t;     // [nb]   hinted path
     uint32_t *slot_key;   // [P]    un-hinted path
@@ -348,7 +336,6 @@ struct Temp {
         t.ctrl = b.take<Ctrl>(2);               // 128 bytes: keeps counts on the next 128-byte boundary
         t.ct = b.take<unsigned long long>(nb);
         t.counts = reinterpret_cast<uint32_t *>(t.ct);
-        t.partial = b.take<uint32_t>(P / 4096 + 2);
         t.zero_bytes = b.offset_of_next();
         t.incl = b.take<uint32_t>(nb);
         t.incl_t = b.take<uint32_t>(nb);
@@ -418,16 +405,14 @@ int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uin
     if (rc) return rc;
     bucket_place_kernel<<<dim3(grid), dim3(256), 0, s>>>(keys, (uint32_t)P, t.ctrl, log_nb, t.counts, t.incl, t.slot_key,
                                                          t.slot_id, order);
-    bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, log_nb, t.incl, t.slot_key, t.slot_id, order,
-                                                        nullptr, t.partial);
+    bucket_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)nb, t.ctrl, log_nb, t.incl, t.slot_key, t.slot_id, order);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }
 
 // ---- hinted path, host side
-DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, uint32_t producer_workgroups)
+DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h)
 {
-    (void)producer_workgroups;
     const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P));
     return DepthReg{t.ct, t.bt, t.wgmm, h};
 }

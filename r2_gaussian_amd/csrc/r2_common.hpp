@@ -84,8 +84,6 @@ size_t sort_temp_bytes(size_t n);
 int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin, uint32_t *vout,
                   const uint32_t *win, uint32_t *wout, size_t n, int end_bit, bool allow_skip, const uint32_t **totals_out,
                   hipStream_t s, uint32_t *inv_out = nullptr /* with win and no skipping: inv_out[value] = position */);
-int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                       uint32_t *vout, size_t n, int end_bit, hipStream_t s);
 // inclusive scan of in[order[j]] over j (the per-Gaussian tile counts visited in depth order)
 // depth_order.hip: ids in (key, id) order by a one-level bucket sort.  depth_order_prepare zeroes the control block + counters
 // and is called BEFORE the kernel that produces the keys (which may set the DW_USER word); depth_order_buckets is the
@@ -170,16 +168,13 @@ uint32_t *depth_order_words(void *temp, size_t P);
 // call, P changed, hints switched off): the caller then runs the un-hinted path.
 bool depth_hint_lookup(int which, size_t P, DepthHint *out);
 void depth_hint_update(int which, size_t P, const uint32_t words[DW_COUNT], bool overflowed);
-DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, uint32_t producer_workgroups);
+DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h);
 // after the producer kernel: dual prefix sum (-> DW_TOTAL, DW_NVIS, DW_OVERFLOW, key extrema are final after this launch
 // pair: its last workgroup posts all DW_COUNT words + seq to the host mailbox, see host_mailbox_arm) ...
 int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s);
 // ... then placement + ranking: order[j] (j < nvis) = ids in (key, id) order, offsets[j] = inclusive instance offsets
 int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
                             uint32_t *offsets, hipStream_t s);
-// second half of inclusive_scan_gather_u32 when the per-group partial sums already exist
-int inclusive_scan_gather_apply(const uint32_t *partial, const uint32_t *in, const uint32_t *order, uint32_t *out, int P,
-                                hipStream_t s, uint32_t *total_out);
 struct WorkListOut;
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,
@@ -188,9 +183,7 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
                              uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s,
                              const struct WorkListOut *work_out = nullptr /* also build tile ranges + work list */);
 // tiles[k] = t for k in ranges[t] (the backward's per-instance tile id when the sort did not scatter the keys);
-// inv[perm[k]] = k (inverse of a scattered permutation, for the general multi-pass sort)
 int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipStream_t s);
-int invert_permutation(const uint32_t *perm, uint32_t *inv, size_t n, hipStream_t s);
 size_t scan_gather_temp_bytes(int P);
 int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in, const uint32_t *order, uint32_t *out,
                               int P, hipStream_t s, uint32_t *total_out = nullptr /* device word receiving out[P-1] */);

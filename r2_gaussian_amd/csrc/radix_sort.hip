@@ -464,10 +464,4 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
     return 0;
 }
 
-int sort_pairs_u32_u32(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout, const uint32_t *vin,
-                       uint32_t *vout, size_t n, int end_bit, hipStream_t s)
-{
-    return sort_pairs_ex(temp, temp_bytes, kin, kout, vin, vout, nullptr, nullptr, n, end_bit, false, nullptr, s);
-}
-
 }  // namespace r2

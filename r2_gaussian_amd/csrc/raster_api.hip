@@ -55,7 +55,7 @@ extern "C" int r2_raster_forward(
     const bool hinted = depth_hint_lookup(0, (size_t)P, &hint);
     const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
     DepthReg reg{};
-    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint, pre_wgs);
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
                              projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, s); }

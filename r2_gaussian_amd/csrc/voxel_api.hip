@@ -61,7 +61,7 @@ extern "C" int r2_voxel_forward(
     const bool hinted = depth_hint_lookup(1, (size_t)P, &hint);
     const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
     DepthReg reg{};
-    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint, pre_wgs);
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
     { StageScope t(ST_VOX_PREPROCESS, s);
     launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
                             radii_y, radii_z, reg, s); }

@@ -132,3 +132,63 @@ def assert_replicas_equal(t, what="tensor"):
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     if not torch.equal(lo, hi):
         raise RuntimeError("replica divergence detected in %s: %s vs %s" % (what, lo.tolist(), hi.tolist()))
+
+
+# ---- full-volume query sharded by x-slab (SURVEY 8e: independent units, no exchange, optional gather to assemble) ----------
+# The volume array is [nx, ny, nz] with x slowest, so a slab of whole 8-voxel tiles along x is a contiguous block of
+# memory and an independent voxelizer call on a sub-volume: same voxel size, centre moved to the slab's centre.
+TILE3D = 8
+
+
+def slab_bounds(n_voxel_x, rank_, world_):
+    """[x0, x1) of rank_'s slab: whole tiles, the first ``tiles % world`` ranks get one tile more."""
+    tiles = (int(n_voxel_x) + TILE3D - 1) // TILE3D
+    per, extra = divmod(tiles, int(world_))
+    t0 = rank_ * per + min(rank_, extra)
+    t1 = t0 + per + (1 if rank_ < extra else 0)
+    return min(t0 * TILE3D, int(n_voxel_x)), min(t1 * TILE3D, int(n_voxel_x))
+
+
+def slab_settings(settings, rank_=None, world_=None):
+    """``GaussianVoxelizationSettings`` of this rank's x-slab of the volume described by ``settings`` (None if the slab is
+    empty: more ranks than tile layers)."""
+    r = rank() if rank_ is None else rank_
+    w = world() if world_ is None else world_
+    x0, x1 = slab_bounds(settings.nVoxel_x, r, w)
+    if x1 <= x0:
+        return None, (x0, x1)
+    dvx = settings.sVoxel_x / settings.nVoxel_x
+    n = x1 - x0
+    centre = settings.center_x - 0.5 * settings.sVoxel_x + (x0 + 0.5 * n) * dvx
+    return settings._replace(nVoxel_x=n, sVoxel_x=dvx * n, center_x=centre), (x0, x1)
+
+
+def query_sharded(voxelizer_cls, settings, means3D, opacities, scales, rotations, gather=True):
+    """Every rank voxelizes its x-slab (no exchange between the slabs); with ``gather`` the slabs are all-gathered into
+    the full [nx, ny, nz] volume on every rank, otherwise ``(slab, (x0, x1))`` is returned."""
+    sub, (x0, x1) = slab_settings(settings)
+    if sub is not None:
+        vol, _radii = voxelizer_cls(sub)(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations)
+    else:
+        vol = means3D.new_zeros((0, settings.nVoxel_y, settings.nVoxel_z))
+    if not gather or world() == 1:
+        return (vol, (x0, x1)) if not gather else vol
+    import torch
+    import torch.distributed as dist
+    full = means3D.new_empty((settings.nVoxel_x, settings.nVoxel_y, settings.nVoxel_z))
+    # slabs differ in size by at most one tile layer: gather into per-rank views of the full volume
+    parts = []
+    for r in range(world()):
+        a, b = slab_bounds(settings.nVoxel_x, r, world())
+        parts.append(full[a:b])
+    if all(p.shape == parts[0].shape for p in parts):
+        dist.all_gather(parts, vol.contiguous())
+    else:   # ragged: pad to the largest slab
+        m = max(p.shape[0] for p in parts)
+        pad = vol.new_zeros((m, settings.nVoxel_y, settings.nVoxel_z))
+        pad[:vol.shape[0]] = vol
+        bufs = [torch.empty_like(pad) for _ in parts]
+        dist.all_gather(bufs, pad)
+        for p, bsrc in zip(parts, bufs):
+            p.copy_(bsrc[:p.shape[0]])
+    return full

@@ -96,3 +96,29 @@ def test_single_process_is_identity():
     flat = torch.ones(4, D.GRAD_WIDTH)
     assert D.allreduce_grads(flat) is None and torch.equal(flat, torch.ones(4, D.GRAD_WIDTH))
     assert [D.view_for(k, 5, rank_=1, world_=2) for k in range(5)] == [1, 3, 0, 2, 4]
+
+
+def test_voxel_slab_settings_tile_the_volume():
+    """x-slab sharding of the full-volume query: whole tiles, contiguous, covering [0, nx) exactly once, same voxel size,
+    slab centres consistent with the full volume's voxel grid."""
+    from r2_gaussian_amd import dist as D
+    from r2_gaussian_amd.voxelization import GaussianVoxelizationSettings as VS
+    for nx, world in ((256, 8), (256, 3), (40, 4), (8, 4), (100, 8)):
+        s = VS(1.0, nx, 64, 32, 2.0, 1.0, 0.5, 0.1, -0.2, 0.3, False, False)
+        cover = []
+        for r in range(world):
+            sub, (x0, x1) = D.slab_settings(s, r, world)
+            assert x0 % 8 == 0 and (x1 % 8 == 0 or x1 == nx)
+            if sub is None:
+                assert x0 == x1
+                continue
+            cover.append((x0, x1))
+            assert sub.nVoxel_x == x1 - x0 and sub.nVoxel_y == s.nVoxel_y and sub.nVoxel_z == s.nVoxel_z
+            dv, dvs = s.sVoxel_x / s.nVoxel_x, sub.sVoxel_x / sub.nVoxel_x
+            assert abs(dv - dvs) < 1e-12
+            # first voxel centre of the slab == centre of voxel x0 of the full volume
+            full_c = s.center_x - s.sVoxel_x / 2 + (x0 + 0.5) * dv
+            slab_c = sub.center_x - sub.sVoxel_x / 2 + 0.5 * dvs
+            assert abs(full_c - slab_c) < 1e-9
+        assert cover[0][0] == 0 and cover[-1][1] == nx
+        assert all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:]))
