@@ -176,7 +176,8 @@ R2_API void r2_depth_hint_control(int mode);
  *  10 depth sort keys u32[P] (bits of the depth; 0xFFFFFFFF for culled Gaussians)
  *  11 first-instance index u32[P]   12 depth order u32[P] (ids sorted by (depth, id); culled ones behind, or unwritten with a hint)
  *  15 host-read words u32[8]: {num_rendered, overflow, thin flag, key extrema x4, nvis}
- *  13 inv u32[R] (sorted position of every emitted instance: the inverse permutation of the tile sort)
+ *  13 inv u32[R] (sorted position of every emitted instance: the inverse permutation of the tile sort; the voxelizer only
+ *     writes it for < 4096 tiles: single-pass tile sort)
  * buffer ids: 0 geometry, 1 binning, 2 image.  Returns -1 for an unknown id. */
 R2_API long long r2_raster_state_offset(int which, int P, long long R, int width, int height, int *buffer_id);
 R2_API long long r2_voxel_state_offset(int which, int P, long long R, int nx, int ny, int nz, int *buffer_id);

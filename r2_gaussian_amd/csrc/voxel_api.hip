@@ -129,10 +129,10 @@ extern "C" int r2_voxel_forward(
         if (sort_is_single_pass(bit)) {
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           bin.inv, R, bit, &tile_counts, s);
-        } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort, then invert its permutation
-            uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)
-            rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, nullptr, perm, bin.vals_unsorted,
-                               bin.point_list, R, bit, false, nullptr, s, bin.inv);
+        } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort of (tile, Gaussian id) pairs -- no permutation is
+                   // carried along: the backward recomputes an instance's emission index from the Gaussian's tile cube
+            rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.vals_unsorted, bin.point_list,
+                               nullptr, nullptr, R, bit, false, nullptr, s);
         } }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "sort");
@@ -190,7 +190,7 @@ extern "C" int r2_voxel_backward(
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_VOX_GEOM_BWD, s);
     launch_voxel_geom_backward(geom, v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
-                               cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, bin.inv, dL_dconic3D,
+                               cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, dL_dconic3D,
                                dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
 __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
-    int gz, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
+    int gz, uint32_t *__restrict__ first, uint4 *__restrict__ cube, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
     const uint32_t *__restrict__ nvis)
 {
     if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
@@ -170,6 +170,8 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
         const float4 r0 = rec[3 * id];
         tile_cube(make_float3(r0.x, r0.y, r0.z), make_float3((float)rx, (float)ry, (float)rz), gx, gy, gz, lo, hi);
         first[id] = excl;
+        cube[id] = make_uint4(excl, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
+                              (uint32_t)(hi.y - lo.y));
     }
     const uint32_t wbeg = __shfl(excl, 0);
     const int last_lane = min(63, P - 1 - wave_first);
@@ -210,7 +212,7 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     int P, const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
     const float *__restrict__ cov3Ds, const float *__restrict__ scales, const float *__restrict__ rotations,
     float scale_modifier, VoxelGrid v, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
-    const uint32_t *__restrict__ inv, const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part,
+    const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part,
     float *__restrict__ dL_dconic3D,
     float *__restrict__ dL_dmean3D_norm, float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans,
     float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
@@ -236,7 +238,7 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 10; ++k) S[k] = 0.f;
     for (uint32_t j = 0; j < ninst; ++j) {
-        const size_t row = inv[first + j];   // sorted position of this Gaussian's j-th instance
+        const size_t row = (size_t)first + j;   // the render backward stores each instance's row at its emission index
         const float4 m0 = part[3 * row];
         const float4 m1 = part[3 * row + 1];
         const float4 m2 = part[3 * row + 2];
@@ -326,20 +328,20 @@ int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const Voxe
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s)
 {
     voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii_x, radii_y,
-                                                                       radii_z, v.gx, v.gy, v.gz, g.first,
+                                                                       radii_z, v.gx, v.gy, v.gz, g.first, g.cube,
                                                                        b.tiles_unsorted, b.vals_unsorted, nvis);
     return 0;
 }
 
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
-                               float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D,
+                               float scale_modifier, const float *part, float *dL_dconic3D,
                                float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s)
 {
     voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, inv, g.tiles_touched,
+        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, g.tiles_touched,
         reinterpret_cast<const float4 *>(part), dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D,
         dL_dscale, dL_drot);
     return 0;

@@ -452,8 +452,8 @@ __device__ __forceinline__ void tile_moments3_gather(const float4 p, const float
 
 __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
-    const float4 *__restrict__ rec, uint32_t R, VoxelGrid v, uint32_t nchunks, const float *__restrict__ dL_dvol,
-    float4 *__restrict__ part)
+    const float4 *__restrict__ rec, const uint4 *__restrict__ cube, uint32_t R, VoxelGrid v, uint32_t nchunks,
+    const float *__restrict__ dL_dvol, float4 *__restrict__ part)
 {
     __shared__ float4 gtile[4][128];   // one 8x8x8 dL/dvol block per wave
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
@@ -463,12 +463,14 @@ __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
     const bool live = k < R;
     uint32_t tile = 0xffffffffu, id = 0;
     float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p, r = p;
+    uint4 cb = make_uint4(0u, 0u, 0u, 0u);
     if (live) {
         tile = tiles[k];
         id = point_list[k];
         p = rec[3 * id];
         q = rec[3 * id + 1];
         r = rec[3 * id + 2];
+        cb = cube[id];   // only needed for the final store's address: requested with the other gathers
     }
     float S[10];
 #pragma unroll
@@ -517,10 +519,17 @@ __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
         }
     }
     if (live) {
-        // scratch row = sorted position (coalesced); the geometry backward gathers through the inverse permutation
-        part[3 * (size_t)k] = make_float4(S[0], S[1], S[2], S[3]);
-        part[3 * (size_t)k + 1] = make_float4(S[4], S[5], S[6], S[7]);
-        part[3 * (size_t)k + 2] = make_float4(S[8], S[9], 0.f, 0.f);
+        // scratch row = the instance's EMISSION index, recomputed from the Gaussian's tile cube (the duplicate kernel emits
+        // a Gaussian's tiles z-major / y / x-minor from `first`): a Gaussian's rows end up contiguous, the geometry backward
+        // streams them, and the tile sort does not have to carry a permutation
+        const int ttx = (int)(tile % (uint32_t)v.gx), tty = (int)((tile / (uint32_t)v.gx) % (uint32_t)v.gy),
+                  ttz = (int)(tile / ((uint32_t)v.gx * (uint32_t)v.gy));
+        const int lox = (int)(cb.y & 0xffffu), loy = (int)(cb.y >> 16), loz = (int)(cb.z & 0xffffu);
+        const int cnx = (int)(cb.z >> 16), cny = (int)cb.w;
+        const size_t u = (size_t)cb.x + (size_t)(((ttz - loz) * cny + (tty - loy)) * cnx + (ttx - lox));
+        part[3 * u] = make_float4(S[0], S[1], S[2], S[3]);
+        part[3 * u + 1] = make_float4(S[4], S[5], S[6], S[7]);
+        part[3 * u + 2] = make_float4(S[8], S[9], 0.f, 0.f);
     }
 }
 
@@ -556,7 +565,7 @@ int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, cons
     if (R == 0) return 0;
     const uint32_t nchunks = (uint32_t)((R + 255) / 256);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    voxel_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, (uint32_t)R, v,
+    voxel_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, g.cube, (uint32_t)R, v,
                                                                   nchunks, dL_dvol, reinterpret_cast<float4 *>(b.part));
     return 0;
 }

@@ -31,6 +31,8 @@ struct VoxelGeom {
     uint32_t *depth_sorted;   // [P]
     uint32_t *order;          // [P]  Gaussian ids in (z bits, id) order
     uint32_t *first;          // [P]  first instance of the Gaussian in the emission list
+    uint4 *cube;              // [P]  {first, lo.x | lo.y << 16, lo.z | nx << 16, ny}: the Gaussian's tile cube (origin + x/y
+                              //      extents in tiles), from which the backward recomputes an instance's emission index
     float *cov3D;             // [6P]
     uint32_t *tiles_touched;  // [P]
     uint32_t *host_words;     // [DW_COUNT] the words the host reads back: the control block at the start of dorder_temp
@@ -53,6 +55,7 @@ struct VoxelGeom {
         g.depth_sorted = b.take<uint32_t>(P);
         g.order = b.take<uint32_t>(P);
         g.first = b.take<uint32_t>(P);
+        g.cube = b.take<uint4>(P);
         g.cov3D = b.take<float>(6 * (size_t)P);
         g.tiles_touched = b.take<uint32_t>(P);
         g.offsets = b.take<uint32_t>(P);
@@ -71,7 +74,8 @@ struct VoxelGeom {
 struct VoxelBinning {
     uint32_t *tiles_unsorted, *tiles;   // [R]
     uint32_t *vals_unsorted;            // [R] Gaussian id per instance (emission order)
-    uint32_t *inv;                      // [R] sorted position of emission index u (inverse permutation of the tile sort)
+    uint32_t *inv;                      // [R] sorted position of emission index u; only written by the single-pass tile sort
+                                        //     (<= 4096 tiles), for introspection -- nothing in the pipeline reads it
     uint32_t *point_list;               // [R]
     float *part;                        // [R*VPART_STRIDE] backward scratch
     char *sort_temp;
@@ -136,7 +140,7 @@ int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const Voxe
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
-                               float scale_modifier, const float *part, const uint32_t *inv, float *dL_dconic3D, float *dL_dmean3D_norm,
+                               float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s);
 // tile lists shorter than this get no forward work item (a light kernel renders them); 0 in debug mode

@@ -159,8 +159,9 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
     out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
-    out["inv"] = read(13, np.uint32, R)
-    out["perm"] = perm_from_inv(out["inv"])
+    if int(T).bit_length() <= 12:   # the inverse permutation is only written by the single-pass (<= 12-bit) tile sort
+        out["inv"] = read(13, np.uint32, R)
+        out["perm"] = perm_from_inv(out["inv"])
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     rec = read(9, np.float32, 12 * P).reshape(P, 12)
     out["rec"] = rec
@@ -243,4 +244,5 @@ def check_binning(h, o):
     assert np.array_equal(h["keys"], o["keys"]), "sorted (tile|depth) keys differ"
     assert np.array_equal(h["point_list"], o["point_list"]), "point_list differs"
     assert np.array_equal(h["ranges"], o["ranges"]), "ranges differ"
-    assert np.array_equal(h["vals_unsorted"][h["perm"]], h["point_list"])
+    if "perm" in h:
+        assert np.array_equal(h["vals_unsorted"][h["perm"]], h["point_list"])
