@@ -139,12 +139,12 @@ extern "C" int r2_voxel_forward(
     }
     { StageScope t(ST_VOX_RANGES, s);
     if (tile_counts) {
-        launch_ranges_and_work(tile_counts, (uint32_t)T, VOX_CHUNK, img.ranges, img.chunk_base, img.work_tile, s,
+        launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(R), img.ranges, img.chunk_base, img.work_tile, s,
                                voxel_short_list_min(debug != 0));
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
         if (rc) return rc;
-        launch_build_work(img.ranges, (uint32_t)T, VOX_CHUNK, img.chunk_base, img.work_tile, img.work_temp, s,
+        launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(R), img.chunk_base, img.work_tile, img.work_temp, s,
                           voxel_short_list_min(debug != 0));
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");

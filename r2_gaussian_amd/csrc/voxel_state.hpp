@@ -5,7 +5,11 @@
 
 namespace r2 {
 
-constexpr uint32_t VOX_CHUNK = 1024;  // instances of one tile list evaluated by one workgroup (load balance)
+constexpr uint32_t VOX_CHUNK = 1024;  // most instances of one tile list evaluated by one workgroup (load balance)
+// Small problems (the training loop's 32^3 TV patch: 64 tiles, ~5e4 instances) are cut finer, so that the forward still
+// launches a few workgroups per CU instead of ~one long-running workgroup per tile.  A pure function of R: the backward and
+// the state introspection re-derive the same layout.
+inline uint32_t vox_chunk_for(size_t R) { return R >= (size_t)1 << 20 ? VOX_CHUNK : (R >= (size_t)1 << 19 ? 512u : (R >= (size_t)1 << 17 ? 256u : 128u)); }
 constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
 constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
 constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)
@@ -112,7 +116,7 @@ struct VoxelImage {
     {
         VoxelImage s;
         Bump b(chunk);
-        s.NW = R / VOX_CHUNK + T;
+        s.NW = R / vox_chunk_for(R) + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 1);
         s.work_tile = b.take<uint4>(s.NW);

@@ -45,6 +45,7 @@ int main(int argc, char **argv)
     auto fwd = sym<decltype(&r2_raster_forward)>(h, "r2_raster_forward");
     auto bwd = sym<decltype(&r2_raster_backward)>(h, "r2_raster_backward");
     auto vfwd = sym<decltype(&r2_voxel_forward)>(h, "r2_voxel_forward");
+    auto vbwd = sym<decltype(&r2_voxel_backward)>(h, "r2_voxel_backward");
     auto prof_enable = sym<decltype(&r2_profile_enable)>(h, "r2_profile_enable");
     auto prof_count = sym<decltype(&r2_profile_stage_count)>(h, "r2_profile_stage_count");
     auto prof_name = sym<decltype(&r2_profile_stage_name)>(h, "r2_profile_stage_name");
@@ -81,7 +82,7 @@ int main(int argc, char **argv)
     CHECK(hipMemcpy(dL, dLh.data(), dLh.size() * 4, hipMemcpyHostToDevice));
     CHECK(hipMalloc(reinterpret_cast<void **>(&out), (size_t)256 * 256 * 256 * 4));
     CHECK(hipMalloc(reinterpret_cast<void **>(&radii), (size_t)3 * P * 4));
-    CHECK(hipMalloc(reinterpret_cast<void **>(&grads), (size_t)32 * P * 4));
+    CHECK(hipMalloc(reinterpret_cast<void **>(&grads), (size_t)32 * P * 4));   // 25 floats/Gaussian (raster), 26 (voxel)
     float *g2d = grads, *gcon = grads + (size_t)3 * P, *gop = grads + (size_t)7 * P, *gmu = grads + (size_t)8 * P,
           *g3d = grads + (size_t)9 * P, *gcov = grads + (size_t)12 * P, *gsc = grads + (size_t)18 * P, *grot = grads + (size_t)21 * P;
     Slot slots[3];
@@ -150,6 +151,39 @@ int main(int argc, char **argv)
     CHECK(hipStreamSynchronize(s));
     const double tv = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / 10;
     printf("voxel 256^3: %.3f ms  %.2f GVoxel/s  (R3 %d)\n", tv * 1e3, 256.0 * 256 * 256 / tv / 1e9, R3);
+    // the training loop's TV regulariser: forward + backward on a 32^3 sub-volume (train.py, tv_vol_size = 32)
+    {
+        float *dLv;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&dLv), (size_t)32 * 32 * 32 * 4));
+        CHECK(hipMemset(dLv, 0x3c, (size_t)32 * 32 * 32 * 4));   // some small positive floats
+        float *gn = grads, *gc3 = grads + (size_t)3 * P, *go = grads + (size_t)9 * P, *gm = grads + (size_t)10 * P,
+              *gcv = grads + (size_t)13 * P, *gs = grads + (size_t)19 * P, *gr = grads + (size_t)22 * P;
+        auto tv = [&](int k) {
+            const float cx = -0.3f + 0.1f * (float)(k % 7), cy = 0.1f * (float)(k % 5) - 0.2f, cz = 0.05f * (float)(k % 9) - 0.2f;
+            const int R3s = vfwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, 32, 32, 32, 0.25f, 0.25f, 0.25f, cx, cy, cz, means,
+                                 dens, scal, 1.f, rot, nullptr, 0, out, radii, radii + P, radii + 2 * (size_t)P, 0, s);
+            if (R3s < 0) { fprintf(stderr, "voxel forward (tv): %d %s\n", R3s, last_error()); exit(1); }
+            const int rc = vbwd(P, R3s, 32, 32, 32, 0.25f, 0.25f, 0.25f, cx, cy, cz, means, scal, 1.f, rot, nullptr, radii, radii + P,
+                                radii + 2 * (size_t)P, slots[0].p, slots[1].p, slots[2].p, dLv, gn, gc3, go, gm, gcv, gs, gr, 0, s);
+            if (rc < 0) { fprintf(stderr, "voxel backward (tv): %d %s\n", rc, last_error()); exit(1); }
+            return R3s;
+        };
+        int R3s = 0;
+        for (int k = 0; k < 10; ++k) R3s = tv(k);
+        CHECK(hipStreamSynchronize(s));
+        const auto t2 = std::chrono::steady_clock::now();
+        for (int k = 0; k < 100; ++k) tv(k);
+        CHECK(hipStreamSynchronize(s));
+        const double tt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count() / 100;
+        printf("voxel 32^3 fwd+bwd (TV patch): %.1f us  (R3 %d)\n", tt * 1e6, R3s);
+        prof_enable(~0ull);
+        for (int k = 0; k < 20; ++k) tv(k);
+        CHECK(hipStreamSynchronize(s));
+        prof_read(ms.data(), cnt.data(), 1);
+        for (int i = 0; i < ns; ++i)
+            if (cnt[i] && !strncmp(prof_name(i), "voxel.", 6)) printf("  tv %-17s %8.2f us\n", prof_name(i), 1e3 * ms[i] / cnt[i]);
+        prof_enable(0);
+    }
     prof_enable(~0ull);
     for (int k = 0; k < 5; ++k) vox();
     CHECK(hipStreamSynchronize(s));
