@@ -90,6 +90,16 @@ def test_depth_hint_paths_are_identical_and_stale_hints_are_harmless(oracle, gpu
         h5 = Hh.hip_raster(c4, v, gpu)
         assert int(h5["host_words"][1]) == 0 and int(h5["host_words"][7]) > 0
         assert np.array_equal(h5["point_list"], h4["point_list"]) and np.array_equal(h5["color"], h4["color"])
+        # part of the cloud behind the near plane (depth = 0.5 - x <= 0.2 is culled): the hinted path only writes the
+        # visible prefix of the depth order, the culled Gaussians must stay out of every list
+        c7 = shifted(1.0, 4.5)
+        o7 = Hh.oracle_raster(oracle, c7, v, render=False)
+        nvis7 = int((o7["tiles_touched"] > 0).sum())
+        assert 0 < nvis7 < P
+        Hh.hip_raster(c7, v, gpu)                      # stale hint (overflow or not), then a fresh one
+        h7 = Hh.hip_raster(c7, v, gpu)
+        assert int(h7["host_words"][1]) == 0 and int(h7["host_words"][7]) == nvis7
+        Hh.check_binning(h7, o7)
         # hints switched off: always the un-hinted path
         L.r2_depth_hint_control(0)
         h6 = Hh.hip_raster(c4, v, gpu)
