@@ -209,10 +209,31 @@ def main():
             torch.cuda.synchronize()
             vprof = _lib.profile_read(reset=True)
             _lib.profile_enable([])
+        # the training loop's TV regulariser: forward + backward of a 32^3 patch through the drop-in voxelizer
+        from r2_gaussian_amd import GaussianVoxelizationSettings, GaussianVoxelizer
+        vox32 = [GaussianVoxelizer(GaussianVoxelizationSettings(1.0, 32, 32, 32, 0.25, 0.25, 0.25, -0.3 + 0.1 * (i % 7),
+                                                                0.1 * (i % 5) - 0.2, 0.05 * (i % 9) - 0.2, False, False))
+                 for i in range(16)]
+        gvol = torch.full((32, 32, 32), 1.0 / 32 ** 3, device=dev)
+
+        def tv_step(i):
+            vol, _r = vox32[i % 16](means3D=xyz, opacities=dens, scales=scal, rotations=rot)
+            for p_ in params:
+                p_.grad = None
+            vol.backward(gvol)
+        for i in range(10):
+            tv_step(i)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for i in range(100):
+            tv_step(i)
+        torch.cuda.synchronize()
+        ttv = (time.perf_counter() - t2) / 100
         vbytes = 168 * P + 88 * R3 + 16 * 32768 + 8 * 256 ** 3
         gvox = {"gvoxel_per_s": round(256 ** 3 / tv / 1e9, 3), "ms": round(tv * 1e3, 3), "R3": int(R3),
                 "alg_MB": round(vbytes / 1e6, 1), "hbm_frac": round(vbytes / tv / 1e9 / HBM_PEAK_GBS, 4),
-                "stages_us": {k: round(1e3 * ms / cnt, 1) for k, (ms, cnt) in sorted(vprof.items()) if k.startswith("voxel.")}}
+                "stages_us": {k: round(1e3 * ms / cnt, 1) for k, (ms, cnt) in sorted(vprof.items()) if k.startswith("voxel.")},
+                "tv_patch_32cube_fwd_bwd_us": round(ttv * 1e6, 1)}
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, one view
     cpu = None
