@@ -406,63 +406,55 @@ __device__ __forceinline__ void row_to_moments(float dx, float dy, float r0, flo
     S[9] += r2;         // zz
 }
 
-// moments over one 8x8x8 tile whose dL/dvol block sits in this wave's LDS slab (zeros outside the volume):
-// 128 float4, index (x*8+y)*2 + z/4; every read is a wave-uniform broadcast.
-__device__ __forceinline__ void tile_moments3_uniform(const float4 p, const float4 q, const float4 r,
-                                                      const float4 *__restrict__ gt, int x0, int y0, int z0, float *S)
+// ------------------------------------------------------------------------------------------------ backward
+// Item-parallel like the rasterizer's (raster_render.hip): one LANE owns one ITEM = one x-slab (1 x 8 x 8 voxels) of one
+// (tile, Gaussian) instance; only slabs that the Gaussian's alpha >= 1e-6 bounding box touches become items (3-4 of 8 on
+// the 32^3 TV patch).  A one-wave workgroup takes 64 consecutive instances of the sorted list, stages dL/dvol of their
+// tiles in LDS (three tiles per pass), expands the instances into items through an LDS queue, evaluates 64 items at a
+// time, and every instance then adds the moment rows of its own items in queue order -- no atomics, bit-reproducible.
+// (The first version let one lane walk all 512 voxels of its tile: twice the arithmetic, and 64 instances per wave meant
+// ~700 long-running waves on the TV patch -- 48 us for 45 k instances.)
+constexpr int VB_TILES = 3;                 // tiles staged per pass
+constexpr int VB_GT = 8 * 8 * 8 + 8;        // floats per staged tile (+ pad: tile slots on different banks)
+
+// moments of w = G * dL/dvol over one x-slab whose dL/dvol rows sit in LDS at gs (row y at gs[y * 8], 8 z values)
+__device__ __forceinline__ void slab_moments(const float4 p, const float4 q, const float4 r, const float *__restrict__ gs,
+                                             float xc, float y0, float z0, float *M)
 {
-    const float dz0 = p.z - ((float)z0 + 0.5f);
-    for (int ix = 0; ix < TILE3D; ++ix) {
-        const float dx = p.x - ((float)(x0 + ix) + 0.5f);
+    const float dx = p.x - xc;
+    const float dz0 = p.z - (z0 + 0.5f);
 #pragma unroll 2
-        for (int iy = 0; iy < TILE3D; ++iy) {
-            const float dy = p.y - ((float)(y0 + iy) + 0.5f);
-            const float k0 = dx * (q.x * dx + q.y * dy) + (q.w * dy) * dy;   // a2 dx^2 + b2 dx dy + d2 dy^2
-            const float k1 = q.z * dx + r.x * dy;                            // c2 dx + e2 dy
-            const float4 g0 = gt[(ix * 8 + iy) * 2], g1 = gt[(ix * 8 + iy) * 2 + 1];
-            const float g[8] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w };
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
+    for (int iy = 0; iy < TILE3D; ++iy) {
+        const float dy = p.y - (y0 + (float)iy + 0.5f);
+        const float k0 = dx * (q.x * dx + q.y * dy) + (q.w * dy) * dy;   // a2 dx^2 + b2 dx dy + d2 dy^2
+        const float k1 = q.z * dx + r.x * dy;                            // c2 dx + e2 dy
+        const float4 g0 = *reinterpret_cast<const float4 *>(gs + iy * 8), g1 = *reinterpret_cast<const float4 *>(gs + iy * 8 + 4);
+        const float g[8] = { g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w };
+        float r0 = 0.f, r1 = 0.f, r2 = 0.f;
 #pragma unroll
-            for (int iz = 0; iz < TILE3D; ++iz) voxel_moments(p, r.y, dz0 - (float)iz, k0, k1, g[iz], r0, r1, r2);
-            row_to_moments(dx, dy, r0, r1, r2, S);
-        }
+        for (int iz = 0; iz < TILE3D; ++iz) voxel_moments(p, r.y, dz0 - (float)iz, k0, k1, g[iz], r0, r1, r2);
+        row_to_moments(dx, dy, r0, r1, r2, M);
     }
 }
 
-// lanes of the wave sit in many different sparse tiles: each lane gathers dL/dvol of its own tile
-__device__ __forceinline__ void tile_moments3_gather(const float4 p, const float4 q, const float4 r,
-                                                     const float *__restrict__ dL, const VoxelGrid &v, int x0, int y0,
-                                                     int z0, float *S)
-{
-    const float dz0 = p.z - ((float)z0 + 0.5f);
-    const int ncx = min(TILE3D, v.nx - x0), ncy = min(TILE3D, v.ny - y0), ncz = min(TILE3D, v.nz - z0);
-    for (int ix = 0; ix < ncx; ++ix) {
-        const float dx = p.x - ((float)(x0 + ix) + 0.5f);
-        for (int iy = 0; iy < ncy; ++iy) {
-            const float dy = p.y - ((float)(y0 + iy) + 0.5f);
-            const float k0 = dx * (q.x * dx + q.y * dy) + (q.w * dy) * dy;
-            const float k1 = q.z * dx + r.x * dy;
-            const float *__restrict__ row = dL + ((size_t)(x0 + ix) * v.ny + (y0 + iy)) * v.nz + z0;
-            float r0 = 0.f, r1 = 0.f, r2 = 0.f;
-            for (int iz = 0; iz < ncz; ++iz) voxel_moments(p, r.y, dz0 - (float)iz, k0, k1, row[iz], r0, r1, r2);
-            row_to_moments(dx, dy, r0, r1, r2, S);
-        }
-    }
-}
-
-__global__ void __launch_bounds__(256) voxel_render_backward_kernel(
+__global__ void __launch_bounds__(64) voxel_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
-    const float4 *__restrict__ rec, const uint4 *__restrict__ cube, uint32_t R, VoxelGrid v, uint32_t nchunks,
-    const float *__restrict__ dL_dvol, float4 *__restrict__ part)
+    const float4 *__restrict__ rec, const float4 *__restrict__ ext, const uint4 *__restrict__ cube, uint32_t R, VoxelGrid v,
+    uint32_t nchunks, uint32_t ipw, const float *__restrict__ dL_dvol, float4 *__restrict__ part)
 {
-    __shared__ float4 gtile[4][128];   // one 8x8x8 dL/dvol block per wave
+    __shared__ float s_gt[VB_TILES * VB_GT];      // dL/dvol of the pass's tiles: [tile][x][y][z]
+    __shared__ float4 s_p[64], s_q[64], s_r[64];  // the wave's 64 instance records
+    __shared__ uint16_t s_queue[64 * TILE3D];     // items: (owner lane << 5) | (tile slot << 3) | slab
+    __shared__ float s_m[64][11];                 // moment rows of the current round of 64 items (+1 pad)
     const uint32_t chunk = xcd_remap(blockIdx.x, nchunks);
     if (chunk >= nchunks) return;
-    const uint32_t k = chunk * 256u + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const bool live = k < R;
+    const int lane = threadIdx.x;
+    // ipw instances per wave (64, or fewer on small problems so that every SIMD gets a few waves: the items of 16
+    // instances still fill the 64 lanes of a round)
+    const uint32_t k = chunk * ipw + (uint32_t)lane;
+    const bool live = (uint32_t)lane < ipw && k < R;
     uint32_t tile = 0xffffffffu, id = 0;
-    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p, r = p;
+    float4 p = make_float4(0.f, 0.f, 0.f, 0.f), q = p, r = p, h = p;
     uint4 cb = make_uint4(0u, 0u, 0u, 0u);
     if (live) {
         tile = tiles[k];
@@ -470,52 +462,108 @@ __global__ void __launch_bounds__(256) voxel_render_backward_kernel(
         p = rec[3 * id];
         q = rec[3 * id + 1];
         r = rec[3 * id + 2];
+        h = ext[id];
         cb = cube[id];   // only needed for the final store's address: requested with the other gathers
     }
     float S[10];
 #pragma unroll
     for (int i = 0; i < 10; ++i) S[i] = 0.f;
-    float4 *gt = gtile[wave];
     const uint32_t gxy = (uint32_t)(v.gx * v.gy);
 
     const uint32_t prev_tile = __shfl_up(tile, 1);
     const unsigned long long heads = __ballot(live && (lane == 0 || tile != prev_tile));
-    if (__popcll(heads) > 3) {
-        if (live)
-            tile_moments3_gather(p, q, r, dL_dvol, v, (int)(tile % v.gx) * TILE3D, (int)((tile / v.gx) % v.gy) * TILE3D,
-                                 (int)(tile / gxy) * TILE3D, S);
-    } else {
-        unsigned long long todo = __ballot(live);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
+    const int ntiles = __popcll(heads);
+    const int my_slot = __popcll(heads & ((2ull << lane) - 1ull)) - 1;   // rank of this lane's tile among the heads
+    unsigned long long hh = heads;
+    for (int slot0 = 0; slot0 < ntiles; slot0 += VB_TILES) {
+        const int npass = min(VB_TILES, ntiles - slot0);
+        const bool mine = live && my_slot >= slot0 && my_slot < slot0 + npass;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // the previous pass is done with the LDS buffers
+        // ---- stage dL/dvol of this pass's tiles: lane -> (x = lane/8, y = lane%8), its 8 z values as two float4
+        for (int slot = 0; slot < npass; ++slot) {
+            const int leader = __ffsll((long long)hh) - 1;
+            hh &= hh - 1;
             const uint32_t t = __builtin_amdgcn_readfirstlane(__shfl(tile, leader));
-            const bool mine = live && tile == t;
-            todo &= ~__ballot(mine);
             const int x0 = (int)(t % v.gx) * TILE3D, y0 = (int)((t / v.gx) % v.gy) * TILE3D, z0 = (int)(t / gxy) * TILE3D;
-            {   // stage the tile's dL/dvol: lane -> (x = lane/8, y = lane%8), its 8 z values as two float4
-                const int vx = x0 + (lane >> 3), vy = y0 + (lane & 7);
-                float g[8];
+            const int vx = x0 + (lane >> 3), vy = y0 + (lane & 7);
+            float g[8];
 #pragma unroll
-                for (int iz = 0; iz < 8; ++iz) g[iz] = 0.f;
-                if (vx < v.nx && vy < v.ny) {
-                    const float *__restrict__ src = dL_dvol + ((size_t)vx * v.ny + vy) * v.nz + z0;
-                    if (z0 + 7 < v.nz && (v.nz & 3) == 0) {
-                        const float4 a = *reinterpret_cast<const float4 *>(src);
-                        const float4 b = *reinterpret_cast<const float4 *>(src + 4);
-                        g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
-                    } else {
+            for (int iz = 0; iz < 8; ++iz) g[iz] = 0.f;
+            if (vx < v.nx && vy < v.ny) {
+                const float *__restrict__ src = dL_dvol + ((size_t)vx * v.ny + vy) * v.nz + z0;
+                if (z0 + 7 < v.nz && (v.nz & 3) == 0) {
+                    const float4 a = *reinterpret_cast<const float4 *>(src);
+                    const float4 b = *reinterpret_cast<const float4 *>(src + 4);
+                    g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w; g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+                } else {
 #pragma unroll
-                        for (int iz = 0; iz < 8; ++iz)
-                            if (z0 + iz < v.nz) g[iz] = src[iz];
-                    }
+                    for (int iz = 0; iz < 8; ++iz)
+                        if (z0 + iz < v.nz) g[iz] = src[iz];
                 }
-                __builtin_amdgcn_wave_barrier();
-                gt[lane * 2] = make_float4(g[0], g[1], g[2], g[3]);
-                gt[lane * 2 + 1] = make_float4(g[4], g[5], g[6], g[7]);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
-            if (mine) tile_moments3_uniform(p, q, r, gt, x0, y0, z0, S);
+            float *dst = s_gt + slot * VB_GT + lane * 8;
+            *reinterpret_cast<float4 *>(dst) = make_float4(g[0], g[1], g[2], g[3]);
+            *reinterpret_cast<float4 *>(dst + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+        // ---- expand instances into slab items
+        const int slot = my_slot - slot0;
+        const float tx0 = (float)((int)(tile % v.gx) * TILE3D), ty0 = (float)((int)((tile / v.gx) % v.gy) * TILE3D),
+                    tz0 = (float)((int)(tile / gxy) * TILE3D);
+        uint32_t mask = 0;
+        if (mine) {
+#pragma unroll
+            for (int sl = 0; sl < TILE3D; ++sl)
+                if (slab_live(p.x, p.y, p.z, h, tx0 + (float)sl + 0.5f, ty0, tz0)) mask |= 1u << sl;
+        }
+        const int cnt = __popc(mask);
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        const int off = incl - cnt;
+        const int total = __shfl(incl, 63);
+        s_p[lane] = p;
+        s_q[lane] = q;
+        s_r[lane] = r;
+        {
+            int o = off;
+#pragma unroll
+            for (int sl = 0; sl < TILE3D; ++sl)
+                if (mask & (1u << sl)) s_queue[o++] = (uint16_t)((lane << 5) | (slot << 3) | sl);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- rounds of 64 items
+        for (int base = 0; base < total; base += 64) {
+            const int e = base + lane;
+            float M[10];
+#pragma unroll
+            for (int i = 0; i < 10; ++i) M[i] = 0.f;
+            const uint32_t item = e < total ? (uint32_t)s_queue[e] : 0u;
+            const int owner = (int)(item >> 5), sl_t = (int)((item >> 3) & 3u), sl = (int)(item & 7u);
+            const uint32_t ot = __shfl(tile, owner);   // the owner's tile (all lanes take part in the shuffle)
+            if (e < total) {
+                const float4 op = s_p[owner], oq = s_q[owner], orr = s_r[owner];
+                const float ox0 = (float)((int)(ot % v.gx) * TILE3D), oy0 = (float)((int)((ot / v.gx) % v.gy) * TILE3D),
+                            oz0 = (float)((int)(ot / gxy) * TILE3D);
+                slab_moments(op, oq, orr, s_gt + sl_t * VB_GT + sl * 64, ox0 + (float)sl + 0.5f, oy0, oz0, M);
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 10; ++i) s_m[lane][i] = M[i];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // every instance adds the rows of its own items that were processed in this round, in item order
+            for (int i = 0; i < cnt; ++i) {
+                const int e2 = off + i - base;
+                if (e2 >= 0 && e2 < 64) {
+#pragma unroll
+                    for (int j = 0; j < 10; ++j) S[j] += s_m[e2][j];
+                }
+            }
         }
     }
     if (live) {
@@ -563,10 +611,12 @@ int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, cons
                                  const float *dL_dvol, hipStream_t s)
 {
     if (R == 0) return 0;
-    const uint32_t nchunks = (uint32_t)((R + 255) / 256);
+    // instances per wave: 64, fewer when that would leave most SIMDs without a wave (the 32^3 TV patch has 45 k instances)
+    const uint32_t ipw = R >= ((size_t)1 << 19) ? 64u : (R >= ((size_t)1 << 18) ? 32u : 16u);
+    const uint32_t nchunks = (uint32_t)((R + ipw - 1) / ipw);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    voxel_render_backward_kernel<<<dim3(grid), dim3(256), 0, s>>>(b.tiles, b.point_list, g.rec, g.cube, (uint32_t)R, v,
-                                                                  nchunks, dL_dvol, reinterpret_cast<float4 *>(b.part));
+    voxel_render_backward_kernel<<<dim3(grid), dim3(64), 0, s>>>(b.tiles, b.point_list, g.rec, g.ext, g.cube, (uint32_t)R, v,
+                                                                 nchunks, ipw, dL_dvol, reinterpret_cast<float4 *>(b.part));
     return 0;
 }
 
