@@ -120,15 +120,19 @@ extern "C" int r2_voxel_forward(
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0);
     const uint32_t *tile_counts = nullptr;
+    bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
         { StageScope t(ST_VOX_DUPLICATE, s);
         launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)T);
         { StageScope t(ST_VOX_SORT, s);
-        if (sort_is_single_pass(bit)) {
+        if (sort_is_single_pass(bit)) {   // block 0 of the sort's last kernel also builds tile ranges + work list
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(R), nullptr,
+                                 voxel_short_list_min(debug != 0)};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
-                                          bin.inv, R, bit, &tile_counts, s);
+                                          bin.inv, R, bit, &tile_counts, s, &wo);
+            work_built = true;
         } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort of (tile, Gaussian id) pairs -- no permutation is
                    // carried along: the backward recomputes an instance's emission index from the Gaussian's tile cube
             rc = sort_pairs_ex(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.tiles, bin.vals_unsorted, bin.point_list,
@@ -138,7 +142,9 @@ extern "C" int r2_voxel_forward(
         R2_STAGE_CHECK(debug, s, "sort");
     }
     { StageScope t(ST_VOX_RANGES, s);
-    if (tile_counts) {
+    if (work_built) {
+        // nothing to do
+    } else if (tile_counts) {
         launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(R), img.ranges, img.chunk_base, img.work_tile, s,
                                voxel_short_list_min(debug != 0));
     } else {
