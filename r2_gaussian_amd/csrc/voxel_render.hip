@@ -10,11 +10,11 @@
 //           written in 32-byte runs of [nx,ny,nz] (the reference's x-fastest thread order strides by ny*nz
 //           floats between lanes).  Records (48 bytes packed) are staged through LDS in 512-record batches;
 //           partial sums per work item are added in list order by a second kernel (deterministic volume).
-// Backward: loop nest inverted as in raster_render.hip: one LANE owns one (tile, Gaussian) instance and walks
-//           the 512 voxels of its tile; dL/dvol of the tile is staged once per wave in LDS.  The 10 gradient
-//           sums of the reference are linear in 10 moments of w = G*dL: sum w, sum w d_i, sum w d_i d_j.
-//           No atomics: each instance stores its moment row at its emission index, the geometry backward
-//           reduces each Gaussian's contiguous run in a fixed order (bit-reproducible gradients).
+// Backward: item-parallel as in raster_render.hip: one LANE owns one x-slab of one (tile, Gaussian) instance; dL/dvol of
+//           the wave's tiles is staged in LDS.  The 10 gradient sums of the reference are linear in 10 moments of
+//           w = G*dL: sum w, sum w d_i, sum w d_i d_j.  No atomics: each instance adds its slabs' rows in a fixed order
+//           and stores its moment row at its emission index, the geometry backward reduces each Gaussian's contiguous
+//           run in a fixed order (bit-reproducible gradients).
 #include "voxel_state.hpp"
 
 namespace r2 {
