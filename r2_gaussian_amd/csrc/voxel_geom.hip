@@ -237,14 +237,25 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     float S[10];
 #pragma unroll
     for (int k = 0; k < 10; ++k) S[k] = 0.f;
-    for (uint32_t j = 0; j < ninst; ++j) {
-        const size_t row = (size_t)first + j;   // the render backward stores each instance's row at its emission index
-        const float4 m0 = part[3 * row];
-        const float4 m1 = part[3 * row + 1];
-        const float4 m2 = part[3 * row + 2];
-        S[0] += m0.x; S[1] += m0.y; S[2] += m0.z; S[3] += m0.w;
-        S[4] += m1.x; S[5] += m1.y; S[6] += m1.z; S[7] += m1.w;
-        S[8] += m2.x; S[9] += m2.y;
+    // the render backward stores each instance's row at its emission index: this Gaussian's rows are contiguous.  Four rows
+    // per trip, all twelve loads in flight before the first add (the adds keep the row order: bit-reproducible); a wave's
+    // trip count is that of its widest Gaussian (up to 64 tiles on the TV patch)
+    for (uint32_t j = 0; j < ninst; j += 4) {
+        float4 m0[4], m1[4], m2[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const size_t row = (size_t)first + min(j + (uint32_t)i, ninst - 1u);   // clamped: branch-free loads
+            m0[i] = part[3 * row];
+            m1[i] = part[3 * row + 1];
+            m2[i] = part[3 * row + 2];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (j + (uint32_t)i < ninst) {
+                S[0] += m0[i].x; S[1] += m0[i].y; S[2] += m0[i].z; S[3] += m0[i].w;
+                S[4] += m1[i].x; S[5] += m1[i].y; S[6] += m1[i].z; S[7] += m1[i].w;
+                S[8] += m2[i].x; S[9] += m2[i].y;
+            }
     }
     // ---- 2. the reference's accumulated sums (VOX/backward.cu:345-370), inverse covariance un-scaled
     const float4 r0 = rec[3 * idx], r1 = rec[3 * idx + 1], r2 = rec[3 * idx + 2];
