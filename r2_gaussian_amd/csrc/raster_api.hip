@@ -154,7 +154,7 @@ extern "C" int r2_raster_forward(
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
-    // single-pass sort: the combine kernel (one workgroup per tile) also writes tiles[k] for the backward
+    // single-pass sort: the tile's last work item (or the combine kernel) also writes tiles[k] for the backward
     launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
                                  /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
