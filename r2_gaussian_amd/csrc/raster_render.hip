@@ -1,27 +1,24 @@
 // raster_render.hip -- per-tile additive line-integral render of the X-ray rasterizer and its backward.
 //
 // Reference: renderCUDA forward RAS/forward.cu:294-395, renderCUDA backward RAS/backward.cu:447-575.
-// These kernels are VALU/exp-bound (256 pixel-Gaussian pairs per 32 bytes gathered; ~15 VALU issue slots
-// per pair, v_exp_f32 alone costs ~7 of them), so this file is compiled with FMA contraction ON and
-// without SLP packing; results are tolerance-checked, not bit-checked.
+// 256 pixel-Gaussian pairs per 32 bytes gathered: never HBM-bound; compiled with FMA contraction ON and without SLP
+// packing; results are tolerance-checked, not bit-checked.  What bounds them today is in DESIGN.md section 4.
 //
-// Forward : a tile's depth-sorted list is cut into work items of FWD_CHUNK instances.  One workgroup =
-//           one work item = 4 waves of 16x4 pixels; records are staged through LDS in 256-record batches
-//           (32-byte packed records, two b128 gathers each) and read back as wave-uniform broadcasts.
-//           Each work item writes 256 partial pixel sums; a second tiny kernel adds a tile's partials IN
-//           LIST ORDER, so the image is deterministic.  Cutting the lists is what balances the machine:
-//           list lengths span 0..9000 on the benchmark scene (median 50), and a workgroup per tile left
-//           most CUs idle behind a few dense tiles.
-// Backward: the loop nest is inverted.  One LANE owns one (tile, Gaussian) instance of the sorted list and
-//           walks the 256 pixels of its tile; dL/dpix of the tile is staged once per wave in LDS and read
-//           as b128 broadcasts.  The 7 gradient sums of the reference are linear in 6 moments
+// Forward : a tile's depth-sorted list is cut into work items of FWD_CHUNK instances (list lengths span 0..9000 on the
+//           benchmark scene, median 50: a workgroup per tile left most CUs idle behind a few dense tiles).  One
+//           workgroup = one work item; its 4 waves own the tile's four 8x8 pixel blocks; records are staged through LDS
+//           in 256-record batches; one LANE evaluates one record against the 64 pixels of the block (see below).  Each
+//           work item produces 256 partial pixel sums; the tile's LAST work item to finish adds them IN LIST ORDER, so
+//           the image is deterministic.
+// Backward: one LANE owns one 8x8 block of one (tile, Gaussian) instance of the sorted list; dL/dpix of the wave's tiles
+//           is staged in LDS.  The 7 gradient sums of the reference are linear in 6 moments
 //           sum(w), sum(w dx), sum(w dy), sum(w dx^2), sum(w dx dy), sum(w dy^2), w = G*dL/dpix,
-//           accumulated in registers: no cross-lane reduction, and NO atomics -- each instance stores its
-//           moment row to scratch at its EMISSION index (recomputed from the Gaussian's tile rectangle; contiguous
-//           per Gaussian), which the geometry backward then reduces in a fixed order.  Gradients are therefore bit-reproducible,
-//           unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
-//           Workgroups (one wave each) are cut as 64 consecutive instances of the global sorted list: perfect balance.
-//           Waves that straddle many sparse tiles (image borders) take their tiles three at a time.
+//           accumulated in registers: NO atomics -- each instance adds its blocks' rows in a fixed order and stores its
+//           moment row to scratch at its EMISSION index (recomputed from the Gaussian's tile rectangle; contiguous per
+//           Gaussian), which the geometry backward then reduces in a fixed order.  Gradients are therefore
+//           bit-reproducible, unlike the reference's float atomicAdd accumulation (RAS/backward.cu:562-572).
+//           One-wave workgroups walk chunks of 64 consecutive instances of the global sorted list (software-pipelined);
+//           waves that straddle many sparse tiles (image borders) take their tiles three at a time.
 //           The reference's n_contrib skip (RAS/backward.cu:523-525) only prunes pairs that failed the
 //           forward tests; re-evaluating the tests prunes the same pairs, so n_contrib is not needed.
 #include "raster_state.hpp"
