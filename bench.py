@@ -117,15 +117,19 @@ def main():
         if use_comm:
             i = k & 1
             if pending[i] is not None:
-                pending[i].wait()          # the reduction that last used this buffer (two steps ago) is done
-            r2dist.pack_grads(xyz.grad, dens.grad, scal.grad, rot.grad, out=flats[i])
-            pending[i] = r2dist.allreduce_grads(flats[i], average=False, async_op=True)
+                pending[i][0].wait()       # the reduction started two steps ago is done
+            # the backward leaves the four parameter gradients adjacent in one buffer: reduce them where they are
+            blk = r2dist.grad_block(xyz.grad, dens.grad, scal.grad, rot.grad)
+            if blk is None:
+                blk = r2dist.pack_grads(xyz.grad, dens.grad, scal.grad, rot.grad, out=flats[i])
+            stats["zero_copy"] = blk is not flats[i]
+            pending[i] = (r2dist.allreduce_grads(blk, average=False, async_op=True), blk)   # keep the buffer alive
         return img
 
     def drain():
         for i in range(2):
             if pending[i] is not None:
-                pending[i].wait()
+                pending[i][0].wait()
                 pending[i] = None
 
     def barrier():
@@ -274,7 +278,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic 0_chest_cone-like cone-beam set: %d Gaussians (seed 0), %dx%d detector, "
                                    "%d views, DSD 7 / DSO 5" % (P, HW, HW, args.views),
-                       "num_rendered": R, "parallelism": "view-sharded dp%d + RCCL all-reduce of [P,11] grads (overlapped with the next view)" % world
+                       "num_rendered": R, "parallelism": "view-sharded dp%d + RCCL all-reduce of [P,11] grads (%s, overlapped with the next view)" % (
+                           world, "in place, zero-copy" if stats.get("zero_copy") else "packed copy")
                        if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -282,6 +287,7 @@ def main():
                          "pipeline_frac": round(total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_alg_bytes": total_bytes},
             "cpu_baseline": cpu,
+            "comm_zero_copy": stats.get("zero_copy") if use_comm else None,
             # host time per step spent waiting for num_rendered at the forward's sync: large = GPU-bound step
             "host_wait_us_per_step": round(wait_us / max(wait_n, 1), 1),
             "host_cpus_pinned": len(pinned) if pinned else None,

@@ -205,15 +205,18 @@ def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifi
     flat = torch.empty(25 * P, dtype=_F32, device=dev)
     # 8 arrays carved out of `flat` (16-byte rows first) with one as_strided each -- this function runs on the autograd
     # engine's critical path, every avoided tensor op is ~2 us of host time per training view
+    # order: conic and rot first (their rows are written 16 bytes at a time), then the four parameter gradients a trainer
+    # exchanges between GPUs ADJACENT to each other -- rot | means3D | scales | opacity = one contiguous [11 P] block that
+    # dist.grad_block() hands to the all-reduce without a packing copy
     o = 0
     dL_dconic = flat.as_strided((P, 2, 2), (4, 2, 1), o); o += 4 * P
     dL_drot = flat.as_strided((P, 4), (4, 1), o); o += 4 * P
     dL_dmeans3D = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
-    dL_dmeans2D = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
+    dL_dscales = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
     dL_dopacity = flat.as_strided((P, 1), (1, 1), o); o += P
+    dL_dmeans2D = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
     dL_dmu = flat.as_strided((P, 1), (1, 1), o); o += P
-    dL_dcov3D = flat.as_strided((P, 6), (6, 1), o); o += 6 * P
-    dL_dscales = flat.as_strided((P, 3), (3, 1), o)
+    dL_dcov3D = flat.as_strided((P, 6), (6, 1), o)
     if P != 0:
         m3 = _dev_f32(means3D, means3D)
         sc, ro, cp = (_dev_f32(t, means3D) for t in (scales, rotations, cov3D_precomp))

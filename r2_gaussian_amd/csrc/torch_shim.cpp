@@ -121,8 +121,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_gau
         o += k * P;
         return v;
     };
-    Tensor dL_dconic = carve(4, {P, 2, 2}), dL_drot = carve(4, {P, 4}), dL_dmeans3D = carve(3, {P, 3}), dL_dmeans2D = carve(3, {P, 3}),
-           dL_dopacity = carve(1, {P, 1}), dL_dmu = carve(1, {P, 1}), dL_dcov3D = carve(6, {P, 6}), dL_dscales = carve(3, {P, 3});
+    // conic and rot first (16-byte rows), then the four parameter gradients a trainer exchanges between GPUs ADJACENT to
+    // each other: rot | means3D | scales | opacity = one contiguous [11 P] block (dist.grad_block: all-reduce without a copy)
+    Tensor dL_dconic = carve(4, {P, 2, 2}), dL_drot = carve(4, {P, 4}), dL_dmeans3D = carve(3, {P, 3}), dL_dscales = carve(3, {P, 3}),
+           dL_dopacity = carve(1, {P, 1}), dL_dmeans2D = carve(3, {P, 3}), dL_dmu = carve(1, {P, 1}), dL_dcov3D = carve(6, {P, 6});
     if (P != 0) {
         const Tensor m3 = dev_f32(means3D, dev), sc = dev_f32(scales, dev), ro = dev_f32(rotations, dev),
                      cp = dev_f32(cov3D_precomp, dev), vm = dev_f32(viewmatrix, dev), pm = dev_f32(projmatrix, dev),

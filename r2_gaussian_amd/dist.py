@@ -82,6 +82,27 @@ def pack_grads(g_xyz, g_density, g_scaling, g_rotation, out=None):
     return out
 
 
+def grad_block(g_xyz, g_density, g_scaling, g_rotation):
+    """The drop-in backward carves its gradients out of one buffer with rotation | xyz | scaling | density adjacent: if
+    these four tensors are that block, return it as ONE flat [11 P] view (all-reduce it in place: no packing copy, the
+    .grad tensors are reduced where they are); otherwise None (use pack_grads)."""
+    P = g_xyz.shape[0]
+    ts = (g_rotation, g_xyz, g_scaling, g_density)
+    if P == 0 or any(t is None or not t.is_contiguous() or t.dtype != torch.float32 for t in ts):
+        return None
+    try:
+        if len({t.untyped_storage().data_ptr() for t in ts}) != 1:
+            return None
+    except Exception:
+        return None
+    o = g_rotation.storage_offset()
+    if (g_xyz.storage_offset(), g_scaling.storage_offset(), g_density.storage_offset()) != (o + 4 * P, o + 7 * P, o + 10 * P):
+        return None
+    if g_rotation.numel() != 4 * P or g_xyz.numel() != 3 * P or g_scaling.numel() != 3 * P or g_density.numel() != P:
+        return None
+    return g_rotation.as_strided((GRAD_WIDTH * P,), (1,), o)
+
+
 def unpack_grads(flat):
     return flat[:, 0:3], flat[:, 3:4], flat[:, 4:7], flat[:, 7:11]
 

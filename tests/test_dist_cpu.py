@@ -122,3 +122,31 @@ def test_voxel_slab_settings_tile_the_volume():
             assert abs(full_c - slab_c) < 1e-9
         assert cover[0][0] == 0 and cover[-1][1] == nx
         assert all(a[1] == b[0] for a, b in zip(cover[:-1], cover[1:]))
+
+
+def test_grad_block_detects_the_backward_layout():
+    """The drop-in backward carves rotation | xyz | scaling | density adjacent out of one buffer: dist.grad_block must hand
+    that block out as one flat view (in-place all-reduce, no packing copy) and refuse anything else."""
+    import torch
+    from r2_gaussian_amd import dist as D
+    P = 37
+    flat = torch.arange(25 * P, dtype=torch.float32)
+    o = 0
+    conic = flat.as_strided((P, 2, 2), (4, 2, 1), o); o += 4 * P
+    rot = flat.as_strided((P, 4), (4, 1), o); o += 4 * P
+    xyz = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
+    scal = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
+    dens = flat.as_strided((P, 1), (1, 1), o); o += P
+    blk = D.grad_block(xyz, dens, scal, rot)
+    assert blk is not None and blk.shape == (11 * P,)
+    assert blk.data_ptr() == rot.data_ptr() and torch.equal(blk, flat[4 * P:15 * P])
+    blk.mul_(2.0)   # in place: the four gradients see it
+    assert torch.equal(xyz, flat.as_strided((P, 3), (3, 1), 8 * P)) and float(xyz[0, 0]) == 2.0 * (8 * P)
+    # not the backward's layout: separate tensors, wrong order, non-contiguous
+    assert D.grad_block(xyz.clone(), dens, scal, rot) is None
+    assert D.grad_block(scal, dens, xyz, rot) is None
+    assert D.grad_block(xyz, dens, scal, conic.reshape(P, 4)) is None
+    # and the packed fallback still round-trips
+    packed = D.pack_grads(xyz, dens, scal, rot)
+    gx, gd, gs, gr = D.unpack_grads(packed)
+    assert torch.equal(gx, xyz) and torch.equal(gd, dens) and torch.equal(gs, scal) and torch.equal(gr, rot)
