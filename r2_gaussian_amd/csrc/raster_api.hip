@@ -124,7 +124,8 @@ extern "C" int r2_raster_forward(
         { StageScope t(ST_RAS_DUPLICATE, s);
         launch_raster_duplicate(geom, bin, P, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
-        const int bit = (int)higher_msb((uint32_t)T);
+        const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
+                                                                     // sorts getHigherMsb(T) bits: one more for T = 2^k)
         // stable sort by tile id; payloads: the emission index (-> perm, the backward's scratch row) and the Gaussian
         // id (-> point_list)
         { StageScope t(ST_RAS_SORT, s);

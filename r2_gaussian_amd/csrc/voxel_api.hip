@@ -125,7 +125,8 @@ extern "C" int r2_voxel_forward(
         { StageScope t(ST_VOX_DUPLICATE, s);
         launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
-        const int bit = (int)higher_msb((uint32_t)T);
+        const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
+                                                                     // sorts getHigherMsb(T) bits: one more for T = 2^k)
         { StageScope t(ST_VOX_SORT, s);
         if (sort_is_single_pass(bit)) {   // block 0 of the sort's last kernel also builds tile ranges + work list
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(R), nullptr,
@@ -182,7 +183,7 @@ extern "C" int r2_voxel_backward(
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
     const size_t T = (size_t)v.gx * v.gy * v.gz;
-    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)T))) {
+    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1)))) {
         if (!img_buffer) {
             set_error("r2_voxel_backward: image state required");
             return R2_ERR_INVALID;

@@ -159,7 +159,7 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
     out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
-    if int(T).bit_length() <= 12:   # the inverse permutation is only written by the single-pass (<= 12-bit) tile sort
+    if max(int(T) - 1, 1).bit_length() <= 12:   # the inverse permutation is only written by the single-pass (<= 12-bit) tile sort
         out["inv"] = read(13, np.uint32, R)
         out["perm"] = perm_from_inv(out["inv"])
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
