@@ -1,36 +1,59 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native R2-Gaussian hot path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats M]
 
 Metric (BASELINE.json): rasterized X-ray views/s (forward + backward) at 300k Gaussians on a 512^2 cone-beam
 detector, plus voxelizer GVoxel/s at 300k Gaussians / 256^3 (reported in the same JSON line).
 
-A "step" = one training view through the drop-in surface: GaussianRasterizer forward (autograd) + backward
-with a fixed upstream gradient dL/dpix, i.e. r2_raster_forward + r2_raster_backward of the C ABI, inputs
-resident in HBM.  With N > 1 ranks (launched by torch.distributed.run, one per GPU) every rank renders its
-own view of the 50-view training set and the packed [P,11] parameter gradients are all-reduced over
-RCCL/xGMI each step (weak scaling: per-GPU work fixed).  value = all views of all ranks / max-over-ranks time.
+A "step" = one training view through the drop-in surface: GaussianRasterizer forward (autograd) + backward with a
+fixed upstream gradient dL/dpix, i.e. r2_raster_forward + r2_raster_backward of the C ABI, inputs resident in HBM.
+
+--gpus N > 1: one process per GPU.  When WORLD_SIZE is not set the script launches its own N ranks (re-exec through
+torch.distributed.run on 127.0.0.1); under a launcher it checks that the world it finds IS N.  Every rank renders its own
+view of the 50-view training set and the [P,11] parameter gradients are all-reduced over RCCL/xGMI each step (weak scaling:
+per-GPU work fixed).  `value` is the SYNCHRONOUS mode: the all-reduce of step k is ordered before step k+1 on the stream
+(what a trainer that applies every step's gradients needs, and what a PSNR study would be run with); `overlapped` in the
+same line is the pipelined mode (the reduction of step k runs while step k+1 renders; gradients arrive one step late).
+
+Timing: W untimed warm-up steps, then M (--repeats) regions of EXACTLY K steps, each bracketed by barrier +
+torch.cuda.synchronize() on both sides and reduced with MAX over ranks; `value` = all views of all ranks / the MEDIAN
+region (min / max / spread are in `timing`): a 20-step driver run is then 25 samples, not one 5 ms sample.
 
 The JSON line also carries
-  roofline     -- dominant kernel: algorithmic bytes per launch / HIP-event duration vs the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, oracle/r2_oracle.c) timed on the host
-                  cores for ONE view of the same workload (rank 0, N == 1 only)
-  kernels      -- per-stage HIP-event breakdown from a second, instrumented pass (not part of `value`)
+  roofline       dominant kernel (picked from an instrumented pre-pass): algorithmic bytes per launch / its HIP-event duration
+                 measured live inside the timed regions, vs the 8 TB/s HBM peak; `traffic` = FETCH_SIZE + WRITE_SIZE of that
+                 kernel from the committed PMC summary, accepted only if it was collected on the same kernel sources
+  cpu_baseline   the CPU oracle (C/OpenMP port of the reference algorithm, oracle/r2_oracle.c) timed on the host cores for
+                 ONE view of the same workload (rank 0, N == 1 only)
+  parity_checked the SAME view's GPU image and gradients checked against that oracle result (pure 1e-4 relative bound +
+                 attributed cut-off flips, oracle/parity.py); the run FAILS when it is out of tolerance
+  forward_only   views/s of the forward alone
+  kernels        per-stage HIP-event breakdown + achieved fraction of the HBM peak, from an instrumented pass (not in `value`)
 Synthetic seeded data (no datasets offline), random Gaussian cloud of the named size.
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+# stage (r2_profile_* name) -> kernel name in the rocprofv3 / PMC summaries
+STAGE_KERNEL = {
+    "raster.render_bwd": "r2::raster_render_backward_kernel",
+    "raster.render_fwd": "r2::raster_render_forward_kernel<false, true>",
+    "raster.geom_bwd": "r2::raster_geom_backward_kernel",
+    "raster.preprocess": "r2::raster_preprocess_kernel",
+    "raster.duplicate": "r2::raster_duplicate_kernel",
+}
 
 
 def algorithmic_bytes(stage, P, R, T, N):
@@ -50,132 +73,279 @@ def algorithmic_bytes(stage, P, R, T, N):
     return table.get(stage, 0)
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(n):
+    """No launcher around us but --gpus n > 1: start our own n ranks, one per GPU, and hand their exit code back."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+class StepRunner:
+    """The step / exchange / drain logic of the data-parallel bench, independent of what renders: `render(k)` runs forward +
+    backward of step k on this rank and returns the flat gradient block to exchange.  mode "sync": the all-reduce is waited for
+    (stream-ordered) before the step returns; "overlap": it is waited for two steps later (double-buffered)."""
+
+    def __init__(self, render, allreduce, use_comm, mode="sync"):
+        self.render, self.allreduce, self.use_comm, self.mode = render, allreduce, use_comm, mode
+        self.pending = [None, None]
+
+    def step(self, k):
+        i = k & 1
+        if self.use_comm and self.mode == "overlap" and self.pending[i] is not None:
+            self.pending[i][0].wait()          # the reduction started two steps ago is done: its buffer may be reused
+            self.pending[i] = None
+        blk = self.render(k, i)
+        if self.use_comm:
+            h = self.allreduce(blk)
+            if self.mode == "sync":
+                h.wait()                       # stream-ordered: whatever runs next on this stream sees the reduced sum
+            else:
+                self.pending[i] = (h, blk)     # keep the buffer alive
+
+    def drain(self):
+        for i in range(2):
+            if self.pending[i] is not None:
+                self.pending[i][0].wait()
+                self.pending[i] = None
+
+
+def timed_regions(runner, steps, repeats, first_step, barrier, max_over_ranks):
+    """`repeats` regions of exactly `steps` steps, each bracketed by barrier + synchronize; -> per-region seconds (max over ranks)."""
+    out = []
+    k = first_step
+    for _ in range(repeats):
+        barrier()
+        t0 = time.perf_counter()
+        for _i in range(steps):
+            runner.step(k)
+            k += 1
+        runner.drain()
+        barrier()
+        out.append(max_over_ranks(time.perf_counter() - t0))
+    return out, k
+
+
+def summarize(region_s, steps, world):
+    med = statistics.median(region_s)
+    return {"value": round(steps * world / med, 2), "ms_per_step": round(1e3 * med / steps, 4),
+            "regions": len(region_s), "ms_per_step_min": round(1e3 * min(region_s) / steps, 4),
+            "ms_per_step_max": round(1e3 * max(region_s) / steps, 4),
+            "spread": round((max(region_s) - min(region_s)) / med, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--repeats", type=int, default=0, help="timed regions of --steps steps (default: 25, or 5 when steps >= 500)")
     ap.add_argument("--gaussians", type=int, default=300000)
     ap.add_argument("--detector", type=int, default=512)
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-voxel", action="store_true")
     args = ap.parse_args()
+    repeats = args.repeats or (5 if args.steps >= 500 else 25)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
+    import torch
     import torch.distributed as dist
-    from r2_gaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
     from r2_gaussian_amd import dist as r2dist
     from r2_gaussian_amd import scene as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks" % (args.gpus, world))
+    # R2_BENCH_STUB=1 (tests/test_dist_cpu.py): exercise launcher + step/exchange/drain logic on CPU over gloo with a
+    # stub in place of the renderer -- no number from such a run means anything and the line says so
+    stub = os.environ.get("R2_BENCH_STUB", "0") == "1"
+    if not stub and not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     all_cpus = os.sched_getaffinity(0)
-    pinned = r2dist.pin_to_gpu_numa_node(local_rank)   # one process per GPU, on a slice of the GPU's own socket
-    if world > 1 or os.environ.get("R2_BENCH_FORCE_COMM", "0") == "1":
+    pinned = None
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        pinned = r2dist.pin_to_gpu_numa_node(local_rank)   # one process per GPU, on a slice of the GPU's own socket
+    force_comm = os.environ.get("R2_BENCH_FORCE_COMM", "0") == "1"   # exercise the collective path on one GPU
+    if world > 1 or force_comm:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29513")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    _lib.lib()
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        assert dist.get_world_size() == args.gpus, "process group size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
+    use_comm = dist.is_initialized()
 
     P, HW = args.gaussians, args.detector
-    cloud = S.make_cloud(P, seed=0)
     views = S.make_views(args.views, (HW, HW))
-    xyz = cloud.xyz.to(dev).requires_grad_(True)
-    dens = cloud.density.to(dev).requires_grad_(True)
-    scal = cloud.scales.to(dev).requires_grad_(True)
-    rot = cloud.rotations.to(dev).requires_grad_(True)
-    params = (xyz, dens, scal, rot)
-    dL = S.make_pixel_grad(HW, HW).to(dev)
-    settings = [GaussianRasterizationSettings(
-        image_height=HW, image_width=HW, tanfovx=v.tanfovx, tanfovy=v.tanfovy, scale_modifier=1.0,
-        viewmatrix=v.world_view_transform.to(dev), projmatrix=v.full_proj_transform.to(dev),
-        campos=v.camera_center.to(dev), prefiltered=False, mode=v.mode, debug=False) for v in views]
-    rasterizers = [GaussianRasterizer(s) for s in settings]
-    # N > 1: the packed [P,11] gradients of step k are all-reduced (RCCL, its own stream) WHILE step k+1 renders: two
-    # flat buffers, each waited for before it is packed again and all of them before the clock stops.  Every step's
-    # reduction is complete inside the timed region; a trainer consumes it one step late (pipelined data parallelism) or
-    # accumulates several views per optimiser step.
-    force_comm = os.environ.get("R2_BENCH_FORCE_COMM", "0") == "1"   # exercise the collective path on one GPU (tests)
-    use_comm = world > 1 or (force_comm and dist.is_initialized())
-    flats = [torch.empty((P, r2dist.GRAD_WIDTH), dtype=torch.float32, device=dev) for _ in range(2)]
-    pending = [None, None]
     stats = {"R": 0}
+    flats = [torch.empty((P, r2dist.GRAD_WIDTH), dtype=torch.float32, device=dev) for _ in range(2)]
 
-    # the screen-space placeholder whose only role is to receive dL/dmeans2D (render_query.py:113-120): an input like
-    # the parameters, resident before the timed region
-    means2D = torch.zeros_like(xyz, requires_grad=True)
+    if stub:
+        g = torch.Generator().manual_seed(rank)
 
-    def step(k):
-        vi = r2dist.view_for(k, len(views), rank_=rank, world_=world)
-        img, radii = rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
-        means2D.grad = None
-        for p in params:
-            p.grad = None
-        img.backward(dL)
-        stats["R"] = img.grad_fn.num_rendered if hasattr(img.grad_fn, "num_rendered") else stats["R"]
-        if use_comm:
-            i = k & 1
-            if pending[i] is not None:
-                pending[i][0].wait()       # the reduction started two steps ago is done
+        def render(k, i):
+            flats[i].copy_(torch.rand(P, r2dist.GRAD_WIDTH, generator=g))
+            return flats[i]
+        _lib = None
+    else:
+        from r2_gaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
+        _lib.lib()
+        cloud = S.make_cloud(P, seed=0)
+        xyz = cloud.xyz.to(dev).requires_grad_(True)
+        dens = cloud.density.to(dev).requires_grad_(True)
+        scal = cloud.scales.to(dev).requires_grad_(True)
+        rot = cloud.rotations.to(dev).requires_grad_(True)
+        params = (xyz, dens, scal, rot)
+        dL = S.make_pixel_grad(HW, HW).to(dev)
+        settings = [GaussianRasterizationSettings(
+            image_height=HW, image_width=HW, tanfovx=v.tanfovx, tanfovy=v.tanfovy, scale_modifier=1.0,
+            viewmatrix=v.world_view_transform.to(dev), projmatrix=v.full_proj_transform.to(dev),
+            campos=v.camera_center.to(dev), prefiltered=False, mode=v.mode, debug=False) for v in views]
+        rasterizers = [GaussianRasterizer(s) for s in settings]
+        # the screen-space placeholder whose only role is to receive dL/dmeans2D (render_query.py:113-120): an input like
+        # the parameters, resident before the timed region
+        means2D = torch.zeros_like(xyz, requires_grad=True)
+
+        def render(k, i):
+            vi = r2dist.view_for(k, len(views), rank_=rank, world_=world)
+            img, _radii = rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
+            means2D.grad = None
+            for p in params:
+                p.grad = None
+            img.backward(dL)
+            if not use_comm:
+                return None
             # the backward leaves the four parameter gradients adjacent in one buffer: reduce them where they are
             blk = r2dist.grad_block(xyz.grad, dens.grad, scal.grad, rot.grad)
             if blk is None:
                 blk = r2dist.pack_grads(xyz.grad, dens.grad, scal.grad, rot.grad, out=flats[i])
             stats["zero_copy"] = blk is not flats[i]
-            pending[i] = (r2dist.allreduce_grads(blk, average=False, async_op=True), blk)   # keep the buffer alive
-        return img
+            return blk
 
-    def drain():
-        for i in range(2):
-            if pending[i] is not None:
-                pending[i][0].wait()
-                pending[i] = None
+    def allreduce(blk):
+        return r2dist.allreduce_grads(blk, average=False, async_op=True)
 
     def barrier():
-        drain()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
+
+    def max_over_ranks(dt):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        return dt
 
     if os.environ.get("R2_BENCH_NOGC", "0") == "1":
         import gc
         gc.disable()
-    for k in range(args.warmup):
-        step(k)
-    # the dominant kernel is bracketed with HIP events on its own stream inside the timed region
-    DOMINANT = "raster.render_bwd"
-    _lib.profile_read(reset=True)
-    _lib.profile_enable([DOMINANT])
-    barrier()
-    _lib.sync_wait_stats(reset=True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    dt = time.perf_counter() - t0
-    wait_us, wait_n = _lib.sync_wait_stats(reset=True)
-    dom = _lib.profile_read(reset=True).get(DOMINANT, (0.0, 0))
-    _lib.profile_enable([])
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
 
-    # ---- second, instrumented pass: per-stage breakdown + R of the measured views (not part of `value`)
+    sync_runner = StepRunner(render, allreduce, use_comm, "sync")
+    k = 0
+    for _ in range(args.warmup):
+        sync_runner.step(k)
+        k += 1
+    sync_runner.drain()
+
+    # ---- instrumented pre-pass (untimed): which stage dominates -> that one is bracketed inside the timed regions
+    DOMINANT = "raster.render_bwd"
+    if not stub:
+        barrier()
+        _lib.profile_read(reset=True)
+        _lib.profile_enable(None)
+        for _ in range(min(10, max(args.steps, 1))):
+            sync_runner.step(k)
+            k += 1
+        sync_runner.drain()
+        barrier()
+        pre = _lib.profile_read(reset=True)
+        if pre:
+            DOMINANT = max(pre.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1))[0]
+        _lib.profile_enable([DOMINANT])
+        _lib.sync_wait_stats(reset=True)
+
+    # ---- the measurement
+    region_s, k = timed_regions(sync_runner, args.steps, repeats, k, barrier, max_over_ranks)
+    dom, wait_us, wait_n = (0.0, 0), 0.0, 0
+    if not stub:
+        wait_us, wait_n = _lib.sync_wait_stats(reset=True)
+        dom = _lib.profile_read(reset=True).get(DOMINANT, (0.0, 0))
+        _lib.profile_enable([])
+    main_t = summarize(region_s, args.steps, world)
+    overlapped = None
+    if use_comm:   # the pipelined mode, labelled as such, next to the synchronous number
+        ov_runner = StepRunner(render, allreduce, use_comm, "overlap")
+        for _ in range(min(args.warmup, 10)):
+            ov_runner.step(k)
+            k += 1
+        ov_runner.drain()
+        ov_s, k = timed_regions(ov_runner, args.steps, repeats, k, barrier, max_over_ranks)
+        overlapped = summarize(ov_s, args.steps, world)
+        overlapped["note"] = "all-reduce of step k overlaps the render of step k+1: gradients are consumed one step late"
+    dt_step = statistics.median(region_s) / args.steps
+
+    if stub:
+        if rank == 0:
+            print(json.dumps({"metric": "STUB renderer on CPU/gloo (launcher + exchange logic test only; not a measurement)",
+                              "value": main_t["value"], "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": main_t["ms_per_step"], "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
+                              "config": {"workload": "stub", "ranks_in_process_group": dist.get_world_size() if use_comm else 1},
+                              "timing": main_t, "overlapped": overlapped}))
+        if use_comm:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- forward-only views/s (SURVEY.md 8d), same views, no autograd
+    fwd_only = None
+    with torch.no_grad():
+        for j in range(10):
+            rasterizers[j % len(views)](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
+        fr = []
+        nf = max(20, min(args.steps, 200))
+        for _ in range(5):
+            barrier()
+            t0 = time.perf_counter()
+            for j in range(nf):
+                vi = r2dist.view_for(j, len(views), rank_=rank, world_=world)
+                rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
+            barrier()
+            fr.append(max_over_ranks(time.perf_counter() - t0))
+        fwd_only = summarize(fr, nf, world)
+
+    # ---- instrumented pass: per-stage breakdown (not part of `value`)
     _lib.profile_enable(None)
-    Rs = []
-    for k in range(min(args.steps, 50)):
-        img = step(args.warmup + k)
-        Rs.append(stats["R"])
+    for _ in range(min(args.steps, 50)):
+        sync_runner.step(k)
+        k += 1
+    sync_runner.drain()
     torch.cuda.synchronize()
     prof = _lib.profile_read(reset=True)
     _lib.profile_enable([])
-    # num_rendered of the measured views via the C mirror (the autograd ctx is gone by now)
+    # num_rendered of the measured views via the C mirror
     from r2_gaussian_amd import _C
     e = torch.empty(0)
     Rl = []
@@ -190,8 +360,9 @@ def main():
     for name, (ms, cnt) in sorted(prof.items()):
         us = 1e3 * ms / cnt
         b = algorithmic_bytes(name, P, R, T, N)
-        kernels[name] = {"us": round(us, 2), "alg_MB": round(b / 1e6, 2),
-                         "GBps": round(b / (us * 1e-6) / 1e9, 1) if us > 0 else None}
+        gbps = b / (us * 1e-6) / 1e9 if us > 0 else 0.0
+        kernels[name] = {"us": round(us, 2), "alg_MB": round(b / 1e6, 2), "GBps": round(gbps, 1),
+                         "frac": round(gbps / HBM_PEAK_GBS, 4)}
     dom_us = 1e3 * dom[0] / max(dom[1], 1)
     dom_bytes = algorithmic_bytes(DOMINANT, P, R, T, N)
     achieved = dom_bytes / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
@@ -204,13 +375,16 @@ def main():
             va = (xyz, dens, scal, rot, 1.0, e, 256, 256, 256, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, False, False)
             for _ in range(3):
                 R3 = _C.voxelize_gaussians(*va)[0]
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
+            tvs = []
             nv = 10
-            for _ in range(nv):
-                _C.voxelize_gaussians(*va)
-            torch.cuda.synchronize()
-            tv = (time.perf_counter() - t1) / nv
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _j in range(nv):
+                    _C.voxelize_gaussians(*va)
+                torch.cuda.synchronize()
+                tvs.append((time.perf_counter() - t1) / nv)
+            tv = statistics.median(tvs)
             _lib.profile_enable(None)       # per-stage breakdown of the same call (not part of the timing above)
             for _ in range(5):
                 _C.voxelize_gaussians(*va)
@@ -238,59 +412,105 @@ def main():
         torch.cuda.synchronize()
         ttv = (time.perf_counter() - t2) / 100
         vbytes = 168 * P + 88 * R3 + 16 * 32768 + 8 * 256 ** 3
-        gvox = {"gvoxel_per_s": round(256 ** 3 / tv / 1e9, 3), "ms": round(tv * 1e3, 3), "R3": int(R3),
-                "alg_MB": round(vbytes / 1e6, 1), "hbm_frac": round(vbytes / tv / 1e9 / HBM_PEAK_GBS, 4),
-                "stages_us": {k: round(1e3 * ms / cnt, 1) for k, (ms, cnt) in sorted(vprof.items()) if k.startswith("voxel.")},
+        gvox = {"gvoxel_per_s": round(256 ** 3 / tv / 1e9, 3), "ms": round(tv * 1e3, 3), "ms_min": round(min(tvs) * 1e3, 3),
+                "R3": int(R3), "alg_MB": round(vbytes / 1e6, 1), "hbm_frac": round(vbytes / tv / 1e9 / HBM_PEAK_GBS, 4),
+                "stages_us": {k_: round(1e3 * ms / cnt, 1) for k_, (ms, cnt) in sorted(vprof.items()) if k_.startswith("voxel.")},
                 "tv_patch_32cube_fwd_bwd_us": round(ttv * 1e6, 1)}
 
-    # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores, one view
-    cpu = None
+    # ---- CPU baseline + parity self-check: the oracle on the host cores, ONE view; the same view's GPU result is checked
+    # against it before the line is printed
+    cpu, parity = None, None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         os.sched_setaffinity(0, all_cpus)   # the CPU baseline may use every host core again
         from oracle import oracle as O
+        from oracle import parity as Pz
         O.lib()
         v = views[0]
         xn, dn, sn, qn = (t.detach().cpu().numpy() for t in (xyz, dens, scal, rot))
         vm, pm = v.world_view_transform.numpy(), v.full_proj_transform.numpy()
+        dLn = dL.cpu().numpy()
         tc = time.perf_counter()
         st = O.raster_forward(xn, dn, sn, qn, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, HW, HW, v.mode)
-        O.raster_backward(st, xn, sn, qn, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL.cpu().numpy(), acc64=False)
+        O.raster_backward(st, xn, sn, qn, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dLn, acc64=False)
         tc = time.perf_counter() - tc
-        cpu = {"value": round(1.0 / tc, 4), "unit": "views/s", "cores": int(O.lib().r2o_num_threads()), "kind": "port",
-               "sample": "1 view fwd+bwd of the same workload (%dk Gaussians, %d^2, R=%d) by oracle/r2_oracle.c, OpenMP"
-                         % (P // 1000, HW, st["num_rendered"])}
+        nthr = int(O.lib().r2o_num_threads())
+        cpu = {"value": round(1.0 / tc, 4), "unit": "views/s", "cores": nthr, "kind": "port",
+               "what": "C/OpenMP port of the reference algorithm (oracle/r2_oracle.c), %d threads; NOT the pure-PyTorch "
+                       "evaluation north_star mentions -- a stronger CPU baseline" % nthr,
+               "sample": "1 view fwd+bwd of the same workload (%dk Gaussians, %d^2, R=%d)" % (P // 1000, HW, st["num_rendered"])}
+        s0 = settings[0]
+        with torch.no_grad():
+            Rg, color, radii, gb, bb, ib = _C.rasterize_gaussians(xyz, dens, scal, rot, 1.0, e, s0.viewmatrix, s0.projmatrix,
+                                                                  s0.tanfovx, s0.tanfovy, HW, HW, s0.campos, False, s0.mode, False)
+            res = _C.rasterize_gaussians_backward(xyz, radii, scal, rot, 1.0, e, s0.viewmatrix, s0.projmatrix, s0.tanfovx,
+                                                  s0.tanfovy, dL, s0.campos, gb, Rg, bb, ib, s0.mode, False)
+        torch.cuda.synchronize()
+        names = ["dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"]
+        gh = {n_: t.cpu().numpy() for n_, t in zip(names, res)}
+        parity = {"view": 0, "rtol": Pz.RTOL, "ok": False}
+        try:
+            assert Rg == st["num_rendered"], "num_rendered %d != oracle %d" % (Rg, st["num_rendered"])
+            assert (radii.cpu().numpy() == st["radii"]).all(), "radii differ from the oracle"
+            budget, _nb = O.raster_forward_audit(st)
+            si = Pz.image_parity(color.cpu().numpy(), st["color"], budget)
+            sg = Pz.raster_grad_parity(O, st, dLn, gh, xn, sn, qn, 1.0, None, vm, pm, v.tanfovx, v.tanfovy)
+            parity.update({"ok": True, "num_rendered_equal": True, "radii_equal": True,
+                           "max_rel_err": si["max_rel_err"], "n_flip_pixels": si["n_flips"],
+                           "n_flip_candidate_pixels": si["n_flip_candidates"],
+                           "grad_max_err_over_tol": round(max(sg[n_]["max_err_over_tol"] for n_ in names if n_ in sg), 5),
+                           "grad_max_err_over_scale": max(sg[n_]["max_err_over_scale_unflagged"] for n_ in names if n_ in sg),
+                           "n_flip_candidate_gaussians": sg["n_flip_candidates"]})
+        except AssertionError as ex:
+            parity["error"] = str(ex)[:1500]
 
     # HBM traffic of the dominant kernel from the TCC counters (FETCH_SIZE / WRITE_SIZE, one counter per rocprofv3 pass:
-    # scripts/gpu_pmc.sh; the summary it writes is committed under profiles/).  bench.py cannot collect PMCs itself.
-    traffic = None
+    # scripts/gpu_pmc.sh; the summary it writes is committed under profiles/).  bench.py cannot collect PMCs itself; the
+    # summary is accepted only when it was collected on the kernel sources this library was built from.
+    traffic, traffic_note = None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
+            from r2_gaussian_amd import build as r2build
             pmc = json.load(open(pmc_path))
-            k = pmc.get("r2::raster_render_backward_kernel", {})
-            if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
-                traffic = int((k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024)   # counters are in KB, per launch
-        except Exception:
-            traffic = None
+            have, want = pmc.get("_meta", {}).get("source_sha"), r2build.source_hash()
+            kq = pmc.get(STAGE_KERNEL.get(DOMINANT, ""), {})
+            if have != want:
+                traffic_note = "profiles/pmc_latest.json was collected on other kernel sources (%s != %s): not used" % (
+                    str(have)[:12], want[:12])
+            elif "FETCH_SIZE" in kq and "WRITE_SIZE" in kq:
+                traffic = int((kq["FETCH_SIZE"] + kq["WRITE_SIZE"]) * 1024)   # counters are in KB, per launch
+                traffic_note = "FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes (profiles/pmc_latest.json, " \
+                               "sources %s); gfx950 FETCH_SIZE under-reports 16 B/lane streaming reads by 2x (uncorrected " \
+                               "here: the kernel gathers)" % want[:12]
+        except Exception as ex:
+            traffic_note = "pmc summary unreadable: %r" % (ex,)
 
     if rank == 0:
-        total_views = args.steps * world
+        if world > 1:
+            par = "view-sharded dp%d, RCCL all-reduce of [P,11] grads (%s), %d ranks in the process group; value = synchronous" % (
+                world, "in place, zero-copy" if stats.get("zero_copy") else "packed copy", dist.get_world_size())
+        else:
+            par = "single GPU"
         out = {
             "metric": "rasterized X-ray views/sec (fwd+bwd) at 300k Gaussians, 512^2 cone-beam detector",
-            "value": round(total_views / dt, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            "value": main_t["value"], "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": main_t["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "synthetic 0_chest_cone-like cone-beam set: %d Gaussians (seed 0), %dx%d detector, "
                                    "%d views, DSD 7 / DSO 5" % (P, HW, HW, args.views),
-                       "num_rendered": R, "parallelism": "view-sharded dp%d + RCCL all-reduce of [P,11] grads (%s, overlapped with the next view)" % (
-                           world, "in place, zero-copy" if stats.get("zero_copy") else "packed copy")
-                       if world > 1 else "single GPU"},
+                       "num_rendered": R, "parallelism": par},
+            "timing": dict(main_t, note="median of %d regions of exactly %d steps, each between barrier + synchronize, "
+                                        "max over ranks" % (repeats, args.steps)),
+            "overlapped": overlapped,
+            "forward_only": fwd_only,
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "us_per_launch": round(dom_us, 2), "alg_bytes_per_launch": dom_bytes,
-                         "pipeline_frac": round(total_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
+                         "traffic_note": traffic_note, "us_per_launch": round(dom_us, 2), "launches_timed": int(dom[1]),
+                         "alg_bytes_per_launch": dom_bytes,
+                         "pipeline_frac": round(total_bytes / dt_step / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_alg_bytes": total_bytes},
             "cpu_baseline": cpu,
+            "parity_checked": parity,
             "comm_zero_copy": stats.get("zero_copy") if use_comm else None,
             # host time per step spent waiting for num_rendered at the forward's sync: large = GPU-bound step
             "host_wait_us_per_step": round(wait_us / max(wait_n, 1), 1),
@@ -303,6 +523,9 @@ def main():
         if world > 1:
             dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity["ok"]:
+        sys.stderr.write("bench.py: PARITY CHECK FAILED: %s\n" % parity.get("error"))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

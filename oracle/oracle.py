@@ -176,6 +176,63 @@ def raster_backward(st, means3D, scales, rotations, scale_modifier, cov3D_precom
     return g
 
 
+def raster_forward_audit(st):
+    """Per pixel: (flip_budget, n_border) -- how much of the pixel hangs on pairs that sit ON one of the reference's cut-off
+    tests (see the AUDIT section of r2_oracle.c).  A parity test asserts |got - ref| <= rtol*|ref| + flip_budget."""
+    H, W = st["H"], st["W"]
+    budget, nb = np.zeros((1, H, W), _f), np.zeros(H * W, np.uint32)
+    if st["P"]:
+        lib().r2o_raster_render_fwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(W), C.c_int(H), _p(st["means2D"]),
+                                          _p(st["conic_opacity"]), _p(st["mus"]), _p(budget), _p(nb))
+    return budget, nb.reshape(H, W)
+
+
+RASTER_RAW = ("mean2D_x", "mean2D_y", "conic_x", "conic_y", "conic_w", "opacity", "mu")
+
+
+def raster_backward_audit(st, dL_dcolor):
+    """The 7 raw sums of the render backward per Gaussian, accumulated in double: (sum, abssum, flip), each [P,7] in the order
+    RASTER_RAW.  abssum = sum of |terms| (the scale a float sum with cancellation is accurate to), flip = |terms| of pairs on a
+    cut-off."""
+    P, H, W = st["P"], st["H"], st["W"]
+    out = [np.zeros((P, 7), np.float64) for _ in range(3)]
+    if P:
+        lib().r2o_raster_render_bwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(W), C.c_int(H), C.c_int(P),
+                                          C.c_int64(st["num_rendered"]), _p(st["means2D"]), _p(st["conic_opacity"]),
+                                          _p(st["mus"]), _p(st["n_contrib"]), _p(_c32(dL_dcolor).reshape(-1)),
+                                          _p(out[0]), _p(out[1]), _p(out[2]))
+    return out
+
+
+def raster_geom_chain(st, raw, means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx,
+                      tanfovy):
+    """computeCov2DCUDA + preprocessCUDA backward applied to given raw sums ([P,7], RASTER_RAW order): the (float-evaluated)
+    linear map from the render backward's sums to the returned gradients."""
+    L = lib()
+    P, H, W, mode = st["P"], st["H"], st["W"], st["mode"]
+    raw = np.asarray(raw)
+    g = dict(dL_dmeans3D=np.zeros((P, 3), _f), dL_dmeans2D=np.zeros((P, 3), _f), dL_dconic=np.zeros((P, 2, 2), _f),
+             dL_dopacity=np.zeros((P, 1), _f), dL_dmu=np.zeros((P, 1), _f), dL_dcov3D=np.zeros((P, 6), _f),
+             dL_dscales=np.zeros((P, 3), _f), dL_drotations=np.zeros((P, 4), _f))
+    g["dL_dmeans2D"][:, 0:2] = raw[:, 0:2]
+    g["dL_dconic"].reshape(P, 4)[:, [0, 1, 3]] = raw[:, 2:5]
+    g["dL_dopacity"][:, 0] = raw[:, 5]
+    g["dL_dmu"][:, 0] = raw[:, 6]
+    means3D = _c32(means3D).reshape(-1, 3)
+    scales = _c32(_empty_to_none(scales))
+    rotations = _c32(_empty_to_none(rotations))
+    cov3D_precomp = _c32(_empty_to_none(cov3D_precomp))
+    view, proj = _c32(viewmatrix).reshape(-1), _c32(projmatrix).reshape(-1)
+    cov3D = cov3D_precomp if cov3D_precomp is not None else st["cov3D"]
+    L.r2o_raster_cov2d_bwd(C.c_int(P), _p(means3D), _p(st["radii"]), _p(cov3D), C.c_int(W), C.c_int(H),
+                           C.c_float(tanfovx), C.c_float(tanfovy), _p(view), _p(g["dL_dconic"]), _p(g["dL_dmu"]),
+                           _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), C.c_int(mode))
+    L.r2o_raster_preprocess_bwd(C.c_int(P), _p(means3D), _p(st["radii"]), _p(scales), _p(rotations),
+                                C.c_float(scale_modifier), _p(proj), _p(g["dL_dmeans2D"]), _p(g["dL_dmeans3D"]),
+                                _p(g["dL_dcov3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+    return g
+
+
 # --------------------------------------------------------------------------- voxelizer
 def voxel_forward(means3D, opacities, scales, rotations, scale_modifier, cov3D_precomp,
                   nVoxel, sVoxel, center, render=True):
@@ -249,6 +306,55 @@ def voxel_backward(st, scales, rotations, scale_modifier, cov3D_precomp, dL_dvol
                            C.c_float(sx), C.c_float(sy), C.c_float(sz), C.c_int(P), _p(st["means3D_norm"]),
                            _p(st["conic_opacity"]), _p(st["n_contrib"]), _p(dL_dvol), _p(g["dL_dmeans3D_norm"]),
                            _p(g["dL_dconic3D"]), _p(g["dL_dopacity"]), C.c_int(1 if acc64 else 0))
+    cov3D = cov3D_precomp if cov3D_precomp is not None else st["cov3D"]
+    L.r2o_voxel_cov3d_bwd(C.c_int(P), _p(st["radii_x"]), _p(st["radii_y"]), _p(st["radii_z"]), _p(cov3D),
+                          C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_float(sx), C.c_float(sy), C.c_float(sz),
+                          _p(g["dL_dconic3D"]), _p(g["dL_dcov3D"]))
+    L.r2o_voxel_preprocess_bwd(C.c_int(P), _p(st["radii_x"]), _p(st["radii_y"]), _p(st["radii_z"]), _p(scales),
+                               _p(rotations), C.c_float(scale_modifier), _p(g["dL_dmeans3D_norm"]),
+                               _p(g["dL_dmeans3D"]), _p(g["dL_dcov3D"]), _p(g["dL_dscales"]), _p(g["dL_drotations"]))
+    return g
+
+
+def voxel_forward_audit(st):
+    nx, ny, nz = st["nVoxel"]
+    budget, nb = np.zeros((nx, ny, nz), _f), np.zeros(nx * ny * nz, np.uint32)
+    if st["P"]:
+        lib().r2o_voxel_render_fwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                                         _p(st["means3D_norm"]), _p(st["conic_opacity"]), _p(budget), _p(nb))
+    return budget, nb.reshape(nx, ny, nz)
+
+
+VOXEL_RAW = ("mean_x", "mean_y", "mean_z", "conic_0", "conic_1", "conic_2", "conic_3", "conic_4", "conic_5", "opacity")
+
+
+def voxel_backward_audit(st, dL_dvol):
+    """(sum, abssum, flip), each [P,10] float64 in VOXEL_RAW order -- see raster_backward_audit."""
+    P = st["P"]
+    nx, ny, nz = st["nVoxel"]
+    sx, sy, sz = st["sVoxel"]
+    out = [np.zeros((P, 10), np.float64) for _ in range(3)]
+    if P:
+        lib().r2o_voxel_render_bwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(nx), C.c_int(ny), C.c_int(nz),
+                                         C.c_float(sx), C.c_float(sy), C.c_float(sz), C.c_int(P),
+                                         C.c_int64(st["num_rendered"]), _p(st["means3D_norm"]), _p(st["conic_opacity"]),
+                                         _p(st["n_contrib"]), _p(_c32(dL_dvol).reshape(-1)), _p(out[0]), _p(out[1]), _p(out[2]))
+    return out
+
+
+def voxel_geom_chain(st, raw, scales, rotations, scale_modifier, cov3D_precomp):
+    """computeCov3DCUDA + preprocessCUDA backward (VOX/backward.cu:86-213) applied to given raw sums ([P,10], VOXEL_RAW)."""
+    L = lib()
+    P = st["P"]
+    nx, ny, nz = st["nVoxel"]
+    sx, sy, sz = st["sVoxel"]
+    raw = np.asarray(raw)
+    scales = _c32(_empty_to_none(scales))
+    rotations = _c32(_empty_to_none(rotations))
+    cov3D_precomp = _c32(_empty_to_none(cov3D_precomp))
+    g = dict(dL_dmeans3D=np.zeros((P, 3), _f), dL_dmeans3D_norm=np.ascontiguousarray(raw[:, 0:3], _f),
+             dL_dconic3D=np.ascontiguousarray(raw[:, 3:9], _f), dL_dopacity=np.ascontiguousarray(raw[:, 9:10], _f),
+             dL_dcov3D=np.zeros((P, 6), _f), dL_dscales=np.zeros((P, 3), _f), dL_drotations=np.zeros((P, 4), _f))
     cov3D = cov3D_precomp if cov3D_precomp is not None else st["cov3D"]
     L.r2o_voxel_cov3d_bwd(C.c_int(P), _p(st["radii_x"]), _p(st["radii_y"]), _p(st["radii_z"]), _p(cov3D),
                           C.c_int(nx), C.c_int(ny), C.c_int(nz), C.c_float(sx), C.c_float(sy), C.c_float(sz),

@@ -930,6 +930,236 @@ R2O_API void r2o_knn_dist2(int P, const float *pts, float *out)
     }
 }
 
+
+/* ====================================================================================== AUDIT (test bookkeeping)
+ * The render kernels' cut-off tests (power > 0, alpha < 1e-5 / 1e-6) are discontinuities: an implementation that
+ * evaluates alpha with different rounding (exp2 of a pre-scaled conic, a row recurrence, FMA contraction -- or nvcc's
+ * own contraction of the reference) may take the other branch for a pair whose alpha sits ON a threshold.  The functions
+ * below restate the same loops as the render kernels above and additionally book, per output element, how much of the
+ * result hangs on such borderline pairs, so that a parity test can assert the pure relative tolerance everywhere and
+ * attribute every excess to a counted, bounded set of cut-off flips instead of hiding them under an absolute floor.
+ * A pair is BORDERLINE when
+ *   (a) |ln(alpha) - ln(cutoff)| <= dlt, or   (b) |power| <= dlt   (the power > 0 test, RAS/forward.cu:369),
+ * dlt = 32 eps_f32 * (sum of the magnitudes of the terms of `power` + |ln(opacity*mu)| + 1): a few dozen roundings of
+ * the largest intermediate, evaluated in double.  Its budget is the alpha it would add.
+ * The backward audit accumulates, per Gaussian and per raw gradient sum, the double-precision sum, the sum of absolute
+ * terms (the honest scale of a float sum with cancellation) and the absolute terms of borderline pairs; it accumulates
+ * per list instance first and reduces over instances in list order (deterministic, no per-thread slabs). */
+static int r2o_borderline(double power, double mag, double lnw, double ln_cut, double *alpha_if_added)
+{
+    const double dlt = 32.0 * (double)FLT_EPSILON * (mag + fabs(lnw) + 1.0);
+    *alpha_if_added = exp(lnw + (power < 0.0 ? power : 0.0));
+    if (fabs(power) <= dlt && lnw >= ln_cut - dlt) return 1;                 /* (b) sign of power undecided */
+    if (power <= dlt && fabs(lnw + power - ln_cut) <= dlt) return 1;         /* (a) alpha on the cut-off */
+    return 0;
+}
+
+R2O_API void r2o_raster_render_fwd_audit(const uint32_t *ranges, const uint32_t *point_list, int W, int H,
+                                         const float *means2D, const float *conic_opacity, const float *mus,
+                                         float *flip_budget, uint32_t *n_border)
+{
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    const double ln_cut = log((double)0.00001f);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        const int ty = tile / gx, tx = tile % gx;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int ly = 0; ly < 16; ly++)
+            for (int lx = 0; lx < 16; lx++) {
+                const int pxi = tx * 16 + lx, pyi = ty * 16 + ly;
+                if (!(pxi < W && pyi < H)) continue;
+                double budget = 0.0;
+                uint32_t nb = 0;
+                for (uint32_t k = r0; k < r1; k++) {
+                    const uint32_t id = point_list[k];
+                    const double dx = (double)means2D[2 * id] - pxi, dy = (double)means2D[2 * id + 1] - pyi;
+                    const float *co = conic_opacity + 4 * id;
+                    const double t0 = 0.5 * co[0] * dx * dx, t1 = 0.5 * co[2] * dy * dy, t2 = (double)co[1] * dx * dy;
+                    const double w = (double)co[3] * (double)mus[id];
+                    if (!(w > 0.0)) continue;
+                    double a;
+                    if (r2o_borderline(-t0 - t1 - t2, fabs(t0) + fabs(t1) + fabs(t2), log(w), ln_cut, &a)) { budget += a; nb++; }
+                }
+                flip_budget[pyi * W + pxi] = (float)(budget * 1.0001);
+                n_border[pyi * W + pxi] = nb;
+            }
+    }
+}
+
+/* sum / abssum / flip: [P*7] doubles, order {mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, mu}; R = list length */
+R2O_API void r2o_raster_render_bwd_audit(const uint32_t *ranges, const uint32_t *point_list, int W, int H, int P, int64_t R,
+                                         const float *means2D, const float *conic_opacity, const float *mus,
+                                         const uint32_t *n_contrib, const float *dL_dpixels,
+                                         double *sum, double *abssum, double *flip)
+{
+    const int gx = (W + 15) / 16, gy = (H + 15) / 16;
+    const double ln_cut = log((double)0.00001f);
+    const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    double *inst = (double *)calloc((size_t)R * 21 + 1, sizeof(double));   /* per list instance: 7 sums, 7 abs, 7 flip */
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        const int ty = tile / gx, tx = tile % gx;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (uint32_t k = r0; k < r1; k++) {
+            const uint32_t id = point_list[k];
+            const float *co = conic_opacity + 4 * id;
+            const float mu = mus[id];
+            double *acc = inst + (size_t)k * 21;
+            const double w = (double)co[3] * (double)mu;
+            for (int ly = 0; ly < 16; ly++)
+                for (int lx = 0; lx < 16; lx++) {
+                    const int pxi = tx * 16 + lx, pyi = ty * 16 + ly;
+                    if (!(pxi < W && pyi < H)) continue;
+                    const float dL_dpixel = dL_dpixels[pyi * W + pxi];
+                    const float dx = means2D[2 * id] - (float)pxi, dy = means2D[2 * id + 1] - (float)pyi;
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const float G = expf(power <= 0.0f ? power : 0.0f);
+                    const float dL_dG = co[3] * mu * dL_dpixel;
+                    const float gdx = G * dx, gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    const float v[7] = {
+                        dL_dG * dG_ddelx * ddelx_dx, dL_dG * dG_ddely * ddely_dy,
+                        -0.5f * gdx * dx * dL_dG, -1.0f * gdx * dy * dL_dG, -0.5f * gdy * dy * dL_dG,
+                        mu * G * dL_dpixel, co[3] * G * dL_dpixel };
+                    /* the reference's tests (RAS/backward.cu:523-543) */
+                    const int passes = (k - r0) < n_contrib[pyi * W + pxi] && !(power > 0.0f) && !(co[3] * mu * G < 0.00001f);
+                    if (passes) for (int q = 0; q < 7; q++) { acc[q] += (double)v[q]; acc[7 + q] += fabs((double)v[q]); }
+                    if (w > 0.0) {
+                        const double ddx = dx, ddy = dy;
+                        const double t0 = 0.5 * co[0] * ddx * ddx, t1 = 0.5 * co[2] * ddy * ddy, t2 = (double)co[1] * ddx * ddy;
+                        double a;
+                        if (r2o_borderline(-t0 - t1 - t2, fabs(t0) + fabs(t1) + fabs(t2), log(w), ln_cut, &a))
+                            for (int q = 0; q < 7; q++) acc[14 + q] += fabs((double)v[q]) * 1.0001;
+                    }
+                }
+        }
+    }
+    memset(sum, 0, sizeof(double) * 7 * (size_t)P);
+    memset(abssum, 0, sizeof(double) * 7 * (size_t)P);
+    memset(flip, 0, sizeof(double) * 7 * (size_t)P);
+    for (int64_t k = 0; k < R; k++) {
+        const uint32_t id = point_list[k];
+        for (int q = 0; q < 7; q++) {
+            sum[7 * (size_t)id + q] += inst[(size_t)k * 21 + q];
+            abssum[7 * (size_t)id + q] += inst[(size_t)k * 21 + 7 + q];
+            flip[7 * (size_t)id + q] += inst[(size_t)k * 21 + 14 + q];
+        }
+    }
+    free(inst);
+}
+
+static void vox_terms(const float *co, double dx, double dy, double dz, double *power, double *mag)
+{
+    const double t[6] = { 0.5 * co[0] * dx * dx, 0.5 * co[3] * dy * dy, 0.5 * co[5] * dz * dz,
+                          (double)co[1] * dx * dy, (double)co[2] * dx * dz, (double)co[4] * dy * dz };
+    *power = 0.0; *mag = 0.0;
+    for (int i = 0; i < 6; i++) { *power -= t[i]; *mag += fabs(t[i]); }
+}
+
+R2O_API void r2o_voxel_render_fwd_audit(const uint32_t *ranges, const uint32_t *point_list, int nx, int ny, int nz,
+                                        const float *points_vol, const float *conic_opacity,
+                                        float *flip_budget, uint32_t *n_border)
+{
+    const int gx = (nx + 7) / 8, gy = (ny + 7) / 8, gz = (nz + 7) / 8;
+    const double ln_cut = log((double)0.000001f);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy * gz; tile++) {
+        const int tz = tile / (gy * gx), ty = (tile / gx) % gy, tx = tile % gx;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (int lz = 0; lz < 8; lz++)
+            for (int ly = 0; ly < 8; ly++)
+                for (int lx = 0; lx < 8; lx++) {
+                    const int vx = tx * 8 + lx, vy = ty * 8 + ly, vz = tz * 8 + lz;
+                    if (!(vx < nx && vy < ny && vz < nz)) continue;
+                    const size_t vid = (size_t)nz * ny * vx + (size_t)nz * vy + vz;
+                    const float fx = (float)vx + 0.5f, fy = (float)vy + 0.5f, fz = (float)vz + 0.5f;
+                    double budget = 0.0;
+                    uint32_t nb = 0;
+                    for (uint32_t k = r0; k < r1; k++) {
+                        const uint32_t id = point_list[k];
+                        const float dx = points_vol[3 * id] - fx, dy = points_vol[3 * id + 1] - fy, dz = points_vol[3 * id + 2] - fz;
+                        const float *co = conic_opacity + 7 * id;
+                        if (!(co[6] > 0.0f)) continue;
+                        double power, mag, a;
+                        vox_terms(co, dx, dy, dz, &power, &mag);
+                        if (r2o_borderline(power, mag, log((double)co[6]), ln_cut, &a)) { budget += a; nb++; }
+                    }
+                    flip_budget[vid] = (float)(budget * 1.0001);
+                    n_border[vid] = nb;
+                }
+    }
+}
+
+/* sum / abssum / flip: [P*10] doubles, order {mean.x, mean.y, mean.z, conic[6], opacity} */
+R2O_API void r2o_voxel_render_bwd_audit(const uint32_t *ranges, const uint32_t *point_list, int nx, int ny, int nz,
+                                        float sx, float sy, float sz, int P, int64_t R,
+                                        const float *points_vol, const float *conic_opacity, const uint32_t *n_contrib,
+                                        const float *dL_dpixels, double *sum, double *abssum, double *flip)
+{
+    const int gx = (nx + 7) / 8, gy = (ny + 7) / 8, gz = (nz + 7) / 8;
+    const float dvx = sx / (float)nx, dvy = sy / (float)ny, dvz = sz / (float)nz;
+    const double ln_cut = log((double)0.000001f);
+    double *inst = (double *)calloc((size_t)R * 30 + 1, sizeof(double));
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < gx * gy * gz; tile++) {
+        const int tz = tile / (gy * gx), ty = (tile / gx) % gy, tx = tile % gx;
+        const uint32_t r0 = ranges[2 * tile], r1 = ranges[2 * tile + 1];
+        for (uint32_t k = r0; k < r1; k++) {
+            const uint32_t id = point_list[k];
+            const float *co = conic_opacity + 7 * id;
+            const float opa = co[6];
+            double *acc = inst + (size_t)k * 30;
+            for (int lz = 0; lz < 8; lz++)
+                for (int ly = 0; ly < 8; ly++)
+                    for (int lx = 0; lx < 8; lx++) {
+                        const int vx = tx * 8 + lx, vy = ty * 8 + ly, vz = tz * 8 + lz;
+                        if (!(vx < nx && vy < ny && vz < nz)) continue;
+                        const size_t vid = (size_t)nz * ny * vx + (size_t)nz * vy + vz;
+                        const float fx = (float)vx + 0.5f, fy = (float)vy + 0.5f, fz = (float)vz + 0.5f;
+                        const float dL_dpixel = dL_dpixels[vid];
+                        const float dx = points_vol[3 * id] - fx, dy = points_vol[3 * id + 1] - fy, dz = points_vol[3 * id + 2] - fz;
+                        const float power = vox_power(co, dx, dy, dz);
+                        const float G = expf(power <= 0.0f ? power : 0.0f);
+                        const float dL_dG = opa * dL_dpixel;
+                        const float gdx = G * dx, gdy = G * dy, gdz = G * dz;
+                        const float dG_ddelx = -co[0] * gdx - co[1] * gdy - co[2] * gdz;
+                        const float dG_ddely = -co[3] * gdy - co[1] * gdx - co[4] * gdz;
+                        const float dG_ddelz = -co[5] * gdz - co[2] * gdx - co[4] * gdy;
+                        const float v[10] = {
+                            dL_dG * dG_ddelx * dvx, dL_dG * dG_ddely * dvy, dL_dG * dG_ddelz * dvz,
+                            (float)(-0.5 * (double)gdx * (double)dx * (double)dL_dG),
+                            (float)(-1.0 * (double)gdx * (double)dy * (double)dL_dG),
+                            (float)(-1.0 * (double)gdx * (double)dz * (double)dL_dG),
+                            (float)(-0.5 * (double)gdy * (double)dy * (double)dL_dG),
+                            (float)(-1.0 * (double)gdy * (double)dz * (double)dL_dG),
+                            (float)(-0.5 * (double)gdz * (double)dz * (double)dL_dG),
+                            G * dL_dpixel };
+                        const int passes = (k - r0) < n_contrib[vid] && !(power > 0.0f) && !(opa * G < 0.000001f);
+                        if (passes) for (int q = 0; q < 10; q++) { acc[q] += (double)v[q]; acc[10 + q] += fabs((double)v[q]); }
+                        if (opa > 0.0f) {
+                            double pw, mag, a;
+                            vox_terms(co, dx, dy, dz, &pw, &mag);
+                            if (r2o_borderline(pw, mag, log((double)opa), ln_cut, &a))
+                                for (int q = 0; q < 10; q++) acc[20 + q] += fabs((double)v[q]) * 1.0001;
+                        }
+                    }
+        }
+    }
+    memset(sum, 0, sizeof(double) * 10 * (size_t)P);
+    memset(abssum, 0, sizeof(double) * 10 * (size_t)P);
+    memset(flip, 0, sizeof(double) * 10 * (size_t)P);
+    for (int64_t k = 0; k < R; k++) {
+        const uint32_t id = point_list[k];
+        for (int q = 0; q < 10; q++) {
+            sum[10 * (size_t)id + q] += inst[(size_t)k * 30 + q];
+            abssum[10 * (size_t)id + q] += inst[(size_t)k * 30 + 10 + q];
+            flip[10 * (size_t)id + q] += inst[(size_t)k * 30 + 20 + q];
+        }
+    }
+    free(inst);
+}
+
 R2O_API int r2o_abi_version(void) { return 1; }
 R2O_API int r2o_num_threads(void) { return omp_get_max_threads(); }
 R2O_API void r2o_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }

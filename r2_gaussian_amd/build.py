@@ -38,6 +38,22 @@ SOURCES = {
 }
 
 
+def source_hash():
+    """sha256 over the kernel sources + build flags: identifies WHICH kernels a measurement (e.g. the PMC summary under
+    profiles/) belongs to, independently of rebuilds."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp")))
+    for f in files:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "r2hip.h"), "rb") as fh:
+        h.update(fh.read())
+    h.update(repr((COMMON[:7], EXACT, FAST, sorted(SOURCES.items()))).encode())
+    return h.hexdigest()
+
+
 def _hipcc():
     for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):

@@ -3,6 +3,7 @@
 // reference (RAS/rasterizer_impl.cu:116-138,275,308-316); the sort lives in radix_sort.hip.
 #include "r2_common.hpp"
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdarg.h>
 #include <vector>
@@ -76,7 +77,31 @@ void host_mark_forward_end()
 // idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency is on the
 // critical path -- a blocking hipStreamSynchronize may sleep on an interrupt (tens of microseconds)
 static thread_local uint32_t *g_pinned = nullptr;
-static thread_local hipEvent_t g_read_ev = nullptr;
+// one event per device: an event can only be recorded on a stream of the device it was created on, and one host thread may
+// drive several GPUs (the caller makes the stream's device current, like every HIP API that takes a stream)
+constexpr int MAX_DEVICES = 64;
+static thread_local hipEvent_t g_read_evs[MAX_DEVICES] = {};
+static thread_local hipEvent_t g_read_ev = nullptr;   // the event of the read in flight
+
+int current_device_slot()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % MAX_DEVICES;
+}
+
+int device_cu_count()
+{
+    static int cus[MAX_DEVICES] = {};   // written once per device with the same value: a benign race at worst
+    const int slot = current_device_slot();
+    if (cus[slot] == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus[slot] = n;
+    }
+    return cus[slot];
+}
 
 int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s)
 {
@@ -84,8 +109,10 @@ int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s)
         set_error("read_host_words: %d words", n);
         return R2_ERR_INVALID;
     }
-    if (!g_pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_pinned), 64, hipHostMallocDefault));
-    if (!g_read_ev) R2_HIP_TRY(hipEventCreateWithFlags(&g_read_ev, hipEventDisableTiming));
+    if (!g_pinned) R2_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&g_pinned), 64, hipHostMallocPortable));
+    hipEvent_t &ev = g_read_evs[current_device_slot()];
+    if (!ev) R2_HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    g_read_ev = ev;
     R2_HIP_TRY(hipMemcpyAsync(g_pinned, dev_words, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     R2_HIP_TRY(hipEventRecord(g_read_ev, s));
     return 0;
@@ -134,9 +161,17 @@ int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
     volatile uint32_t *mb = g_mailbox;
     unsigned spins = 0;
     bool drained = false;
+    static const double timeout_s = [] { const char *e = getenv("R2_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 30.0; }();
     while (__atomic_load_n(&g_mailbox[15], __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 0x3FFFu) == 0u) {   // the producing kernel never ran?  (launch failure: do not spin forever)
+            // a hung GPU or a stream blocked on something that never happens: give up after a wall-clock limit instead of
+            // spinning forever (R2_SYNC_TIMEOUT_S, default 30 s); kernels queued so far may still write the mailbox later,
+            // which is harmless -- the next call uses a new sequence number
+            if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                set_error("host_mailbox_wait: no control words from the GPU after %.0f s (hung device or blocked stream)", timeout_s);
+                return R2_ERR_INVALID;
+            }
             const hipError_t q = hipStreamQuery(s);
             if (q != hipSuccess && q != hipErrorNotReady) {
                 set_error("host_mailbox_wait: %s", hipGetErrorString(q));

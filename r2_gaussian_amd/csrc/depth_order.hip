@@ -14,6 +14,7 @@
 // pass has anyway.
 #include "r2_common.hpp"
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
 #include <cmath>
@@ -452,15 +453,20 @@ struct HintEntry {
 };
 thread_local HintEntry g_hints[2][4];
 thread_local unsigned g_hint_clock[2] = { 0, 0 };
-int g_hint_mode = -1;   // -1: read R2_DEPTH_HINT from the environment on first use; 0 off; 1 on
+std::atomic<int> g_hint_mode{-1};   // -1: read R2_DEPTH_HINT from the environment on first use; 0 off; 1 on
 
 bool hints_enabled()
 {
-    if (g_hint_mode < 0) {
+    int m = g_hint_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
         const char *e = getenv("R2_DEPTH_HINT");
-        g_hint_mode = (e && e[0] == '0') ? 0 : 1;
+        int want = (e && e[0] == '0') ? 0 : 1;
+        // several threads may get here at once: the first to install its (identical) answer wins
+        int expected = -1;
+        g_hint_mode.compare_exchange_strong(expected, want, std::memory_order_relaxed);
+        m = g_hint_mode.load(std::memory_order_relaxed);
     }
-    return g_hint_mode == 1;
+    return m == 1;
 }
 HintEntry *find_hint(int which, size_t P)
 {
@@ -531,7 +537,7 @@ void depth_hint_update(int which, size_t P, const uint32_t w[DW_COUNT], bool ove
 // 2: forget the hint history.  Results never depend on this: it only selects between two exact sorting paths.
 extern "C" void r2_depth_hint_control(int mode)
 {
-    if (mode == 0 || mode == 1) r2::g_hint_mode = mode;
+    if (mode == 0 || mode == 1) r2::g_hint_mode.store(mode, std::memory_order_relaxed);
     if (mode == 2)
         for (auto &tab : r2::g_hints)
             for (auto &e : tab) e = r2::HintEntry();

@@ -189,6 +189,8 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
                               int P, hipStream_t s, uint32_t *total_out = nullptr /* device word receiving out[P-1] */);
 // one small device->host read (n <= 16 words) through pinned memory + busy-wait on an event.  begin enqueues the copy on the
 // stream, wait spins until it has landed: work enqueued between the two keeps the GPU busy while the host waits.
+int current_device_slot();   // index of the current HIP device into small per-device host tables (binning.hip)
+int device_cu_count();       // compute units of the current device (cached per device)
 int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
 int read_host_words_wait(uint32_t *out, int n);
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);

@@ -706,12 +706,7 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     // of the first waves (pipelined, see the kernel).  Chunks cost about the same, so with one wave per chunk the last,
     // partly filled round ran at low occupancy for a full wave lifetime: 18068 chunks on 4096 slots = 4.4 rounds took as
     // long as 5 (69 us); 4 full rounds + 1684 second chunks take 58 us.
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
-    }
+    const int cus = device_cu_count();
     const uint32_t slots = (uint32_t)cus * 4u * (uint32_t)BWD_OCC;   // a multiple of 8 (XCD-aware chunk order)
     const uint32_t nslots = ((nchunks + 7u) >> 3) << 3;
     const uint32_t grid = (nslots <= slots || (slots & 7u)) ? nslots : (nslots / slots) * slots;

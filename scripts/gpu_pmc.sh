@@ -28,7 +28,12 @@ for C in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
         for c, v in agg[k].items():
             res[k][c] = v / max(n[k][c], 1)
             res[k]["launches_" + c] = n[k][c]
+import sys
+sys.path.insert(0, ".")
+from r2_gaussian_amd import build as _b
+res["_meta"] = {"source_sha": _b.source_hash(), "cmd": """$CMD""", "tag": "${TAG}"}   # which kernels these counters belong to
 json.dump(res, open("gpurun_out/pmc/${TAG}_pmc_per_launch.json", "w"), indent=1, sort_keys=True)
+res.pop("_meta")
 for k, d in sorted(res.items(), key=lambda kv: -kv[1].get("FETCH_SIZE", 0)):
     if "FETCH_SIZE" in d or "WRITE_SIZE" in d:
         print("%-46s FETCH_SIZE %10.1f KB  WRITE_SIZE %10.1f KB  waves %s valu %s" % (k, d.get("FETCH_SIZE", -1), d.get("WRITE_SIZE", -1), d.get("SQ_WAVES"), d.get("SQ_INSTS_VALU")))

@@ -76,10 +76,11 @@ def test_training_iteration_like_reference(oracle, gpu):
     xyz_n, rho_n, sc_n, q_n = (t.detach().cpu().numpy() for t in (_xyz, dens, scales, rot))
     vm, pm = Hh.np_view(v)
     o = oracle.raster_forward(xyz_n, rho_n, sc_n, q_n, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, 64, 64, 1)
-    np.testing.assert_allclose(out["render"].detach().cpu().numpy(), o["color"], rtol=1e-4, atol=2e-5)
+    Hh.parity_image(oracle, o, out["render"].detach().cpu().numpy(), "autograd render")
     dL = (torch.sign(out["render"].detach() - gt) / gt.numel()).cpu().numpy()
-    go = oracle.raster_backward(o, xyz_n, sc_n, q_n, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
-    Hh.assert_close_scaled(vsp.cpu().numpy(), go["dL_dmeans2D"], rtol=2e-3, name="viewspace grad", atol_frac=2e-5)
+    s64, a64, f64 = oracle.raster_backward_audit(o, dL)
+    err = np.abs(vsp.cpu().numpy()[:, :2].astype(np.float64) - s64[:, :2])
+    assert (err <= 1e-4 * a64[:, :2] + f64[:, :2]).all(), "viewspace gradient outside 1e-4 of its terms + attributed flips"
 
 
 def test_argument_validation(gpu):

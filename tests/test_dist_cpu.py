@@ -150,3 +150,83 @@ def test_grad_block_detects_the_backward_layout():
     packed = D.pack_grads(xyz, dens, scal, rot)
     gx, gd, gs, gr = D.unpack_grads(packed)
     assert torch.equal(gx, xyz) and torch.equal(gd, dens) and torch.equal(gs, scal) and torch.equal(gr, rot)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py launcher
+def _bench_line(out):
+    import json
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it must start 2 ranks itself (one per GPU on a node; here on CPU over
+    gloo with the renderer stubbed: R2_BENCH_STUB=1), report n_gpus = 2 = the size of the process group it found, and both a
+    synchronous and an overlapped number.  Under a launcher whose world differs from --gpus it must refuse."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, R2_BENCH_STUB="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
+                        "--repeats", "3", "--gaussians", "513"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _bench_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2
+    assert line["steps"] == 4 and line["timing"]["regions"] == 3 and line["overlapped"]["regions"] == 3
+    assert line["value"] > 0 and line["overlapped"]["value"] > 0
+    # a launcher that started a different number of ranks than --gpus says: refuse
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                        env=env2, capture_output=True, text=True, timeout=120)
+    assert r2.returncode != 0 and "launcher started 1 ranks" in (r2.stderr + r2.stdout)
+
+
+def test_bench_step_runner_sync_and_overlap_order():
+    """sync: every step's reduction is waited for before the step returns.  overlap: it is waited for two steps later, before
+    its buffer is rendered into again, and drain() waits for whatever is left."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    log = []
+
+    class H:
+        def __init__(self, k):
+            self.k = k
+
+        def wait(self):
+            log.append(("wait", self.k))
+
+    def render(k, i):
+        log.append(("render", k, i))
+        return k
+
+    def allreduce(blk):
+        log.append(("reduce", blk))
+        return H(blk)
+
+    r = bench.StepRunner(render, allreduce, True, "sync")
+    for k in range(3):
+        r.step(k)
+    r.drain()
+    assert log == [("render", 0, 0), ("reduce", 0), ("wait", 0), ("render", 1, 1), ("reduce", 1), ("wait", 1),
+                   ("render", 2, 0), ("reduce", 2), ("wait", 2)]
+    del log[:]
+    r = bench.StepRunner(render, allreduce, True, "overlap")
+    for k in range(4):
+        r.step(k)
+    r.drain()
+    assert log == [("render", 0, 0), ("reduce", 0), ("render", 1, 1), ("reduce", 1), ("wait", 0), ("render", 2, 0),
+                   ("reduce", 2), ("wait", 1), ("render", 3, 1), ("reduce", 3), ("wait", 2), ("wait", 3)]
+    del log[:]
+    r = bench.StepRunner(render, allreduce, False, "sync")   # single GPU: no exchange at all
+    r.step(0)
+    r.drain()
+    assert log == [("render", 0, 0)]
+    s = bench.summarize([0.010, 0.012, 0.011], 10, 2)
+    assert s["value"] == round(10 * 2 / 0.011, 2) and s["ms_per_step"] == 1.1 and s["regions"] == 3

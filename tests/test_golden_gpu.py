@@ -1,7 +1,9 @@
 """GPU parity against the committed golden fixtures (tests/golden/*.npz = outputs of the reference's own kernels run
 on the CPU, see tests/golden/make_golden.py): the HIP path, called through the C ABI, must reproduce the reference's
-radii / sorted point lists / ranges bit for bit, images and volumes within 1e-4 relative, gradients within 2e-3 of each
-array's scale (the reference's own gradient sums are float-atomic, order-nondeterministic)."""
+radii / sorted point lists / ranges bit for bit, images and volumes within the PURE 1e-4 relative bound except on attributed
+cut-off flips, gradients within 1e-4 of the sum of their absolute terms (oracle/parity.py; the cut-off audit runs the oracle on
+the fixture's inputs, whose image / volume is first checked to be the fixture's bit for bit), and within 2e-4 of each array's
+scale of the reference's own float-atomic gradients."""
 import glob
 import os
 
@@ -22,14 +24,16 @@ def _cloud(z):
     return S.Cloud(*(torch.from_numpy(z[k].copy()) for k in ("in_means3D", "in_scales", "in_rotations", "in_opacities")))
 
 
-def _grad_close(name, got, want, frac=2e-3):
+def _grad_close(name, got, want, flagged, frac=2e-4):
+    """vs the reference's own (float-atomic) gradient arrays: within 2e-4 of the array's scale on every Gaussian that holds no
+    pair on a cut-off test (those are bounded by the attributed-flip check against the oracle)."""
     scale = max(float(np.abs(want).max()), 1e-30)
-    err = float(np.abs(got.astype(np.float64) - want.astype(np.float64)).max())
-    assert err <= frac * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64).reshape(got.shape))[~flagged]
+    assert err.size == 0 or float(err.max()) <= frac * scale, "%s: max err %.3e vs scale %.3e" % (name, float(err.max()), scale)
 
 
 @pytest.mark.parametrize("path", RASTER, ids=[os.path.basename(p)[:-4] for p in RASTER])
-def test_raster_vs_reference_golden(path, gpu):
+def test_raster_vs_reference_golden(path, gpu, oracle):
     z = np.load(path)
     H, W, mode, precomp = (int(v) for v in z["in_meta"])
     tfx, tfy, mod = (float(v) for v in z["in_params"])
@@ -44,20 +48,25 @@ def test_raster_vs_reference_golden(path, gpu):
     assert np.array_equal(h["keys"], z["fw_keys"]), "sorted (tile|depth) keys differ from the reference"
     assert np.array_equal(h["point_list"], z["fw_point_list"])
     assert np.array_equal(h["ranges"], z["fw_ranges"])
-    ref = z["fw_color"]
-    assert (np.abs(h["color"] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
-    # n_contrib: identical except where a pair sits on the alpha cut-off (exp2 vs exp rounding)
-    assert (h["n_contrib"] != z["fw_n_contrib"]).mean() < 0.01
+    o = Hh.oracle_raster(oracle, c, v, cov3D_precomp=cov, scale_modifier=mod)
+    assert np.array_equal(o["color"].view(np.uint32), z["fw_color"].view(np.uint32))   # the oracle IS the reference here
+    name = os.path.basename(path)[:-4]
+    Hh.parity_image(oracle, o, h["color"], "golden " + name)
+    # n_contrib: identical except on pixels holding a pair ON a cut-off test (exp2 vs exp rounding)
+    _b, nb = oracle.raster_forward_audit(o)
+    mism = h["n_contrib"] != z["fw_n_contrib"]
+    assert not (mism & (nb.reshape(-1) == 0)).any()
     g = Hh.hip_raster_backward(h, c, v, z["in_dL_dcolor"], gpu)
+    st = Hh.parity_raster_grads(oracle, o, g, c, v, z["in_dL_dcolor"], "golden " + name, cov3D_precomp=cov, scale_modifier=mod)
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D"):
-        _grad_close(k, g[k], z["bw_" + k])
+        _grad_close(k, g[k], z["bw_" + k], st["_flagged"])
     if not precomp:
         for k in ("dL_dscales", "dL_drotations"):
-            _grad_close(k, g[k], z["bw_" + k])
+            _grad_close(k, g[k], z["bw_" + k], st["_flagged"])
 
 
 @pytest.mark.parametrize("path", VOXEL, ids=[os.path.basename(p)[:-4] for p in VOXEL])
-def test_voxel_vs_reference_golden(path, gpu):
+def test_voxel_vs_reference_golden(path, gpu, oracle):
     z = np.load(path)
     nV = tuple(int(v) for v in z["in_nVoxel"])
     sV, ctr = tuple(float(v) for v in z["in_sVoxel"]), tuple(float(v) for v in z["in_center"])
@@ -67,8 +76,11 @@ def test_voxel_vs_reference_golden(path, gpu):
     assert h["num_rendered"] == int(z["num_rendered"])
     for k in ("radii_x", "radii_y", "radii_z", "tiles_touched", "keys", "point_list", "ranges"):
         assert np.array_equal(h[k], z["fw_" + k]), k
-    ref = z["fw_vol"]
-    assert (np.abs(h["vol"] - ref) <= 1e-4 * np.abs(ref) + 2e-6).all()
+    o = Hh.oracle_voxel(oracle, c, nV, sV, ctr, scale_modifier=mod)
+    assert np.array_equal(o["vol"].view(np.uint32), z["fw_vol"].view(np.uint32))
+    name = os.path.basename(path)[:-4]
+    Hh.parity_volume(oracle, o, h["vol"], "golden " + name)
     g = Hh.hip_voxel_backward(h, c, nV, sV, ctr, z["in_dL_dvol"], gpu)
+    st = Hh.parity_voxel_grads(oracle, o, g, c, z["in_dL_dvol"], "golden " + name, scale_modifier=mod)
     for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
-        _grad_close(k, g[k], z["bw_" + k])
+        _grad_close(k, g[k], z["bw_" + k], st["_flagged"])

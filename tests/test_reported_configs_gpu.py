@@ -1,0 +1,81 @@
+"""GPU parity AT THE CONFIGURATIONS THAT ARE REPORTED (bench.py / BASELINE.json), not only at small ones:
+
+* the headline workload itself -- 300k Gaussians (seed 0), 512^2 cone-beam detector, views 0 and 17 of the 50-view set:
+  bit-exact binning (radii, depth order, tile runs, sorted (tile|depth) keys, point_list, ranges), image within the pure 1e-4
+  relative bound + attributed cut-off flips, the full backward against the oracle's double sums;
+* the voxelizer's reported query -- 300k Gaussians on 256^3: bit-exact indices, volume parity; and the training loop's 32^3 TV
+  patch at 300k (forward + backward), the configuration bench.py times as `tv_patch_32cube_fwd_bwd_us`;
+* BASELINE config E -- 1M Gaussians, 1024^2 detector (T = 4096 tiles: the single-pass 12-bit tile sort): bit-exact indices,
+  image parity, full backward.
+
+The oracle needs seconds per case on the GPU box's host cores (OpenMP).
+"""
+import numpy as np
+import pytest
+import torch
+
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+def _raster_full(oracle, gpu, c, v, label, backward=True):
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    assert np.array_equal(h["radii"], o["radii"])
+    Hh.check_binning(h, o)
+    st = Hh.parity_image(oracle, o, h["color"], label)
+    assert st["n_flip_candidates"] < 0.01 * st["n"]
+    if backward:
+        dL = S.make_pixel_grad(v.image_height, v.image_width).numpy()
+        gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+        sg = Hh.parity_raster_grads(oracle, o, gh, c, v, dL, label)
+        for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+            assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])
+    return o, h
+
+
+@pytest.mark.parametrize("view", [0, 17])
+def test_headline_300k_512_forward_backward(view, oracle, gpu):
+    c = S.make_cloud(300000, seed=0)                   # bench.py's cloud
+    v = S.make_views(50, (512, 512))[view]             # ... and its view set
+    o, _h = _raster_full(oracle, gpu, c, v, "HEADLINE 300k/512^2 view %d" % view)
+    assert 0.8e6 < o["num_rendered"] < 1.6e6
+
+
+def test_config_E_1M_1024(oracle, gpu):
+    c = S.make_cloud(1000000, seed=0)
+    v = S.make_views(360, (1024, 1024))[41]
+    o, h = _raster_full(oracle, gpu, c, v, "config E 1M/1024^2")
+    assert o["ranges"].shape[0] == 4096
+
+
+def test_voxelizer_300k_256cube(oracle, gpu):
+    c = S.make_cloud(300000, seed=0)
+    n, s, ctr = (256, 256, 256), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)   # bench.py's query
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 4e6
+    for k in ("radii_x", "radii_y", "radii_z"):
+        assert np.array_equal(h[k], o[k]), k
+    Hh.check_binning(h, o)
+    st = Hh.parity_volume(oracle, o, h["vol"], "voxelizer 300k/256^3")
+    assert st["n_flip_candidates"] < 0.01 * st["n"]
+
+
+def test_tv_patch_300k_32cube_forward_backward(oracle, gpu):
+    c = S.make_cloud(300000, seed=0)
+    n, s, ctr = (32, 32, 32), (0.25, 0.25, 0.25), (-0.1, 0.0, 0.05)   # one of bench.py's TV patches (train.py:128-142)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    Hh.check_binning(h, o)
+    Hh.parity_volume(oracle, o, h["vol"], "TV patch 300k/32^3")
+    g = torch.Generator().manual_seed(1)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    gh = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+    sg = Hh.parity_voxel_grads(oracle, o, gh, c, dL, "TV patch 300k/32^3")
+    for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])
