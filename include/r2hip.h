@@ -58,6 +58,18 @@ typedef char *(*r2_alloc_fn)(size_t bytes, void *user);
 R2_API int r2_abi_version(void);
 R2_API const char *r2_last_error(void);
 
+/* Alignment.  All pointers are device pointers to float / int arrays and must be 4-byte aligned; the kernels move the
+ * following arrays 16 bytes at a time, so THESE must be 16-byte aligned (any fresh torch / hipMalloc allocation is):
+ *   rotations [P,4], dL_dpix [H,W] (rasterizer backward, when width % 16 == 0), dL_dconic [P,2,2], dL_drot [P,4] (both
+ *   backwards), and the state buffers handed out by the r2_alloc_fn callbacks (128-byte aligned).
+ * The torch boundaries (r2_gaussian_amd/_C.py, csrc/torch_shim.cpp) copy an input whose data pointer is not 16-byte
+ * aligned (e.g. a view into a flat parameter buffer at an odd offset) before passing it down.
+ * Devices / threads.  Calls take the caller's HIP stream; the device that stream belongs to must be current (hipSetDevice)
+ * in the calling thread, as for every HIP API that takes a stream.  A host thread may drive several devices.
+ * num_rendered.  The forward calls return the number of (tile, Gaussian) instances as a non-negative int; a scene whose
+ * instance count does not fit 31 bits is rejected with R2_ERR_INVALID (the reference's int num_rendered has the same range).
+ */
+
 /* ---- rasterizer ------------------------------------------------------------------------------ */
 R2_API int r2_raster_forward(
     r2_alloc_fn geometryBuffer, void *geometry_user,

@@ -61,7 +61,12 @@ def _dev_f32(t, like):
         t = t.to(_F32)
     if t.device != like.device:
         t = t.to(like.device)
-    return t.contiguous()
+    t = t.contiguous()
+    # the kernels read rotations / dL_dpix rows 16 bytes at a time (include/r2hip.h, "Alignment"): a view carved out of a
+    # flat parameter buffer at an odd offset is contiguous but not 16-byte aligned -> take an (allocator-aligned) copy
+    if t.data_ptr() & 15:
+        t = t.clone()
+    return t
 
 
 def _require_gpu(t, name):

@@ -105,6 +105,10 @@ extern "C" int r2_raster_forward(
         full_order = true;
     }
     depth_hint_update(0, (size_t)P, hw, overflow);
+    if (num_rendered > 0x7FFFFFFFu) {   // the API returns it as a non-negative int (like the reference's int num_rendered)
+        set_error("r2_raster_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
+        return R2_ERR_INVALID;
+    }
     const size_t R = num_rendered;
 
     // both remaining state buffers are sized by R: the sorted lists (+ backward scratch) and the

@@ -41,9 +41,10 @@ namespace r2 {
 // Sums are formed in a fixed order (per lane in list order, then a fixed butterfly): the image is deterministic.
 // When may a pixel row be walked with the recurrence?  The only hazard is an underflowed start: exp2(p0) = 0 for
 // p0 < -126, and 0 stays 0 however large the ratios.  Along a row p(c) = -|A2| c^2 + beta c + p0 is a concave parabola
-// that never exceeds 0 (positive definite conic), hence p(c) <= -(sqrt(-p0) - c sqrt|A2|)^2.  With p0 < -126 and
-// c <= 7 no later pixel of the row can reach log2(alpha) >= log2(1e-5), i.e. p(c) >= log2(1e-5) - L, as long as
-//     sqrt|A2| <= (sqrt(126) - sqrt(L - log2(1e-5) + 1)) / 7
+// that never exceeds 0 (positive definite conic), hence p(c) <= -(sqrt(-p0) - c sqrt|A2|)^2 (p = log2 G, without L).  The
+// evaluated exponent p + L underflows for p0 < -(126 + L); with c <= 7 no later pixel of the row can then reach
+// log2(alpha) >= log2(1e-5), i.e. p(c) >= log2(1e-5) - L, as long as
+//     sqrt|A2| <= (sqrt(126 + L) - sqrt(L - log2(1e-5) + 1)) / 7
 // (for opacity*mu = 0.01 that is |A2| <= 1.3, a conditional sigma of 0.75 px along x).  Gaussians beyond that, or
 // without a finite culling box (conic not safely positive definite), are evaluated exactly, pixel by pixel.
 constexpr int FWD_BATCH = 256;          // list entries staged per round: one per thread of the workgroup
@@ -419,8 +420,10 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
                 G4 = __builtin_amdgcn_exp2f(dxs * (a.z * dxs + bdy) + cdy2);
                 rt4 = __builtin_amdgcn_exp2f(fminf(k1 + (float)N * a.z - bdy, 120.0f));
             }
-            // column moments t_k = sum_c c^k w_c (the c^k are literals: one FMA each), turned into moments of
-            // dx = dx0 - c once per row
+            // column moments t_k = sum_c (c - mid)^k w_c about the block's centre column (the (c - mid)^k are literals: one
+            // FMA each), turned into moments of dx = (dx0 - mid) - (c - mid) once per row; centring halves |dx0 - mid| and
+            // with it the cancellation in r3
+            constexpr float mid = 0.5f * (float)(N - 1);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int c = 0; c < N; ++c) {
@@ -430,14 +433,15 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
                 }
                 const float w = (G >= gthr) ? G * g[c] : 0.f;   // power <= 0 holds for a positive definite conic
                 t0 += w;
-                t1 = fmaf(w, (float)c, t1);
-                t2 = fmaf(w, (float)(c * c), t2);
+                t1 = fmaf(w, (float)c - mid, t1);
+                t2 = fmaf(w, ((float)c - mid) * ((float)c - mid), t2);
                 G *= rt;
                 rt *= rr;
             }
+            const float dm = dx0 - mid;
             r0 = t0;
-            r1 = dx0 * t0 - t1;
-            r3 = dx0 * (dx0 * t0 - 2.0f * t1) + t2;
+            r1 = dm * t0 - t1;
+            r3 = dm * (dm * t0 - 2.0f * t1) + t2;
         }
         S[0] += r0; S[1] += r1; S[3] += r3;
         S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;

@@ -27,7 +27,13 @@ __device__ __forceinline__ int row_tier(float A2, float L, float hx)
 {
     // 0: recurrence over the whole 8-pixel row; 1: recurrence re-anchored every 4 pixels (3 steps: safe down to a
     // conditional sigma of ~0.33 px); 2: exact per-pixel evaluation
-    const float room = 11.2f - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
+    // q(c) = log2 G(c) = p(c) - L <= 0 is the concave parabola; the evaluated exponent p = q + L underflows (exp2 -> 0, or a
+    // flushed denormal) when q0 < -(126 + L), and a later pixel still passes the cut-off when q(c) >= log2(1e-5) - L.
+    // q(c) <= -(sqrt(-q0) - c sqrt|A2|)^2, so c steps are safe if sqrt(126 + L) - c sqrt|A2| >= sqrt(L - log2(1e-5) + 1).
+    // (Round 1 used sqrt(126) for the first term: too optimistic by sqrt(126) - sqrt(126 + L) for L < 0 -- found by the
+    // pure-1e-4 parity check on sub-pixel Gaussians, which lost one 1.3e-5 contribution.)  The 0.5 keeps clear of the
+    // last normal binade.
+    const float room = sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
     const float s8 = room * (1.0f / 7.0f), s4 = room * (1.0f / 3.0f);
     const float a = fabsf(A2);
     if (!(hx < 3.0e38f) || !(room > 0.f)) return 2;

@@ -36,7 +36,11 @@ Tensor dev_f32(const Tensor &t, const c10::Device &dev)
     Tensor r = t;
     if (r.scalar_type() != torch::kFloat) r = r.to(torch::kFloat);
     if (r.device() != dev) r = r.to(dev);
-    return r.contiguous();
+    r = r.contiguous();
+    // the kernels read rotations / dL_dpix rows 16 bytes at a time (include/r2hip.h, "Alignment"): a view carved out of a
+    // flat parameter buffer at an odd offset is contiguous but not 16-byte aligned -> take an (allocator-aligned) copy
+    if (reinterpret_cast<uintptr_t>(r.data_ptr()) & 15u) r = r.clone();
+    return r;
 }
 const float *fptr(const Tensor &t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
 char *bptr(const Tensor &t) { return (t.defined() && t.numel() > 0) ? reinterpret_cast<char *>(t.data_ptr()) : nullptr; }

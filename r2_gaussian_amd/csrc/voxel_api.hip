@@ -109,6 +109,10 @@ extern "C" int r2_voxel_forward(
         full_order = true;
     }
     depth_hint_update(1, (size_t)P, hw, overflow);
+    if (num_rendered > 0x7FFFFFFFu) {   // the API returns it as a non-negative int (like the reference's int num_rendered)
+        set_error("r2_voxel_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
+        return R2_ERR_INVALID;
+    }
     const size_t R = num_rendered;
 
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);

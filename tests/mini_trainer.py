@@ -1,0 +1,409 @@
+"""A miniature R2-Gaussian trainer for the 3D-PSNR parity study (TEST INFRASTRUCTURE: not part of the product; the product is
+the kernels behind the drop-in packages, on which the reference's own train.py / GaussianModel run unmodified).
+
+It restates, in compact form, exactly the parts of the reference that decide the optimisation trajectory:
+  * the training iteration                       train.py:97-177
+  * parameters, activations, Adam groups, LR     r2_gaussian/gaussian/gaussian_model.py:38-64,112-126,133-164,188-254
+  * densify (clone / split) and prune            r2_gaussian/gaussian/gaussian_model.py:320-556
+  * L1 + 0.25 (1 - SSIM) + 0.05 TV(32^3)         r2_gaussian/utils/loss_utils.py:19-104, arguments/__init__.py:47-72
+  * render() / query() glue                      r2_gaussian/gaussian/render_query.py:27-160
+  * initialisation from a volume                 initialize_pcd.py:64-89, gaussian_model.py:133-164
+  * 3D PSNR                                      r2_gaussian/utils/image_utils.py:90-104
+and runs them on either backend:
+  "hip"    -- the drop-in packages (xray_gaussian_rasterization_voxelization, simple_knn) on cuda:0: the MI355X kernels;
+  "oracle" -- test-only torch.autograd.Functions around the CPU oracle (oracle/r2_oracle.c): the reference's arithmetic.
+All randomness (view order, TV patch centres, split samples) comes from seeded CPU generators, so both backends see the same
+stream as long as they take the same densification decisions.
+
+The synthetic case ("0_chest_cone-synthetic"): a hidden set of GT Gaussians (seed 2) rendered by the ORACLE
+gives the training projections, its oracle voxelization is vol_gt, the initial points are sampled from vol_gt > 0.05 with
+density x 0.15.
+"""
+import math
+import random
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from r2_gaussian_amd import scene as S
+
+
+# ---------------------------------------------------------------------------------------------- configuration
+class Opt:
+    """OptimizationParams of the reference (arguments/__init__.py:44-72), iteration counts scaled by the caller."""
+    iterations = 30000
+    position_lr_init, position_lr_final = 0.0002, 0.00002
+    density_lr_init, density_lr_final = 0.01, 0.001
+    scaling_lr_init, scaling_lr_final = 0.005, 0.0005
+    rotation_lr_init, rotation_lr_final = 0.001, 0.0001
+    lambda_dssim, lambda_tv, tv_vol_size = 0.25, 0.05, 32
+    density_min_threshold = 0.00001
+    densification_interval, densify_from_iter, densify_until_iter = 100, 500, 15000
+    densify_grad_threshold, densify_scale_threshold = 5.0e-5, 0.1
+    max_num_gaussians = 500000
+    scale_min, scale_max = 0.0005, 0.5
+
+    def __init__(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(Opt, k):
+                raise AttributeError(k)
+            setattr(self, k, v)
+        self.lr_max_steps = kw.get("iterations", self.iterations)   # *_lr_max_steps follow the run length
+
+
+def expon_lr(lr_init, lr_final, max_steps):
+    """log-linear interpolation lr_init -> lr_final (utils/gaussian_utils.py:13-46, no delay)."""
+    def f(step):
+        if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+            return 0.0
+        t = min(max(step / max_steps, 0.0), 1.0)
+        return math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+    return f
+
+
+# ---------------------------------------------------------------------------------------------- oracle backend
+class _OracleRaster(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, v):
+        from oracle import oracle as O
+        a = [t.detach().cpu().numpy() for t in (means3D, opacities, scales, rotations)]
+        vm, pm = v.world_view_transform.numpy(), v.full_proj_transform.numpy()
+        st = O.raster_forward(a[0], a[1], a[2], a[3], 1.0, None, vm, pm, v.tanfovx, v.tanfovy, v.image_height, v.image_width,
+                              v.mode)
+        ctx.st, ctx.a, ctx.v = st, a, v
+        radii = torch.from_numpy(st["radii"].copy())
+        ctx.mark_non_differentiable(radii)
+        return torch.from_numpy(st["color"].copy()), radii
+
+    @staticmethod
+    def backward(ctx, g, _):
+        from oracle import oracle as O
+        v, a = ctx.v, ctx.a
+        vm, pm = v.world_view_transform.numpy(), v.full_proj_transform.numpy()
+        r = O.raster_backward(ctx.st, a[0], a[2], a[3], 1.0, None, vm, pm, v.tanfovx, v.tanfovy, g.contiguous().numpy(),
+                              acc64=False)   # float accumulation, like the reference's atomics
+        t = torch.from_numpy
+        return t(r["dL_dmeans3D"]), t(r["dL_dmeans2D"]), t(r["dL_dopacity"]), t(r["dL_dscales"]), t(r["dL_drotations"]), None
+
+
+class _OracleVoxel(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, opacities, scales, rotations, geo):
+        from oracle import oracle as O
+        a = [t.detach().cpu().numpy() for t in (means3D, opacities, scales, rotations)]
+        n, s, c = geo
+        st = O.voxel_forward(a[0], a[1], a[2], a[3], 1.0, None, n, s, c)
+        ctx.st, ctx.a = st, a
+        return torch.from_numpy(st["vol"].copy())
+
+    @staticmethod
+    def backward(ctx, g):
+        from oracle import oracle as O
+        a = ctx.a
+        r = O.voxel_backward(ctx.st, a[2], a[3], 1.0, None, g.contiguous().numpy(), acc64=False)
+        t = torch.from_numpy
+        return t(r["dL_dmeans3D"]), t(r["dL_dopacity"]), t(r["dL_dscales"]), t(r["dL_drotations"]), None
+
+
+class Backend:
+    """render() / query() / distCUDA2 of one backend (render_query.py:27-160 semantics)."""
+
+    def __init__(self, name):
+        assert name in ("hip", "oracle")
+        self.name = name
+        self.device = torch.device("cuda:0") if name == "hip" else torch.device("cpu")
+        self._settings = {}
+
+    def render(self, v, xyz, dens, scales, rot):
+        screen = torch.zeros_like(xyz, requires_grad=True) + 0
+        screen.retain_grad()
+        if self.name == "oracle":
+            img, radii = _OracleRaster.apply(xyz, screen, dens, scales, rot, v)
+        else:
+            from xray_gaussian_rasterization_voxelization import GaussianRasterizationSettings, GaussianRasterizer
+            rs = self._settings.get(id(v))
+            if rs is None:
+                d = self.device
+                rs = self._settings[id(v)] = GaussianRasterizationSettings(
+                    image_height=v.image_height, image_width=v.image_width, tanfovx=v.tanfovx, tanfovy=v.tanfovy,
+                    scale_modifier=1.0, viewmatrix=v.world_view_transform.to(d), projmatrix=v.full_proj_transform.to(d),
+                    campos=v.camera_center.to(d), prefiltered=False, mode=v.mode, debug=False)
+            img, radii = GaussianRasterizer(raster_settings=rs)(means3D=xyz, means2D=screen, opacities=dens, scales=scales,
+                                                                rotations=rot, cov3D_precomp=None)
+        return dict(render=img, viewspace_points=screen, visibility_filter=radii > 0, radii=radii)
+
+    def query(self, xyz, dens, scales, rot, center, nVoxel, sVoxel):
+        n = tuple(int(x) for x in nVoxel)
+        s = tuple(float(x) for x in sVoxel)
+        c = tuple(float(x) for x in center)
+        if self.name == "oracle":
+            return _OracleVoxel.apply(xyz, dens, scales, rot, (n, s, c))
+        from xray_gaussian_rasterization_voxelization import GaussianVoxelizationSettings, GaussianVoxelizer
+        vs = GaussianVoxelizationSettings(scale_modifier=1.0, nVoxel_x=n[0], nVoxel_y=n[1], nVoxel_z=n[2], sVoxel_x=s[0],
+                                          sVoxel_y=s[1], sVoxel_z=s[2], center_x=c[0], center_y=c[1], center_z=c[2],
+                                          prefiltered=False, debug=False)
+        vol, _radii = GaussianVoxelizer(voxel_settings=vs)(means3D=xyz, opacities=dens, scales=scales, rotations=rot,
+                                                           cov3D_precomp=None)
+        return vol
+
+    def dist2(self, pts):
+        if self.name == "oracle":
+            from oracle import oracle as O
+            return torch.from_numpy(O.knn_dist2(pts.cpu().numpy()))
+        from simple_knn._C import distCUDA2
+        return distCUDA2(pts)
+
+
+# ---------------------------------------------------------------------------------------------- the synthetic case
+class Case:
+    """GT Gaussians -> training projections (oracle render) + vol_gt (oracle voxelization) + initial points."""
+
+    def __init__(self, detector=128, n_vol=64, n_views=50, p_gt=20000, n_init=5000, seed=2):
+        from oracle import oracle as O
+        self.scanner = dict(S.CONE_BEAM, nVoxel=[n_vol] * 3)
+        self.views = S.make_views(n_views, (detector, detector))
+        gt = S.make_cloud(p_gt, seed=seed)
+        a = (gt.xyz.numpy(), gt.density.numpy(), gt.scales.numpy(), gt.rotations.numpy())
+        self.projs = []
+        for v in self.views:
+            st = O.raster_forward(a[0], a[1], a[2], a[3], 1.0, None, v.world_view_transform.numpy(),
+                                  v.full_proj_transform.numpy(), v.tanfovx, v.tanfovy, detector, detector, v.mode)
+            self.projs.append(torch.from_numpy(st["color"].copy()))
+        self.nVoxel, self.sVoxel, self.center = (n_vol,) * 3, (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+        self.vol_gt = torch.from_numpy(O.voxel_forward(a[0], a[1], a[2], a[3], 1.0, None, self.nVoxel, self.sVoxel,
+                                                       self.center)["vol"].copy())
+        # initial points: n_init voxels with vol_gt > 0.05, density x 0.15 (initialize_pcd.py:67-86)
+        rng = np.random.default_rng(seed + 1)
+        idx = np.argwhere(self.vol_gt.numpy() > 0.05)
+        pick = idx[rng.choice(len(idx), n_init, replace=False)]
+        dV = np.array(self.sVoxel) / np.array(self.nVoxel)
+        self.init_xyz = torch.tensor(pick * dV - np.array(self.sVoxel) / 2 + np.array(self.center), dtype=torch.float32)
+        self.init_density = torch.tensor(self.vol_gt.numpy()[pick[:, 0], pick[:, 1], pick[:, 2]] * 0.15, dtype=torch.float32)
+        self.bbox = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+        self.dVoxel = torch.tensor(dV, dtype=torch.float32)
+
+
+# ---------------------------------------------------------------------------------------------- model
+class Model:
+    """GaussianModel in miniature (gaussian_model.py): raw parameters, activations, Adam with four groups, densify/prune."""
+    NAMES = ("xyz", "density", "scaling", "rotation")
+
+    def __init__(self, case, opt, backend, gen):
+        self.opt, self.be, self.gen = opt, backend, gen
+        dev = backend.device
+        self.lo, self.hi = opt.scale_min * 2.0, opt.scale_max * 2.0       # scale bound * volume_to_world (train.py:59-61)
+        xyz = case.init_xyz.to(dev)
+        dist = torch.sqrt(torch.clamp_min(backend.dist2(xyz).to(dev), 0.001 ** 2))
+        dist = torch.clamp(dist, self.lo + 1e-7, self.hi - 1e-7)
+        self.p = {
+            "xyz": xyz.clone().requires_grad_(True),
+            "density": self.inv_softplus(case.init_density.to(dev))[:, None].contiguous().requires_grad_(True),
+            "scaling": self.scaling_inv(dist)[:, None].repeat(1, 3).contiguous().requires_grad_(True),
+            "rotation": torch.tensor([1.0, 0, 0, 0], device=dev).repeat(xyz.shape[0], 1).requires_grad_(True),
+        }
+        self.max_radii2D = torch.zeros(xyz.shape[0], device=dev)
+        self.lr = {"xyz": expon_lr(opt.position_lr_init, opt.position_lr_final, opt.lr_max_steps),
+                   "density": expon_lr(opt.density_lr_init, opt.density_lr_final, opt.lr_max_steps),
+                   "scaling": expon_lr(opt.scaling_lr_init, opt.scaling_lr_final, opt.lr_max_steps),
+                   "rotation": expon_lr(opt.rotation_lr_init, opt.rotation_lr_final, opt.lr_max_steps)}
+        self.optimizer = torch.optim.Adam([{"params": [self.p[n]], "lr": self.lr[n](0), "name": n} for n in self.NAMES],
+                                          lr=0.0, eps=1e-15)
+        self._reset_stats()
+
+    # activations (gaussian_model.py:38-64)
+    @staticmethod
+    def inv_softplus(x):
+        return torch.log(torch.exp(x) - 1)
+
+    def scaling_act(self, x):
+        return torch.sigmoid(x) * (self.hi - self.lo) + self.lo
+
+    def scaling_inv(self, x):
+        y = torch.relu((x - self.lo) / (self.hi - self.lo))
+        return torch.log(y / (1 - y))
+
+    def activated(self):
+        return (self.p["xyz"], F.softplus(self.p["density"]), self.scaling_act(self.p["scaling"]),
+                F.normalize(self.p["rotation"]))
+
+    @property
+    def P(self):
+        return self.p["xyz"].shape[0]
+
+    def _reset_stats(self):
+        dev = self.be.device
+        self.grad_accum = torch.zeros((self.P, 1), device=dev)
+        self.denom = torch.zeros((self.P, 1), device=dev)
+
+    def update_lr(self, it):
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.lr[g["name"]](it)
+
+    # optimizer-state surgery (gaussian_model.py:335-403)
+    def _replace(self, new):
+        for g in self.optimizer.param_groups:
+            old = g["params"][0]
+            st = self.optimizer.state.pop(old, None)
+            t = new[g["name"]](old, st)
+            param = t[0].detach().clone().requires_grad_(True)
+            g["params"][0] = param
+            if st is not None:
+                st["exp_avg"], st["exp_avg_sq"] = t[1], t[2]
+                self.optimizer.state[param] = st
+            self.p[g["name"]] = param
+
+    def _append(self, ext):
+        def mk(name):
+            def f(old, st):
+                e = ext[name]
+                if st is None:
+                    return (torch.cat((old.detach(), e), 0), None, None)
+                return (torch.cat((old.detach(), e), 0), torch.cat((st["exp_avg"], torch.zeros_like(e)), 0),
+                        torch.cat((st["exp_avg_sq"], torch.zeros_like(e)), 0))
+            return f
+        self._replace({n: mk(n) for n in self.NAMES})
+        self._reset_stats()   # densification_postfix zeroes the statistics (gaussian_model.py:423-425)
+
+    def _keep(self, keep):
+        def f(old, st):
+            if st is None:
+                return (old.detach()[keep], None, None)
+            return (old.detach()[keep], st["exp_avg"][keep], st["exp_avg_sq"][keep])
+        self._replace({n: f for n in self.NAMES})
+        self.grad_accum, self.denom, self.max_radii2D = self.grad_accum[keep], self.denom[keep], self.max_radii2D[keep]
+
+    @staticmethod
+    def _rotmat(q):
+        q = q / q.norm(dim=1, keepdim=True)
+        r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+
+    @torch.no_grad()
+    def densify_and_prune(self, bbox):
+        """gaussian_model.py:503-550 with max_screen_size = max_scale = None (the defaults)."""
+        opt = self.opt
+        thr_scale = opt.densify_scale_threshold * 2.0
+        grads = self.grad_accum / self.denom
+        grads[grads.isnan()] = 0.0
+        if self.P < opt.max_num_gaussians:
+            # clone: small Gaussians with a large view-space gradient; BOTH copies get half the density (:474-501)
+            _x, dens, scal, _r = self.activated()
+            sel = (grads.norm(dim=-1) >= opt.densify_grad_threshold) & (scal.max(dim=1).values <= thr_scale)
+            half = self.inv_softplus(dens[sel] * 0.5)
+            ext = {"xyz": self.p["xyz"].detach()[sel], "density": half, "scaling": self.p["scaling"].detach()[sel],
+                   "rotation": self.p["rotation"].detach()[sel]}
+            self.p["density"].data[sel] = half
+            new_r = self.max_radii2D[sel]
+            self._append(ext)
+            self.max_radii2D = torch.cat([self.max_radii2D, new_r])
+            # split: large Gaussians -> 2 samples from N(0, scale) in the local frame, scale / 1.6, density / 2 (:430-472)
+            n0 = self.P
+            pad = torch.zeros(n0, device=grads.device)
+            pad[:grads.shape[0]] = grads.squeeze(-1)
+            _x, dens, scal, _r = self.activated()
+            sel = (pad >= opt.densify_grad_threshold) & (scal.max(dim=1).values > thr_scale)
+            stds = scal[sel].repeat(2, 1)
+            samples = (torch.randn(stds.shape, generator=self.gen) * stds.cpu()).to(stds.device)   # seeded CPU stream
+            R = self._rotmat(self.p["rotation"].detach()[sel]).repeat(2, 1, 1)
+            ext = {"xyz": torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self.p["xyz"].detach()[sel].repeat(2, 1),
+                   "density": self.inv_softplus(dens[sel].repeat(2, 1) * 0.5),
+                   "scaling": self.scaling_inv(scal[sel].repeat(2, 1) / 1.6),
+                   "rotation": self.p["rotation"].detach()[sel].repeat(2, 1)}
+            new_r = self.max_radii2D[sel].repeat(2)
+            self._append(ext)
+            self.max_radii2D = torch.cat([self.max_radii2D, new_r])
+            keep = ~torch.cat([sel, torch.zeros(2 * int(sel.sum()), dtype=torch.bool, device=sel.device)])
+            self._keep(keep)
+        xyz, dens, _s, _r = self.activated()
+        b = bbox.to(xyz.device)
+        prune = (dens < opt.density_min_threshold).squeeze(-1) | ((xyz < b[0]) | (xyz > b[1])).any(dim=1)
+        self._keep(~prune)
+
+
+def ssim(img1, img2, window_size=11):
+    """loss_utils.py:57-104: 11x11 Gaussian window (sigma 1.5), zero padding, mean of the SSIM map; img [1,H,W]."""
+    g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / (2 * 1.5 ** 2)) for x in range(window_size)])
+    g = (g / g.sum()).unsqueeze(1)
+    w = (g @ g.t()).float()[None, None].to(img1.device)
+    a, b = img1[None], img2[None]
+    pad = window_size // 2
+    mu1, mu2 = F.conv2d(a, w, padding=pad), F.conv2d(b, w, padding=pad)
+    s1 = F.conv2d(a * a, w, padding=pad) - mu1 * mu1
+    s2 = F.conv2d(b * b, w, padding=pad) - mu2 * mu2
+    s12 = F.conv2d(a * b, w, padding=pad) - mu1 * mu2
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    return (((2 * mu1 * mu2 + C1) * (2 * s12 + C2)) / ((mu1 * mu1 + mu2 * mu2 + C1) * (s1 + s2 + C2))).mean()
+
+
+def tv3d_mean(vol):
+    d0, d1, d2 = (torch.diff(vol, dim=k).abs().sum() for k in range(3))
+    n = vol.shape
+    return (d0 + d1 + d2) / ((n[0] - 1) * n[1] * n[2] + n[0] * (n[1] - 1) * n[2] + n[0] * n[1] * (n[2] - 1))
+
+
+def psnr3d(case, model):
+    with torch.no_grad():
+        x, d, s, r = model.activated()
+        vol = model.be.query(x, d, s, r, case.center, case.nVoxel, case.sVoxel)
+        return S.psnr3d(case.vol_gt, vol.detach().cpu())
+
+
+def train(case, opt, backend_name, eval_every=100, seed=0, log=None):
+    """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177."""
+    be = Backend(backend_name)
+    gen = torch.Generator().manual_seed(seed)          # TV centres, split samples
+    pyrng = random.Random(seed)                        # view order (train.py:104-106)
+    model = Model(case, opt, be, gen)
+    dev = be.device
+    gts = [p.to(dev) for p in case.projs]
+    tvN = torch.tensor([opt.tv_vol_size] * 3)
+    tvS = case.dVoxel * tvN
+    out = {"iters": [0], "psnr": [psnr3d(case, model)], "P": [model.P], "backend": backend_name}
+    stack = []
+    t_train = 0.0
+    for it in range(1, opt.iterations + 1):
+        t0 = time.perf_counter()
+        model.update_lr(it)
+        if not stack:
+            stack = list(range(len(case.views)))
+        vi = stack.pop(pyrng.randint(0, len(stack) - 1))
+        x, d, s, r = model.activated()
+        pkg = be.render(case.views[vi], x, d, s, r)
+        img = pkg["render"]
+        loss = (img - gts[vi]).abs().mean()
+        if opt.lambda_dssim > 0:
+            loss = loss + opt.lambda_dssim * (1.0 - ssim(img, gts[vi]))
+        if opt.lambda_tv > 0:
+            c = (case.bbox[0] + tvS / 2) + (case.bbox[1] - tvS - case.bbox[0]) * torch.rand(3, generator=gen)
+            vol = be.query(x, d, s, r, c, tvN, tvS)
+            loss = loss + opt.lambda_tv * tv3d_mean(vol)
+        loss.backward()
+        with torch.no_grad():
+            vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
+            model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
+            g2 = pkg["viewspace_points"].grad
+            model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
+            model.denom[vis] += 1
+            if it < opt.densify_until_iter and it > opt.densify_from_iter and it % opt.densification_interval == 0:
+                model.densify_and_prune(case.bbox)
+            if model.P == 0:
+                raise ValueError("No Gaussian left")
+            if it < opt.iterations:
+                model.optimizer.step()
+                model.optimizer.zero_grad(set_to_none=True)
+        if be.name == "hip":
+            torch.cuda.synchronize()
+        t_train += time.perf_counter() - t0
+        if it % eval_every == 0 or it == opt.iterations:
+            out["iters"].append(it)
+            out["psnr"].append(psnr3d(case, model))
+            out["P"].append(model.P)
+            if log:
+                log("it %5d  P %6d  psnr3d %.3f dB  loss %.4e  (%.1f it/s)" % (it, model.P, out["psnr"][-1], float(loss),
+                                                                              it / t_train))
+    out["it_per_s"] = opt.iterations / t_train
+    return out
