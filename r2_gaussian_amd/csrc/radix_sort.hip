@@ -324,7 +324,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
             const uint32_t d = (key[i] >> shift) & (radix - 1u);
             const uint32_t pos = digit_off[pidx(d)] + wh[pidx(d)] + rank[i];
             if (INV) {
-                inv[idx] = pos;
+                if (inv != nullptr) inv[idx] = pos;   // introspection only (debug mode)
             } else {
                 kout[pos] = key[i];
                 if (INVV) inv[val[i]] = pos;

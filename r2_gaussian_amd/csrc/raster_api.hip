@@ -58,7 +58,7 @@ extern "C" int r2_raster_forward(
     if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
-                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, s); }
+                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, true, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     uint32_t hw[DW_COUNT] = { 0 };
     if (hinted) {
@@ -94,7 +94,7 @@ extern "C" int r2_raster_forward(
     const bool overflow = hw[DW_OVERFLOW] != 0;
     bool full_order = !hinted;   // order / offsets cover all P Gaussians (else only the visible prefix)
     if (overflow) {   // general radix sort instead
-        rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
+        rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, nullptr /* values = indices */, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
                                                 s, host_words + DW_TOTAL);
@@ -137,7 +137,7 @@ extern "C" int r2_raster_forward(
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK,
                                  debug ? nullptr : img.tile_done, 0u};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
-                                          bin.inv, R, bit, &tile_counts, s, &wo);
+                                          debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo);   // inv: introspection only
             work_built = true;
         } else {   // > 4096 tiles: general multi-pass sort, then invert its permutation (the scratch is free until backward)
             uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)

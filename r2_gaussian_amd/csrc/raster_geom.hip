@@ -68,7 +68,7 @@ __device__ __forceinline__ void raster_preprocess_one(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
-    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
     uint32_t *__restrict__ thin_flag, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
 {
@@ -76,7 +76,6 @@ __device__ __forceinline__ void raster_preprocess_one(
     radii[idx] = 0;
     tiles_touched[idx] = 0;
     depth_key[idx] = 0xFFFFFFFFu;   // culled Gaussians sort behind every visible one
-    iota[idx] = (uint32_t)idx;
 
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     const float3 p_view = xform4x3(p, view);
@@ -92,8 +91,10 @@ __device__ __forceinline__ void raster_preprocess_one(
     } else {
         const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
         cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q, cov3D);
+        // stored for the backward like the reference's geometry state (written even if rejected below, Q12)
+        if (cov3Ds != nullptr)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];   // written even if rejected below (Q12)
+            for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];
     }
 
     Cov2D c;
@@ -158,7 +159,7 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
-    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
     uint32_t *__restrict__ thin_flag, DepthReg reg)
 {
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P)
         raster_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,
-                              tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, iota, cov3Ds, tiles_touched, op_mu,
+                              tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds, tiles_touched, op_mu,
                               thin_flag, reg, key, bt);
     depth_register_end(reg, (uint32_t)idx, key, bt);
 }
@@ -288,12 +289,14 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
     const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
     const float2 om = op_mu[idx];
-    float cov3D[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float sc_in[3] = { 0.f, 0.f, 0.f };
     float4 rot_in = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cov3D[6];
+    // the covariance comes from the forward's state (recomputing it from scales / rotations instead -- 24 B/Gaussian less
+    // to write and read -- was measured: the preprocess got no faster, this kernel 1.2 us slower: both are latency-bound)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
     if (scales != nullptr) {
         sc_in[0] = scales[3 * idx]; sc_in[1] = scales[3 * idx + 1]; sc_in[2] = scales[3 * idx + 2];
         rot_in = reinterpret_cast<const float4 *>(rotations)[idx];
@@ -434,14 +437,14 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, hipStream_t s)
+                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s)
 {
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.iota, g.cov3D, g.tiles_touched, g.op_mu, thin_flag,
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr, g.tiles_touched, g.op_mu, thin_flag,
         reg);
     return 0;
 }

@@ -29,10 +29,13 @@ __device__ __forceinline__ int row_tier(float A2, float L, float hx)
     // conditional sigma of ~0.33 px); 2: exact per-pixel evaluation
     // q(c) = log2 G(c) = p(c) - L <= 0 is the concave parabola; the evaluated exponent p = q + L underflows (exp2 -> 0, or a
     // flushed denormal) when q0 < -(126 + L), and a later pixel still passes the cut-off when q(c) >= log2(1e-5) - L.
-    // q(c) <= -(sqrt(-q0) - c sqrt|A2|)^2, so c steps are safe if sqrt(126 + L) - c sqrt|A2| >= sqrt(L - log2(1e-5) + 1).
-    // (Round 1 used sqrt(126) for the first term: too optimistic by sqrt(126) - sqrt(126 + L) for L < 0 -- found by the
-    // pure-1e-4 parity check on sub-pixel Gaussians, which lost one 1.3e-5 contribution.)  The 0.5 keeps clear of the
-    // last normal binade.
+    // sqrt(-q) is Lipschitz along a pixel row with constant sqrt|A2|, so c steps from an underflowed start cannot reach the
+    // cut-off if sqrt(126 + L) - c sqrt|A2| >= sqrt(L - log2(1e-5) + 1).  (Round 1 used sqrt(126) for the first term: too
+    // optimistic by sqrt(126) - sqrt(126 + L) for L < 0 -- found by the pure-1e-4 parity check on sub-pixel Gaussians, which
+    // lost one 1.3e-5 contribution.)  The 0.5 keeps clear of the last normal binade.
+    // These thresholds are also where the recurrence's ACCURACY ends: carrying alpha * 2^64 through the recurrence moves the
+    // underflow out of reach (measured, round 2) and would allow |A2| <= ~2 on the 8-step path, but 7 ratio steps at
+    // |A2| > ~1.1 put the covariance gradients of such Gaussians 1.3-2.6x outside the 1e-4 bound.
     const float room = sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
     const float s8 = room * (1.0f / 7.0f), s4 = room * (1.0f / 3.0f);
     const float a = fabsf(A2);
@@ -159,7 +162,7 @@ struct RasterImage {
 int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
-                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, hipStream_t s);
+                             int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
                             const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);

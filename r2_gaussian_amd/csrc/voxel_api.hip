@@ -64,7 +64,7 @@ extern "C" int r2_voxel_forward(
     if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
     { StageScope t(ST_VOX_PREPROCESS, s);
     launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
-                            radii_y, radii_z, reg, s); }
+                            radii_y, radii_z, reg, true, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     uint32_t hw[DW_COUNT] = { 0 };
     if (hinted) {
@@ -98,7 +98,7 @@ extern "C" int r2_voxel_forward(
     const bool overflow = hw[DW_OVERFLOW] != 0;
     bool full_order = !hinted;   // order / offsets cover all P Gaussians (else only the visible prefix)
     if (overflow) {   // general radix sort instead
-        rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, geom.iota, geom.order, nullptr,
+        rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, nullptr /* values = indices */, geom.order, nullptr,
                            nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
         if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
                                                 s, host_words + DW_TOTAL);
@@ -136,7 +136,7 @@ extern "C" int r2_voxel_forward(
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(R), nullptr,
                                  voxel_short_list_min(debug != 0)};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
-                                          bin.inv, R, bit, &tile_counts, s, &wo);
+                                          debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo);   // inv: introspection only
             work_built = true;
         } else {   // > 4096 tiles (e.g. 256^3): general multi-pass sort of (tile, Gaussian id) pairs -- no permutation is
                    // carried along: the backward recomputes an instance's emission index from the Gaussian's tile cube

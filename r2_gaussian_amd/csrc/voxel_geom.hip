@@ -34,7 +34,7 @@ __device__ __forceinline__ void voxel_preprocess_one(
     int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const VoxelGrid &v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
-    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
 {
     key_out = DEPTH_CULLED_KEY;
@@ -48,7 +48,6 @@ __device__ __forceinline__ void voxel_preprocess_one(
     // unsigned ints, negative z sorts after positive -- quirk Q10).  Culled Gaussians emit nothing, so their
     // position in the depth order is irrelevant.
     depth_key[idx] = __float_as_uint(p.z);
-    iota[idx] = (uint32_t)idx;
 
     float cov3D[6];
     if (cov3D_precomp != nullptr) {
@@ -57,8 +56,9 @@ __device__ __forceinline__ void voxel_preprocess_one(
     } else {
         const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
         cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q, cov3D);
+        if (cov3Ds != nullptr)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];
+            for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];
     }
     M3 M;
     float h[6];
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
-    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, uint32_t *__restrict__ iota,
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -132,7 +132,7 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P)
         voxel_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z,
-                             rec, depth_key, iota, cov3Ds, tiles_touched, ext, reg, key, bt);
+                             rec, depth_key, cov3Ds, tiles_touched, ext, reg, key, bt);
     depth_register_end(reg, (uint32_t)idx, key, bt);
 }
 
@@ -326,11 +326,11 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            hipStream_t s)
+                            bool store_cov3D, hipStream_t s)
 {
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
-                                                                        radii_z, g.rec, g.depth_key, g.iota, g.cov3D,
+                                                                        radii_z, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr,
                                                                         g.tiles_touched, g.ext, reg);
     return 0;
 }

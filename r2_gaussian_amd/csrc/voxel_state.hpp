@@ -141,7 +141,7 @@ struct VoxelGrid {
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            hipStream_t s);
+                            bool store_cov3D, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,

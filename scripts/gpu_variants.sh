@@ -1,0 +1,7 @@
+#!/bin/bash
+# time several builds of the library through the C-ABI harness: scripts/gpu_variants.sh libA.so libB.so ...
+cd $GRAFT_REPO_ROOT
+for L in "$@"; do
+  echo "=== $L"
+  for rep in 1 2; do timeout 200 scripts/cbench ${STEPS:-300} r2_gaussian_amd/$L 2>&1 | grep -E "BEST|raster\.|voxel 256|voxel 32" | head -13 | tr '\n' ';' ; echo; done
+done

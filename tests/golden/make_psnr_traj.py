@@ -1,0 +1,27 @@
+"""Generates tests/golden/psnr_traj_oracle.json: the 3D-PSNR trajectory of the miniature trainer (tests/mini_trainer.py) on
+the synthetic cone-beam case with the CPU ORACLE as renderer / voxelizer -- the reference's arithmetic end to end.
+tests/test_psnr_parity_gpu.py trains the same case with the HIP kernels and compares at matched iterations (<= 0.1 dB).
+
+    python tests/golden/make_psnr_traj.py            (about 10 minutes on 8 cores)
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+CASE = dict(detector=128, n_vol=64, n_views=50, p_gt=20000, n_init=5000, seed=2)
+OPT = dict(iterations=1500, densify_from_iter=300, densify_until_iter=1200, densification_interval=100)
+EVAL_EVERY = 100
+
+if __name__ == "__main__":
+    import torch
+    from tests import mini_trainer as T
+    torch.set_num_threads(os.cpu_count())
+    case = T.Case(**CASE)
+    out = T.train(case, T.Opt(**OPT), "oracle", eval_every=EVAL_EVERY, seed=0, log=print)
+    out.update(case=CASE, opt=OPT, eval_every=EVAL_EVERY)
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "psnr_traj_oracle.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("final psnr3d %.3f dB, P %d, %.2f it/s" % (out["psnr"][-1], out["P"][-1], out["it_per_s"]))

@@ -89,8 +89,9 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
     out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
-    out["inv"] = read(13, np.uint32, R)
-    out["perm"] = perm_from_inv(out["inv"])
+    if debug and max(int(T) - 1, 1).bit_length() <= 12:   # inverse permutation of the single-pass tile sort: debug mode only
+        out["inv"] = read(13, np.uint32, R)
+        out["perm"] = perm_from_inv(out["inv"])
     # the reference's 64-bit sort keys, reconstructed: (tile << 32) | depth bits of the listed Gaussian
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)
     # decode the packed render record back to the reference's quantities
@@ -159,7 +160,7 @@ def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
     out["first"] = read(11, np.uint32, P)
     out["order"] = read(12, np.uint32, P)
     out["host_words"] = read(15, np.uint32, 8)   # {num_rendered, overflow, thin, key extrema x4, nvis (hinted path only)}
-    if max(int(T) - 1, 1).bit_length() <= 12:   # the inverse permutation is only written by the single-pass (<= 12-bit) tile sort
+    if debug and max(int(T) - 1, 1).bit_length() <= 12:   # inverse permutation: single-pass (<= 12-bit) tile sort, debug mode
         out["inv"] = read(13, np.uint32, R)
         out["perm"] = perm_from_inv(out["inv"])
     out["keys"] = (out["tiles"].astype(np.uint64) << np.uint64(32)) | out["depth_key"][out["point_list"]].astype(np.uint64)

@@ -36,10 +36,12 @@ def _case(case):
 def test_indices_bit_exact(case, oracle, gpu):
     c, v = _case(case)
     o = Hh.oracle_raster(oracle, c, v, render=False)
-    h = Hh.hip_raster(c, v, gpu)
+    h = Hh.hip_raster(c, v, gpu, debug=True)   # debug: the introspection-only state (cov3D, inverse permutation) is written
     assert h["num_rendered"] == o["num_rendered"] > 0
     assert np.array_equal(h["radii"], o["radii"])
     Hh.check_binning(h, o)
+    hp = Hh.hip_raster(c, v, gpu)                # ... and the production path bins identically
+    assert np.array_equal(hp["point_list"], h["point_list"]) and np.array_equal(hp["ranges"], h["ranges"])
     # values feeding the indices are bit-exact too (same op order, no contraction)
     assert np.array_equal(h["cov3D"].view(np.uint32), o["cov3D"].view(np.uint32))
     vis = o["radii"] > 0

@@ -58,7 +58,7 @@ def test_depth_hint_paths_are_identical_and_stale_hints_are_harmless(oracle, gpu
         h1 = Hh.hip_raster(c, v, gpu)                  # same P again: hinted
         assert int(h1["host_words"][7]) == int((h1["tiles_touched"] > 0).sum()) > 0
         assert int(h1["host_words"][1]) == 0
-        for k in ("tiles_touched", "tiles_unsorted", "vals_unsorted", "point_list", "ranges", "inv", "first", "color"):
+        for k in ("tiles_touched", "tiles_unsorted", "vals_unsorted", "point_list", "ranges", "first", "color"):
             assert np.array_equal(h0[k], h1[k]), k
         o = Hh.oracle_raster(oracle, c, v, render=False)
         Hh.check_binning(h1, o)

@@ -29,11 +29,13 @@ def test_indices_bit_exact(case, oracle, gpu):
     P, n, s, ctr, sm = case
     c = _cloud(case)
     o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
-    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu, debug=True)   # debug: introspection-only state (cov3D, inverse permutation) is written
     assert h["num_rendered"] == o["num_rendered"] > 0
     for k in ("radii_x", "radii_y", "radii_z"):
         assert np.array_equal(h[k], o[k]), "%s differs (%d mismatches)" % (k, int((h[k] != o[k]).sum()))
     Hh.check_binning(h, o)
+    hp = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert np.array_equal(hp["point_list"], h["point_list"]) and np.array_equal(hp["ranges"], h["ranges"])
     assert np.array_equal(h["cov3D"].view(np.uint32), o["cov3D"].view(np.uint32))
     vis = o["tiles_touched"] > 0
     assert np.array_equal(h["means3D_norm"][vis].view(np.uint32), o["means3D_norm"][vis].view(np.uint32))
