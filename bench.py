@@ -48,9 +48,9 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 
 # stage (r2_profile_* name) -> kernel name in the rocprofv3 / PMC summaries
 STAGE_KERNEL = {
-    "raster.render_bwd": "r2::raster_render_backward_kernel",
-    "raster.render_fwd": "r2::raster_render_forward_kernel<false, true>",
-    "raster.geom_bwd": "r2::raster_geom_backward_kernel",
+    "raster.render_bwd": "r2::raster_render_backward_kernel<false>",
+    "raster.render_fwd": "r2::raster_render_forward_kernel<false, true, false>",
+    "raster.geom_bwd": "r2::raster_geom_backward_kernel<false>",
     "raster.preprocess": "r2::raster_preprocess_kernel",
     "raster.duplicate": "r2::raster_duplicate_kernel",
 }
@@ -336,6 +336,46 @@ def main():
             fr.append(max_over_ranks(time.perf_counter() - t0))
         fwd_only = summarize(fr, nf, world)
 
+    # ---- batched views (new functionality, reported NEXT TO the per-view drop-in number, never instead of it): BV views of
+    # the same Gaussians per call through r2_raster_forward_batch / _backward_batch -- what a trainer that accumulates
+    # several views per optimiser step calls.  Same views, same upstream gradient, forward + backward.
+    batched = None
+    if rank == 0 or world > 1:
+        from r2_gaussian_amd import GaussianRasterizerBatch
+        BV = 4
+        nbt = len(views) // BV
+        bsets = []
+        for b_ in range(nbt):
+            vs_ = views[b_ * BV:(b_ + 1) * BV]
+            bsets.append(GaussianRasterizerBatch(GaussianRasterizationSettings(
+                image_height=HW, image_width=HW, tanfovx=vs_[0].tanfovx, tanfovy=vs_[0].tanfovy, scale_modifier=1.0,
+                viewmatrix=torch.stack([v.world_view_transform for v in vs_]).to(dev),
+                projmatrix=torch.stack([v.full_proj_transform for v in vs_]).to(dev),
+                campos=torch.stack([v.camera_center for v in vs_]).to(dev), prefiltered=False, mode=vs_[0].mode, debug=False)))
+        m2b = torch.zeros((BV,) + tuple(xyz.shape), device=dev, requires_grad=True)
+        dLb = dL.expand(BV, HW, HW).contiguous()
+
+        def bstep(j):
+            imgb, _rb = bsets[(j * world + rank) % nbt](means3D=xyz, means2D=m2b, opacities=dens, scales=scal, rotations=rot)
+            m2b.grad = None
+            for p_ in params:
+                p_.grad = None
+            imgb.backward(dLb)
+        for j in range(2 * nbt):
+            bstep(j)
+        nbs = max(5, args.steps // BV)
+        brs = []
+        for _ in range(5 if args.steps >= 500 else 15):
+            barrier()
+            t0 = time.perf_counter()
+            for j in range(nbs):
+                bstep(j)
+            barrier()
+            brs.append(max_over_ranks(time.perf_counter() - t0))
+        batched = summarize(brs, nbs * BV, world)
+        batched.update(views_per_call=BV, note="r2_raster_forward_batch + _backward_batch, %d views per call; no gradient "
+                                               "exchange in this loop; each view bit-identical to the single-view call" % BV)
+
     # ---- instrumented pass: per-stage breakdown (not part of `value`)
     _lib.profile_enable(None)
     for _ in range(min(args.steps, 50)):
@@ -503,6 +543,7 @@ def main():
                                         "max over ranks" % (repeats, args.steps)),
             "overlapped": overlapped,
             "forward_only": fwd_only,
+            "batched": batched,
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note, "us_per_launch": round(dom_us, 2), "launches_timed": int(dom[1]),

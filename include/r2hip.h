@@ -114,6 +114,49 @@ R2_API int r2_raster_backward(
 R2_API int r2_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                     uint8_t *present /* [P] bool */, void *stream);
 
+/* ---- rasterizer, batched views (NEW functionality: the reference renders one view per call) ----
+ * V views of the SAME Gaussians (same detector size, tan_fov and mode; V camera poses) through one pass of the pipeline:
+ * the views become V * P "view instances" on a tile grid that stacks the views' grids, so every latency-bound stage
+ * (preprocess, depth order, instance emission, tile sort) runs once on V times the work.  A trainer that accumulates
+ * several views per optimiser step (view-sharded data parallelism) calls these instead of V single-view
+ * calls.  Every view is evaluated with exactly the arithmetic of r2_raster_forward / r2_raster_backward: out_color[v] and
+ * radii[v] are bit-identical to the single-view call's, tile lists too.
+ *   forward : viewmatrices / projmatrices [V,16]; out_color [V,H,W]; radii [V,P]; returns num_rendered over all views;
+ *             width * height need not be tile-aligned.
+ *   backward: dL_dpix [V,H,W]; per view: dL_dmean2D [V,P,3], dL_dconic [V,P,2,2], dL_dmu [V,P]; SUMMED over the views (in
+ *             view order, deterministic): dL_dopacity [P], dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dscale [P,3], dL_drot [P,4]. */
+R2_API int r2_raster_forward_batch(
+    r2_alloc_fn geometryBuffer, void *geometry_user,
+    r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user,
+    int P, int V, int width, int height,
+    const float *means3D, const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp,
+    const float *viewmatrices, /* [V,16] */
+    const float *projmatrices, /* [V,16] */
+    float tan_fovx, float tan_fovy, int mode,
+    float *out_color,          /* [V,H,W] */
+    int *radii,                /* [V,P] */
+    int debug, void *stream);
+
+R2_API int r2_raster_backward_batch(
+    int P, int V, int R, int width, int height,
+    const float *means3D, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+    float tan_fovx, float tan_fovy,
+    const int *radii,          /* [V,P] */
+    char *geom_buffer, char *binning_buffer, char *img_buffer,
+    const float *dL_dpix,      /* [V,H,W] */
+    float *dL_dmean2D,         /* [V,P,3] */
+    float *dL_dconic,          /* [V,P,2,2]; 16-byte aligned */
+    float *dL_dopacity,        /* [P,1]   summed over the views */
+    float *dL_dmu,             /* [V,P] */
+    float *dL_dmean3D,         /* [P,3]   summed */
+    float *dL_dcov3D,          /* [P,6]   summed */
+    float *dL_dscale,          /* [P,3]   summed */
+    float *dL_drot,            /* [P,4]   summed */
+    int mode, int debug, void *stream);
+
 /* ---- voxelizer ------------------------------------------------------------------------------- */
 R2_API int r2_voxel_forward(
     r2_alloc_fn geometryBuffer, void *geometry_user,

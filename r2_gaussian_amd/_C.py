@@ -239,6 +239,80 @@ def rasterize_gaussians_backward(means3D, radii, scales, rotations, scale_modifi
     return dL_dmeans2D, dL_dopacity, dL_dmu, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drot
 
 
+# ---------------------------------------------------------------------------------------------- batched views (new)
+def rasterize_gaussians_batch(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices, projmatrices,
+                              tan_fovx, tan_fovy, image_height, image_width, mode, debug):
+    """V views of the same Gaussians in one pass (r2_raster_forward_batch): viewmatrices / projmatrices [V,4,4] ->
+    (num_rendered, out_color[V,H,W], radii[V,P] i32, geomBuffer, binningBuffer, imgBuffer).  Each view's image and radii are
+    bit-identical to ``rasterize_gaussians`` for that view."""
+    if means3D.ndim != 2 or means3D.shape[1] != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    _require_gpu(means3D, "means3D")
+    if viewmatrices.ndim != 3 or viewmatrices.shape[1:] != (4, 4) or projmatrices.shape != viewmatrices.shape:
+        raise RuntimeError("viewmatrices / projmatrices must have dimensions (num_views, 4, 4)")
+    dev = means3D.device
+    P, V, H, W = means3D.shape[0], viewmatrices.shape[0], int(image_height), int(image_width)
+    hk = _hooks(dev)
+    if P == 0:
+        return 0, torch.zeros((V, H, W), dtype=_F32, device=dev), torch.zeros((V, 0), dtype=torch.int32, device=dev), \
+            hk.empty, hk.empty, hk.empty
+    out_color = torch.empty((V, H, W), dtype=_F32, device=dev)
+    radii = torch.empty((V, P), dtype=torch.int32, device=dev)
+    m3 = _dev_f32(means3D, means3D)
+    op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
+    vm, pm = (_dev_f32(t, means3D) for t in (viewmatrices, projmatrices))
+    st = hk.begin()
+    try:
+        with _on_device(dev):
+            rc = _lib.lib().r2_raster_forward_batch(
+                hk.cbs[0], None, hk.cbs[1], None, hk.cbs[2], None, P, V, W, H, _ptr(m3), _ptr(op), _ptr(sc),
+                float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm), float(tan_fovx), float(tan_fovy), int(mode),
+                out_color.data_ptr(), radii.data_ptr(), int(bool(debug)), _stream(dev))
+    finally:
+        bufs = hk.finish(st)
+    rendered = _lib.check(rc, "r2_raster_forward_batch")
+    return rendered, out_color, radii, bufs[0], bufs[1], bufs[2]
+
+
+def rasterize_gaussians_backward_batch(means3D, radii, scales, rotations, scale_modifier, cov3D_precomp, viewmatrices,
+                                       projmatrices, tan_fovx, tan_fovy, dL_dout_color, geomBuffer, R, binningBuffer,
+                                       imageBuffer, mode, debug):
+    """-> (dL_dmeans2D[V,P,3], dL_dopacity[P,1], dL_dmu[V,P], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dscales[P,3],
+    dL_drotations[P,4]): per-view screen-space gradients (the densification statistics are per view), parameter gradients
+    summed over the V views in view order."""
+    _require_gpu(means3D, "means3D")
+    dev = means3D.device
+    P, V = means3D.shape[0], viewmatrices.shape[0]
+    H, W = int(dL_dout_color.shape[-2]), int(dL_dout_color.shape[-1])
+    # per-view arrays first (16-byte rows in front), then rot | means3D | scales | opacity adjacent like the single-view
+    # backward: the block dist.grad_block() hands to the all-reduce
+    flat = torch.empty(8 * V * P + 17 * P, dtype=_F32, device=dev)
+    o = 0
+    dL_dconic = flat.as_strided((V, P, 2, 2), (4 * P, 4, 2, 1), o); o += 4 * V * P
+    dL_drot = flat.as_strided((P, 4), (4, 1), o); o += 4 * P
+    dL_dmeans3D = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
+    dL_dscales = flat.as_strided((P, 3), (3, 1), o); o += 3 * P
+    dL_dopacity = flat.as_strided((P, 1), (1, 1), o); o += P
+    dL_dcov3D = flat.as_strided((P, 6), (6, 1), o); o += 6 * P
+    dL_dmeans2D = flat.as_strided((V, P, 3), (3 * P, 3, 1), o); o += 3 * V * P
+    dL_dmu = flat.as_strided((V, P), (P, 1), o)
+    if P != 0:
+        m3 = _dev_f32(means3D, means3D)
+        sc, ro, cp = (_dev_f32(t, means3D) for t in (scales, rotations, cov3D_precomp))
+        vm, pm = (_dev_f32(t, means3D) for t in (viewmatrices, projmatrices))
+        g = _dev_f32(dL_dout_color, means3D)
+        rad = radii.contiguous()
+        with _on_device(dev):
+            rc = _lib.lib().r2_raster_backward_batch(
+                P, V, int(R), W, H, _ptr(m3), _ptr(sc), float(scale_modifier), _ptr(ro), _ptr(cp), _ptr(vm), _ptr(pm),
+                float(tan_fovx), float(tan_fovy), rad.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer),
+                _ptr(g), dL_dmeans2D.data_ptr(), dL_dconic.data_ptr(), dL_dopacity.data_ptr(), dL_dmu.data_ptr(),
+                dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(), dL_dscales.data_ptr(), dL_drot.data_ptr(), int(mode),
+                int(bool(debug)), _stream(dev))
+        _lib.check(rc, "r2_raster_backward_batch")
+    return dL_dmeans2D, dL_dopacity, dL_dmu, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drot
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     """-> bool[P], ``z_view > 0.2``  (SUB/rasterize_points.cu:166-185)."""
     _require_gpu(means3D, "means3D")

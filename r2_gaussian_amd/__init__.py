@@ -7,7 +7,7 @@
 Drop-in import names for unmodified reference code live in the top-level shim packages
 ``xray_gaussian_rasterization_voxelization`` and ``simple_knn``.
 """
-from .rasterization import GaussianRasterizationSettings, GaussianRasterizer   # noqa: F401
+from .rasterization import GaussianRasterizationSettings, GaussianRasterizer, GaussianRasterizerBatch   # noqa: F401
 from .voxelization import GaussianVoxelizationSettings, GaussianVoxelizer      # noqa: F401
 from ._C import distCUDA2                                                      # noqa: F401
 

@@ -26,6 +26,10 @@ _SIGNATURES = {
     "r2_raster_backward": (C.c_int, [_i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp, _fp, _fp, _f, _f, _p, _p, _p, _p,
                                      _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _p]),
     "r2_mark_visible": (C.c_int, [_i, _fp, _fp, _fp, _p, _p]),
+    "r2_raster_forward_batch": (C.c_int, [ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _i, _fp, _fp, _fp, _f, _fp,
+                                          _fp, _fp, _fp, _f, _f, _i, _fp, _p, _i, _p]),
+    "r2_raster_backward_batch": (C.c_int, [_i, _i, _i, _i, _i, _fp, _fp, _f, _fp, _fp, _fp, _fp, _f, _f, _p, _p, _p, _p,
+                                           _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _i, _p]),
     "r2_voxel_forward": (C.c_int, [ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f,
                                    _fp, _fp, _fp, _f, _fp, _fp, _i, _fp, _p, _p, _p, _i, _p]),
     "r2_voxel_backward": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _fp, _f, _fp, _fp, _p, _p, _p,

@@ -4,61 +4,65 @@
 
 using namespace r2;
 
-extern "C" int r2_raster_forward(
-    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
-    r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height, const float *means3D,
+// Forward of V views of the same Gaussians (V = 1: the reference's call).  viewmatrices / projmatrices: [V,16]; out_color
+// [V,H,W]; radii [V,P].  See raster_state.hpp (tile_decode) for how the views share one pipeline.
+static int raster_forward_impl(
+    const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int V, int width, int height, const float *means3D,
     const float *opacities, const float *scales, float scale_modifier, const float *rotations,
-    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
-    float tan_fovx, float tan_fovy, int prefiltered, int mode, float *out_color, int *radii, int debug, void *stream)
+    const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+    float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, int debug, hipStream_t s)
 {
-    (void)cam_pos;
-    (void)prefiltered;   // the reference only uses it to trap on an impossible state (RAS/auxiliary.h:160-164)
-    hipStream_t s = (hipStream_t)stream;
     host_mark_forward_begin();
-    if (P < 0 || width <= 0 || height <= 0 || !geometryBuffer || !binningBuffer || !imageBuffer || !out_color) {
-        set_error("r2_raster_forward: invalid argument");
+    if (P < 0 || V < 1 || width <= 0 || height <= 0 || !geometryBuffer || !binningBuffer || !imageBuffer || !out_color) {
+        set_error("%s: invalid argument", what);
         return R2_ERR_INVALID;
     }
-    const size_t N = (size_t)width * height;
+    const size_t N = (size_t)width * height * (size_t)V;
     const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
-    const size_t T = (size_t)gx * gy;
+    const size_t T = (size_t)gx * gy * (size_t)V;
+    if ((size_t)P * (size_t)V >= (size_t)1 << 31 || T >= (size_t)1 << 24) {
+        set_error("%s: %d views x %d Gaussians / %zu tiles exceed the 31-bit instance / 24-bit tile range", what, V, P, T);
+        return R2_ERR_INVALID;
+    }
     if (P == 0) {   // the torch boundary skips the call (SUB/rasterize_points.cu:70); out_color is pre-zeroed
         R2_HIP_TRY(hipMemsetAsync(out_color, 0, N * sizeof(float), s));
         return 0;
     }
-    if (!means3D || !opacities || !viewmatrix || !projmatrix || !radii ||
+    if (!means3D || !opacities || !viewmatrices || !projmatrices || !radii ||
         (!cov3D_precomp && (!scales || !rotations))) {
-        set_error("r2_raster_forward: NULL input (need means3D, opacities, matrices, radii and scales+rotations or cov3D_precomp)");
+        set_error("%s: NULL input (need means3D, opacities, matrices, radii and scales+rotations or cov3D_precomp)", what);
         return R2_ERR_INVALID;
     }
     if (mode != 0 && mode != 1) {
-        set_error("r2_raster_forward: unsupported mode %d", mode);
+        set_error("%s: unsupported mode %d", what, mode);
         return R2_ERR_INVALID;
     }
+    const int PV = P * V;   // view instances: everything between the preprocess and the render kernels works on these
 
-    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P).bytes, geometry_user);
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, PV).bytes, geometry_user);
     if (!gchunk) {
-        set_error("r2_raster_forward: state allocation callback returned NULL");
+        set_error("%s: state allocation callback returned NULL", what);
         return R2_ERR_ALLOC;
     }
-    const RasterGeom geom = RasterGeom::carve(gchunk, P);
+    const RasterGeom geom = RasterGeom::carve(gchunk, PV);
 
-    // Binning, first half: Gaussians in (depth, id) order + their instance offsets in that order.
-    //   hinted path (depth range known from the previous call with this P): preprocess registers every key in its bucket,
+    // Binning, first half: view instances in (depth, id) order + their instance offsets in that order.
+    //   hinted path (depth range known from the previous call with this size): preprocess registers every key in its bucket,
     //   one dual scan + place + rank finish the job, and the host's read-back overlaps place + rank;
     //   un-hinted path: min/max, count, scan, place, rank, then the offsets scan;
     //   either may overflow a bucket (many identical depths / a stale hint): general radix sort + scan instead.
-    int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)P, s);   // zeroes counters + the host-read words
+    int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)PV, s);   // zeroes counters + the host-read words
     if (rc) return rc;
     uint32_t *host_words = geom.host_words;
     DepthHint hint;
-    const bool hinted = depth_hint_lookup(0, (size_t)P, &hint);
-    const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
+    const bool hinted = depth_hint_lookup(0, (size_t)PV, &hint);
+    const uint32_t pre_wgs = (uint32_t)((PV + 255) / 256);
     DepthReg reg{};
-    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)PV, hint);
     { StageScope t(ST_RAS_PREPROCESS, s);
-    launch_raster_preprocess(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
-                             projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, true, s); }
+    launch_raster_preprocess(geom, P, V, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrices,
+                             projmatrices, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, true, s); }
     R2_STAGE_CHECK(debug, s, "preprocess");
     uint32_t hw[DW_COUNT] = { 0 };
     if (hinted) {
@@ -66,23 +70,23 @@ extern "C" int r2_raster_forward(
         rc = host_mailbox_arm(&mailbox, &mailbox_seq);
         if (rc) return rc;
         { StageScope t(ST_RAS_SCAN, s);
-        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)P, pre_wgs, mailbox, mailbox_seq, s); }
+        rc = depth_order_fast_scan(geom.dorder_temp, (size_t)PV, pre_wgs, mailbox, mailbox_seq, s); }
         if (rc) return rc;
         { StageScope t(ST_RAS_DEPTHSORT, s);
-        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)P, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
+        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)PV, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
         if (rc) return rc;
         rc = host_mailbox_wait(mailbox_seq, hw, DW_COUNT, s);   // the GPU places + ranks while the host waits for the words
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "depth order (hinted)");
     } else {
         { StageScope t(ST_RAS_DEPTHSORT, s);
-        rc = depth_order_buckets(geom.dorder_temp, geom.dorder_bytes, geom.depth_key, geom.order, (size_t)P, s); }
+        rc = depth_order_buckets(geom.dorder_temp, geom.dorder_bytes, geom.depth_key, geom.order, (size_t)PV, s); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "depth order");
         // (fusing the scan's per-group reduction into the depth order's last kernel with per-wave atomics was measured
         // 4x slower than this separate 5 us kernel: ~5k atomics on ~75 addresses serialise at the memory side)
         { StageScope t(ST_RAS_SCAN, s);
-        rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P, s,
+        rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, PV, s,
                                        host_words + DW_TOTAL); }
         if (rc) return rc;
         R2_STAGE_CHECK(debug, s, "scan");
@@ -92,11 +96,11 @@ extern "C" int r2_raster_forward(
     }
     uint32_t num_rendered = hw[DW_TOTAL];
     const bool overflow = hw[DW_OVERFLOW] != 0;
-    bool full_order = !hinted;   // order / offsets cover all P Gaussians (else only the visible prefix)
+    bool full_order = !hinted;   // order / offsets cover all view instances (else only the visible prefix)
     if (overflow) {   // general radix sort instead
         rc = sort_pairs_ex(geom.psort_temp, geom.psort_bytes, geom.depth_key, geom.depth_sorted, nullptr /* values = indices */, geom.order, nullptr,
-                           nullptr, (size_t)P, 32, /*allow_skip=*/true, nullptr, s);
-        if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, P,
+                           nullptr, (size_t)PV, 32, /*allow_skip=*/true, nullptr, s);
+        if (!rc) rc = inclusive_scan_gather_u32(geom.scan_temp, geom.scan_bytes, geom.tiles_touched, geom.order, geom.offsets, PV,
                                                 s, host_words + DW_TOTAL);
         uint32_t total = 0;
         if (!rc) rc = read_host_words(host_words + DW_TOTAL, &total, 1, s);
@@ -104,9 +108,9 @@ extern "C" int r2_raster_forward(
         num_rendered = total;
         full_order = true;
     }
-    depth_hint_update(0, (size_t)P, hw, overflow);
+    depth_hint_update(0, (size_t)PV, hw, overflow);
     if (num_rendered > 0x7FFFFFFFu) {   // the API returns it as a non-negative int (like the reference's int num_rendered)
-        set_error("r2_raster_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
+        set_error("%s: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", what, num_rendered);
         return R2_ERR_INVALID;
     }
     const size_t R = num_rendered;
@@ -116,7 +120,7 @@ extern "C" int r2_raster_forward(
     char *bchunk = binningBuffer(RasterBinning::carve(nullptr, R).bytes, binning_user);
     char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, R, debug != 0).bytes, image_user);
     if (!bchunk || !ichunk) {
-        set_error("r2_raster_forward: binning/image allocation callback returned NULL");
+        set_error("%s: binning/image allocation callback returned NULL", what);
         return R2_ERR_ALLOC;
     }
     const RasterBinning bin = RasterBinning::carve(bchunk, R);
@@ -126,7 +130,7 @@ extern "C" int r2_raster_forward(
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
         { StageScope t(ST_RAS_DUPLICATE, s);
-        launch_raster_duplicate(geom, bin, P, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
+        launch_raster_duplicate(geom, bin, P, V, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)
@@ -160,11 +164,53 @@ extern "C" int r2_raster_forward(
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
     { StageScope t(ST_RAS_RENDER_FWD, s);
     // single-pass sort: the tile's last work item (or the combine kernel) also writes tiles[k] for the backward
-    launch_raster_render_forward(geom, bin, img, width, height, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
+    launch_raster_render_forward(geom, bin, img, width, height, V, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
                                  /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
     host_mark_forward_end();
     return (int)num_rendered;
+}
+
+static int raster_backward_impl(
+    const char *what, int P, int V, int R, int width, int height, const float *means3D, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+    float tan_fovx, float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer,
+    const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dmu,
+    float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, hipStream_t s)
+{
+    if (P == 0) return 0;
+    if (P < 0 || V < 1 || R < 0 || !means3D || !radii || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
+        !viewmatrices || !projmatrices || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmu || !dL_dmean3D || !dL_dcov3D ||
+        (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
+        set_error("%s: invalid argument", what);
+        return R2_ERR_INVALID;
+    }
+    const RasterGeom geom = RasterGeom::carve(geom_buffer, P * V);
+    const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
+    { StageScope t(ST_RAS_RENDER_BWD, s);
+    launch_raster_render_backward(geom, bin, radii, width, height, V, (size_t)R, dL_dpix, s); }
+    R2_STAGE_CHECK(debug, s, "render backward");
+    const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
+    { StageScope t(ST_RAS_GEOM_BWD, s);
+    launch_raster_geom_backward(P, V, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
+                                tan_fovy, viewmatrices, projmatrices, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D,
+                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, s); }
+    R2_STAGE_CHECK(debug, s, "geometry backward");
+    return 0;
+}
+
+extern "C" int r2_raster_forward(
+    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height, const float *means3D,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix, const float *cam_pos,
+    float tan_fovx, float tan_fovy, int prefiltered, int mode, float *out_color, int *radii, int debug, void *stream)
+{
+    (void)cam_pos;
+    (void)prefiltered;   // the reference only uses it to trap on an impossible state (RAS/auxiliary.h:160-164)
+    return raster_forward_impl("r2_raster_forward", geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user,
+                               P, 1, width, height, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix,
+                               projmatrix, tan_fovx, tan_fovy, mode, out_color, radii, debug, (hipStream_t)stream);
 }
 
 extern "C" int r2_raster_backward(
@@ -175,26 +221,38 @@ extern "C" int r2_raster_backward(
     float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, void *stream)
 {
     (void)campos;
-    hipStream_t s = (hipStream_t)stream;
-    if (P == 0) return 0;
-    if (P < 0 || R < 0 || !means3D || !radii || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dpix ||
-        !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dmu || !dL_dmean3D || !dL_dcov3D ||
-        (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
-        set_error("r2_raster_backward: invalid argument");
-        return R2_ERR_INVALID;
-    }
-    const RasterGeom geom = RasterGeom::carve(geom_buffer, P);
-    const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
-    { StageScope t(ST_RAS_RENDER_BWD, s);
-    launch_raster_render_backward(geom, bin, radii, width, height, (size_t)R, dL_dpix, s); }
-    R2_STAGE_CHECK(debug, s, "render backward");
-    const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
-    { StageScope t(ST_RAS_GEOM_BWD, s);
-    launch_raster_geom_backward(P, means3D, radii, cov3D, scales, rotations, scale_modifier, width, height, tan_fovx,
-                                tan_fovy, viewmatrix, projmatrix, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D,
-                                dL_dcov3D, dL_dscale, dL_drot, mode, geom, bin.part, s); }
-    R2_STAGE_CHECK(debug, s, "geometry backward");
-    return 0;
+    (void)img_buffer;
+    return raster_backward_impl("r2_raster_backward", P, 1, R, width, height, means3D, scales, scale_modifier, rotations, cov3D_precomp,
+                                viewmatrix, projmatrix, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, dL_dpix, dL_dmean2D,
+                                dL_dconic, dL_dopacity, dL_dmu, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode, debug,
+                                (hipStream_t)stream);
+}
+
+// ---- batched views (new functionality; the reference renders one view per call): see include/r2hip.h
+extern "C" int r2_raster_forward_batch(
+    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int V, int width, int height, const float *means3D,
+    const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+    float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, int debug, void *stream)
+{
+    return raster_forward_impl("r2_raster_forward_batch", geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer,
+                               image_user, P, V, width, height, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                               viewmatrices, projmatrices, tan_fovx, tan_fovy, mode, out_color, radii, debug, (hipStream_t)stream);
+}
+
+extern "C" int r2_raster_backward_batch(
+    int P, int V, int R, int width, int height, const float *means3D, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp, const float *viewmatrices, const float *projmatrices,
+    float tan_fovx, float tan_fovy, const int *radii, char *geom_buffer, char *binning_buffer, char *img_buffer,
+    const float *dL_dpix, float *dL_dmean2D, float *dL_dconic, float *dL_dopacity, float *dL_dmu,
+    float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, int debug, void *stream)
+{
+    (void)img_buffer;
+    return raster_backward_impl("r2_raster_backward_batch", P, V, R, width, height, means3D, scales, scale_modifier, rotations,
+                                cov3D_precomp, viewmatrices, projmatrices, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer,
+                                dL_dpix, dL_dmean2D, dL_dconic, dL_dopacity, dL_dmu, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode,
+                                debug, (hipStream_t)stream);
 }
 
 extern "C" int r2_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,

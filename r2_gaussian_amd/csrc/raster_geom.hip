@@ -64,7 +64,7 @@ __device__ __forceinline__ float mu_of(float circ, float diamond)
 // ------------------------------------------------------------------ forward: one lane per Gaussian
 // returns the Gaussian's depth key (DEPTH_CULLED_KEY if it emits nothing) and its number of tiles
 __device__ __forceinline__ void raster_preprocess_one(
-    int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    int idx /* view instance v * P + src */, int src /* Gaussian */, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
@@ -77,7 +77,7 @@ __device__ __forceinline__ void raster_preprocess_one(
     tiles_touched[idx] = 0;
     depth_key[idx] = 0xFFFFFFFFu;   // culled Gaussians sort behind every visible one
 
-    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    const float3 p = make_float3(means3D[3 * src], means3D[3 * src + 1], means3D[3 * src + 2]);
     const float3 p_view = xform4x3(p, view);
     if (p_view.z <= 0.2f) return;   // near cull (RAS/auxiliary.h:158)
     const float4 p_hom = xform4x4(p, proj);
@@ -87,10 +87,10 @@ __device__ __forceinline__ void raster_preprocess_one(
     float cov3D[6];
     if (cov3D_precomp != nullptr) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) cov3D[k] = cov3D_precomp[6 * idx + k];
+        for (int k = 0; k < 6; ++k) cov3D[k] = cov3D_precomp[6 * src + k];
     } else {
-        const float4 q = reinterpret_cast<const float4 *>(rotations)[idx];
-        cov3d_from_scale_rot(scales[3 * idx], scales[3 * idx + 1], scales[3 * idx + 2], scale_modifier, q, cov3D);
+        const float4 q = reinterpret_cast<const float4 *>(rotations)[src];
+        cov3d_from_scale_rot(scales[3 * src], scales[3 * src + 1], scales[3 * src + 2], scale_modifier, q, cov3D);
         // stored for the backward like the reference's geometry state (written even if rejected below, Q12)
         if (cov3Ds != nullptr)
 #pragma unroll
@@ -129,7 +129,7 @@ __device__ __forceinline__ void raster_preprocess_one(
     // alpha = opacity*mu*exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2 + L), L = log2(opacity*mu), and the
     // half-extents (hx, hy) of the bounding box of the set where alpha can reach the reference's 1e-5 cut-off
     // (RAS/forward.cu:374) -- the render kernels skip 8x8 pixel blocks that lie outside it.
-    const float op = opacities[idx];
+    const float op = opacities[src];
     const float opmu = op * mu;
     const float L = opmu > 0.0f ? log2f(opmu) : -INFINITY;
     float hx = INFINITY, hy = INFINITY;   // +inf: never cull (degenerate / ill-conditioned conics)
@@ -155,21 +155,24 @@ __device__ __forceinline__ void raster_preprocess_one(
 }
 
 __global__ void __launch_bounds__(256) raster_preprocess_kernel(
-    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    int P, int V, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
-    const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
+    const float *__restrict__ views, const float *__restrict__ projs, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
     uint32_t *__restrict__ thin_flag, DepthReg reg)
 {
+    // one lane per VIEW INSTANCE: idx = v * P + src (V = 1: the reference's one lane per Gaussian); view v's matrices
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
-    if (idx < P)
-        raster_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,
-                              tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds, tiles_touched, op_mu,
-                              thin_flag, reg, key, bt);
+    if (idx < P * V) {
+        const int v = V == 1 ? 0 : idx / P;
+        raster_preprocess_one(idx, idx - v * P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, views + 16 * v,
+                              projs + 16 * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds,
+                              tiles_touched, op_mu, thin_flag, reg, key, bt);
+    }
     depth_register_end(reg, (uint32_t)idx, key, bt);
 }
 
@@ -191,7 +194,7 @@ __global__ void __launch_bounds__(256) mark_visible_kernel(int P, const float *_
 // span 64 instances at a time (coalesced stores) and each lane finds its owner with a 6-step search over
 // the lanes' exclusive offsets (ds_bpermute), instead of every lane dribbling out its own run.
 __global__ void __launch_bounds__(256) raster_duplicate_kernel(
-    int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
+    int P /* view instances */, int Pview, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
     uint32_t *__restrict__ vals, const uint32_t *__restrict__ nvis)
 {
@@ -242,7 +245,9 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
             const uint32_t local = k - o_excl;
             const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
             const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
-            tiles[k] = (uint32_t)(ty * gx + tx);
+            // the views' tile grids are stacked: view v = o_id / Pview owns tile rows [v * gy, (v + 1) * gy)
+            const int vrow = Pview == P ? 0 : (int)(o_id / (uint32_t)Pview) * gy;
+            tiles[k] = (uint32_t)((vrow + ty) * gx + tx);
             vals[k] = o_id;
         }
     }
@@ -256,51 +261,56 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
 //   2. turn the moments into dL/dmean2D, dL/dconic, dL/dopacity, dL/dmu (the 7 sums of the reference);
 //   3. computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA backward (RAS/backward.cu:402-444).
 // Outputs are ASSIGNED; the caller's zero-initialisation covers the rows of culled Gaussians.
+template <bool MV>
 __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
-    int P, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
-    const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
-    float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ view,
-    const float *__restrict__ proj, const float4 *__restrict__ rec, const float2 *__restrict__ op_mu,
+    int P, int Vn, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
+    int cov_per_view, const float *__restrict__ scales, const float *__restrict__ rotations, float scale_modifier,
+    float h_x, float h_y, float tan_fovx, float tan_fovy, const float *__restrict__ views,
+    const float *__restrict__ projs, const float4 *__restrict__ rec, const float2 *__restrict__ op_mu,
     const uint32_t *__restrict__ first_inst,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part, float W_half, float H_half,
     float *__restrict__ dL_dconics, float *__restrict__ dL_dmus, float *__restrict__ dL_dmean2D,
     float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov,
     float *__restrict__ dL_dscale, float *__restrict__ dL_drot, int mode)
 {
+    // one lane per Gaussian; its V view instances g = v * P + idx are visited in view order and their gradients summed in
+    // that order (deterministic).  Per view: dL/dmean2D, dL/dconic, dL/dmu (rows g); summed over the views: dL/dopacity,
+    // dL/dmean3D, dL/dcov3D and, through ONE covariance backward on the sum (it is linear), dL/dscale, dL/drot (rows idx).
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= P) return;
-    if (!(radii[idx] > 0)) {
-        // culled Gaussian: all-zero gradient rows.  The reference gets them from the torch boundary's zero-filled
-        // tensors (SUB/rasterize_points.cu:124-131); writing them here spares the caller a 100 B/Gaussian memset.
-        dL_dmean2D[3 * idx + 0] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
-        dL_dopacity[idx] = 0.f;
-        dL_dmus[idx] = 0.f;
-        reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = 0.f;
-        dL_dmeans[3 * idx + 0] = 0.f; dL_dmeans[3 * idx + 1] = 0.f; dL_dmeans[3 * idx + 2] = 0.f;
-        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
-        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
-    }
-
-    // ---- 1. moments of w = G * dL/dpix over all tiles of this Gaussian
-    // every per-Gaussian input is requested up front so that its latency overlaps the (dependent) inv -> row gathers
-    const float4 ra = rec[2 * idx], rb = rec[2 * idx + 1];
-    const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];
-    const float2 om = op_mu[idx];
+    const int V = MV ? Vn : 1;   // single view: a compile-time trip count (the loop folds away)
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float sc_in[3] = { 0.f, 0.f, 0.f };
     float4 rot_in = make_float4(0.f, 0.f, 0.f, 0.f);
-    float cov3D[6];
-    // the covariance comes from the forward's state (recomputing it from scales / rotations instead -- 24 B/Gaussian less
-    // to write and read -- was measured: the preprocess got no faster, this kernel 1.2 us slower: both are latency-bound)
-#pragma unroll
-    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
     if (scales != nullptr) {
         sc_in[0] = scales[3 * idx]; sc_in[1] = scales[3 * idx + 1]; sc_in[2] = scales[3 * idx + 2];
         rot_in = reinterpret_cast<const float4 *>(rotations)[idx];
     }
+    float acc_op = 0.f, acc_mean[3] = { 0.f, 0.f, 0.f }, acc_cov[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+    for (int v = 0; v < V; ++v) {
+    const int g = v * P + idx;
+    const float *__restrict__ view = views + 16 * v;
+    const float *__restrict__ proj = projs + 16 * v;
+    if (!(radii[g] > 0)) {
+        // culled in this view: all-zero per-view rows.  The reference gets them from the torch boundary's zero-filled
+        // tensors (SUB/rasterize_points.cu:124-131); writing them here spares the caller a memset.
+        dL_dmean2D[3 * g + 0] = 0.f; dL_dmean2D[3 * g + 1] = 0.f; dL_dmean2D[3 * g + 2] = 0.f;
+        dL_dmus[g] = 0.f;
+        reinterpret_cast<float4 *>(dL_dconics)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        continue;
+    }
+
+    // ---- 1. moments of w = G * dL/dpix over all tiles of this view instance
+    // every per-instance input is requested up front so that its latency overlaps the (dependent) row gathers
+    const float4 ra = rec[2 * g], rb = rec[2 * g + 1];
+    const uint32_t first = first_inst[g], ninst = tiles_touched[g];
+    const float2 om = op_mu[g];
+    float cov3D[6];
+    // the covariance comes from the forward's state (recomputing it from scales / rotations instead -- 24 B/Gaussian less
+    // to write and read -- was measured: the preprocess got no faster, this kernel 1.2 us slower: both are latency-bound)
+    const size_t cbase = cov_per_view ? (size_t)g : (size_t)idx;   // cov3D_precomp is per Gaussian, the state per view instance
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * cbase + k];
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
     // this Gaussian's rows are contiguous: the render backward stores each instance's row at its EMISSION index
     // four rows per trip, all eight loads in flight before the first add (the adds keep the row order: bit-reproducible);
@@ -326,12 +336,12 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float g2y = opmu * H_half * (-cC * S2 - cB * S1);
     const float gx_ = -0.5f * opmu * S3, gy_ = -opmu * S4, gz_ = -0.5f * opmu * S5;
     const float dL_dmu = op * S0;
-    dL_dmean2D[3 * idx + 0] = g2x;
-    dL_dmean2D[3 * idx + 1] = g2y;
-    dL_dmean2D[3 * idx + 2] = 0.f;   // RAS/backward.cu never touches the third component
-    dL_dopacity[idx] = mu_f * S0;
-    dL_dmus[idx] = dL_dmu;
-    reinterpret_cast<float4 *>(dL_dconics)[idx] = make_float4(gx_, gy_, 0.f, gz_);
+    dL_dmean2D[3 * g + 0] = g2x;
+    dL_dmean2D[3 * g + 1] = g2y;
+    dL_dmean2D[3 * g + 2] = 0.f;   // RAS/backward.cu never touches the third component
+    acc_op += mu_f * S0;
+    dL_dmus[g] = dL_dmu;
+    reinterpret_cast<float4 *>(dL_dconics)[g] = make_float4(gx_, gy_, 0.f, gz_);
 
     // ---- 3. geometry chain
     Cov2D c;
@@ -366,7 +376,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     }
     // else: all six stay 0 (Q8)
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = o[k];
+    for (int k = 0; k < 6; ++k) acc_cov[k] += o[k];
 
     float3 gmean = make_float3(0.f, 0.f, 0.f);
     if (mode == 1) {
@@ -415,14 +425,21 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const float ddx = (proj[0] * m_w - proj[3] * mul1) * g0 + (proj[1] * m_w - proj[3] * mul2) * g1;
     const float ddy = (proj[4] * m_w - proj[7] * mul1) * g0 + (proj[5] * m_w - proj[7] * mul2) * g1;
     const float ddz = (proj[8] * m_w - proj[11] * mul1) * g0 + (proj[9] * m_w - proj[11] * mul2) * g1;
-    dL_dmeans[3 * idx + 0] = gmean.x + ddx;
-    dL_dmeans[3 * idx + 1] = gmean.y + ddy;
-    dL_dmeans[3 * idx + 2] = gmean.z + ddz;
+    acc_mean[0] += gmean.x + ddx;
+    acc_mean[1] += gmean.y + ddy;
+    acc_mean[2] += gmean.z + ddz;
+    }   // views
 
+    dL_dopacity[idx] = acc_op;
+    dL_dmeans[3 * idx + 0] = acc_mean[0];
+    dL_dmeans[3 * idx + 1] = acc_mean[1];
+    dL_dmeans[3 * idx + 2] = acc_mean[2];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dL_dcov[6 * idx + k] = acc_cov[k];
     if (scales != nullptr) {
         float ds[3];
         float4 dq;
-        cov3d_backward(sc_in[0], sc_in[1], sc_in[2], scale_modifier, rot_in, o, ds, &dq);
+        cov3d_backward(sc_in[0], sc_in[1], sc_in[2], scale_modifier, rot_in, acc_cov, ds, &dq);
         dL_dscale[3 * idx + 0] = ds[0];
         dL_dscale[3 * idx + 1] = ds[1];
         dL_dscale[3 * idx + 2] = ds[2];
@@ -434,27 +451,28 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 }
 
 // ------------------------------------------------------------------ host launchers
-int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
+int launch_raster_preprocess(const RasterGeom &g, int P, int V, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
-                             const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
+                             const float *views, const float *projs, int W, int H, float tan_fovx, float tan_fovy,
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s)
 {
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    raster_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
+    raster_preprocess_kernel<<<dim3((unsigned)(((size_t)P * V + 255) / 256)), dim3(256), 0, s>>>(
+        P, V, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, views, projs, W, H, tan_fovx, tan_fovy,
         focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr, g.tiles_touched, g.op_mu, thin_flag,
         reg);
     return 0;
 }
 
-int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
+int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, int V, const int *radii, int W, int H,
                             const uint32_t *nvis, hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    raster_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii, gx, gy,
-                                                                        g.first, b.tiles_unsorted, b.vals_unsorted, nvis);
+    const int PV = P * V;
+    raster_duplicate_kernel<<<dim3((PV + 255) / 256), dim3(256), 0, s>>>(PV, P, g.rec, g.order, g.offsets, radii, gx, gy,
+                                                                         g.first, b.tiles_unsorted, b.vals_unsorted, nvis);
     return 0;
 }
 
@@ -464,19 +482,26 @@ int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t 
     return 0;
 }
 
-int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,
+int launch_raster_geom_backward(int P, int V, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
-                                float tan_fovy, const float *view, const float *proj, float *dL_dconic,
+                                float tan_fovy, const float *views, const float *projs, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s)
 {
     const float h_y = H / (2.0f * tan_fovy);
     const float h_x = W / (2.0f * tan_fovx);
-    raster_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, means3D, radii, cov3D, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy, view, proj, g.rec,
-        g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W, 0.5f * (float)H, dL_dconic,
-        dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
+    // cov3D == the state's array: one covariance per view instance; a caller's cov3D_precomp: one per Gaussian
+    if (V > 1)
+        raster_geom_backward_kernel<true><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, V, means3D, radii, cov3D, cov3D == g.cov3D ? 1 : 0, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy,
+            views, projs, g.rec, g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W,
+            0.5f * (float)H, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
+    else
+        raster_geom_backward_kernel<false><<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, V, means3D, radii, cov3D, cov3D == g.cov3D ? 1 : 0, scales, rotations, scale_modifier, h_x, h_y, tan_fovx, tan_fovy,
+            views, projs, g.rec, g.op_mu, g.first, g.tiles_touched, reinterpret_cast<const float4 *>(part), 0.5f * (float)W,
+            0.5f * (float)H, dL_dconic, dL_dmu, dL_dmean2D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, mode);
     return 0;
 }
 

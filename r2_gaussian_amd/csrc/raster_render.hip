@@ -103,10 +103,10 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
 // FUSED: the work item that is the LAST of its tile to finish adds the tile's partial images in list order and writes the
 // image (and the backward's per-instance tile ids), instead of a separate combine launch; empty tiles are extra work items
 // {tile, 0, 0, 0} that just write zeros.
-template <bool ANY4, bool FUSED>
+template <bool ANY4, bool FUSED, bool MV>
 __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
-    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx, int gy,
     float *__restrict__ partial, uint32_t *__restrict__ tile_done, float *__restrict__ out_color, int W, int H,
     uint32_t *__restrict__ tiles)
 {
@@ -114,7 +114,9 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     if (w >= chunk_base[FUSED ? T + 1 : T]) return;
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
-    const int tx = tile % gx, ty = tile / gx;
+    int tx, ty, tv;   // tile column / row inside its view, view (batched views stack their tile grids)
+    tile_decode<MV>(tile, gx, gy, tx, ty, tv);
+    out_color += (size_t)tv * H * W;   // this view's image
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (FUSED && wd.w == 0u) {   // empty tile
         const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
@@ -252,9 +254,10 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 
 // Debug-mode kernel (pixel-parallel): also tracks n_contrib (RAS/forward.cu:381,391), which only `debug` callers read
 // back.  One lane per pixel, the wave's live entries are compacted per 256-entry batch and broadcast from LDS.
+template <bool MV>
 __global__ void __launch_bounds__(256) raster_render_forward_debug_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
-    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx, int gy,
     float *__restrict__ partial, uint32_t *__restrict__ partial_last)
 {
     const uint32_t w = blockIdx.x;
@@ -262,7 +265,8 @@ __global__ void __launch_bounds__(256) raster_render_forward_debug_kernel(
     const uint4 wd = work_tile[w];
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     const uint2 range = ranges[tile];
-    const int tx = tile % gx, ty = tile / gx;
+    int tx, ty, tv;
+    tile_decode<MV>(tile, gx, gy, tx, ty, tv);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = (wave & 1) * SUB2D, by = (wave >> 1) * SUB2D;
     const int lx = bx + (lane & 7), ly = by + (lane >> 3);
@@ -321,10 +325,10 @@ __global__ void __launch_bounds__(256) raster_render_forward_debug_kernel(
 }
 
 // adds the partial sums of a tile's work items in list order and writes the image (zeros for empty tiles)
-template <bool NCONTRIB>
+template <bool NCONTRIB, bool MV>
 __global__ void __launch_bounds__(256) raster_combine_kernel(
     const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial,
-    const uint32_t *__restrict__ partial_last, int W, int H, int gx, float *__restrict__ out_color,
+    const uint32_t *__restrict__ partial_last, int W, int H, int gx, int gy, float *__restrict__ out_color,
     uint32_t *__restrict__ n_contrib, const uint2 *__restrict__ ranges, uint32_t *__restrict__ tiles)
 {
     const uint32_t tile = blockIdx.x;
@@ -332,7 +336,10 @@ __global__ void __launch_bounds__(256) raster_combine_kernel(
         const uint2 rg = ranges[tile];
         for (uint32_t k = rg.x + threadIdx.x; k < rg.y; k += 256) tiles[k] = tile;
     }
-    const int tx = tile % gx, ty = tile / gx;
+    int tx, ty, tv;
+    tile_decode<MV>(tile, gx, gy, tx, ty, tv);
+    out_color += (size_t)tv * H * W;
+    if (NCONTRIB) n_contrib += (size_t)tv * H * W;
     const int tid = threadIdx.x;
     const int px = tx * TILE2D + (tid & 15), py = ty * TILE2D + (tid >> 4);
     const uint32_t w0 = chunk_base[tile], w1 = chunk_base[tile + 1];
@@ -448,6 +455,7 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
     }
 }
 
+template <bool MV>
 __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
@@ -492,13 +500,16 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     // dL/dpix of one tile: lane -> (row = lane/4, 4 columns), zero outside the image
     const bool aligned = (W & 15) == 0;   // kernel-uniform: every tile column lies inside the image
     auto load_tile = [&](uint32_t t) -> float4 {
-        const int tx0 = (int)(t % gx) * TILE2D, ty0 = (int)(t / gx) * TILE2D;
+        int ttx, tty, ttv;
+        tile_decode<MV>(t, gx, gy, ttx, tty, ttv);
+        const int tx0 = ttx * TILE2D, ty0 = tty * TILE2D;
         const int ry = ty0 + (lane >> 2), cx = tx0 + (lane & 3) * 4;
+        const float *__restrict__ img = dL_dpix + (size_t)ttv * H * W;   // this view's upstream gradient
         if (aligned)   // rows below the image are clamped here and zeroed by tile_row_ok() when the data is used
-            return *reinterpret_cast<const float4 *>(dL_dpix + (size_t)min(ry, H - 1) * W + cx);
+            return *reinterpret_cast<const float4 *>(img + (size_t)min(ry, H - 1) * W + cx);
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ry < H) {
-            const float *__restrict__ src = dL_dpix + (size_t)ry * W + cx;
+            const float *__restrict__ src = img + (size_t)ry * W + cx;
             if (cx + 0 < W) v.x = src[0];
             if (cx + 1 < W) v.y = src[1];
             if (cx + 2 < W) v.z = src[2];
@@ -506,7 +517,10 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         }
         return v;
     };
-    auto tile_row_ok = [&](uint32_t t) -> bool { return (int)(t / gx) * TILE2D + (lane >> 2) < H; };
+    auto tile_row_ok = [&](uint32_t t) -> bool {
+        const uint32_t tyt = t / (uint32_t)gx;
+        return (int)(MV ? tyt % (uint32_t)gy : tyt) * TILE2D + (lane >> 2) < H;
+    };
 
     uint32_t tile, id, tile1, id1;
     bool live, live1;
@@ -575,7 +589,11 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         }
         // ---- expand instances into block items
         const int slot = my_slot - slot0;
-        const float tx0 = (float)((int)(tile % gx) * TILE2D), ty0 = (float)((int)(tile / gx) * TILE2D);
+        // pixel origin of this lane's tile inside its view: one pair of integer divisions per chunk; the items below
+        // fetch their owner's origin with a shuffle
+        int ttx, tty, ttv;
+        tile_decode<MV>(tile, gx, gy, ttx, tty, ttv);
+        const float tx0 = (float)(ttx * TILE2D), ty0 = (float)(tty * TILE2D);
         uint32_t mask = 0;
         if (mine) {
 #pragma unroll
@@ -608,11 +626,11 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
             float M[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
             const uint32_t item = e < total ? (uint32_t)s_q[wave][e] : 0u;
             const int owner = (int)(item >> 4), sl = (int)((item >> 2) & 3u), q = (int)(item & 3u);
-            const uint32_t ot = __shfl(tile, owner);   // the owner's tile (all lanes take part in the shuffle)
+            const float otx0 = __shfl(tx0, owner), oty0 = __shfl(ty0, owner);   // the owner's tile origin (all lanes shuffle)
             float4 oa = make_float4(0.f, 0.f, 0.f, 0.f), ob = oa;
             if (e < total) { oa = s_pa[wave][owner]; ob = s_pb[wave][owner]; }
-            const float bx0 = (float)((int)(ot % gx) * TILE2D + (q % NB) * SUB2D);
-            const float by0 = (float)((int)(ot / gx) * TILE2D + (q / NB) * SUB2D);
+            const float bx0 = otx0 + (float)((q % NB) * SUB2D);
+            const float by0 = oty0 + (float)((q / NB) * SUB2D);
             const float *gq = gt + sl * GT_TILE + (q / NB) * SUB2D * GT_STRIDE + (q % NB) * SUB2D;
             // exact per-pixel path for thin / not safely positive definite Gaussians, the row recurrence for the rest
             const int tier = e < total ? row_tier(oa.z, ob.y, ob.z) : 0;
@@ -649,7 +667,8 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         // the geometry backward streams them -- no permutation has to be carried through the sort
         int rx0, ry0, rx1, ry1;
         tile_rect(a.x, a.y, rad, gx, gy, rx0, ry0, rx1, ry1);
-        const int ttx = (int)(tile % (uint32_t)gx), tty = (int)(tile / (uint32_t)gx);
+        int ttx, tty, ttv;
+        tile_decode<MV>(tile, gx, gy, ttx, tty, ttv);
         const size_t u = (size_t)first_row + (size_t)((tty - ry0) * (rx1 - rx0) + (ttx - rx0));
         part[2 * u] = make_float4(S[0], S[1], S[2], S[3]);
         part[2 * u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
@@ -662,45 +681,53 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
+template <bool MV>
+static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int gx, int gy, uint32_t T,
+                       float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s)
+{
+    if (fused_combine && !write_ncontrib && im.NW > 0) {
+        // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
+        if (any_thin)
+            raster_render_forward_kernel<true, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles);
+        else
+            raster_render_forward_kernel<false, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles);
+        return;
+    }
+    if (im.NW > 0) {
+        if (write_ncontrib)
+            raster_render_forward_debug_kernel<MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.partial_last);
+        else if (any_thin)
+            raster_render_forward_kernel<true, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr);
+        else
+            raster_render_forward_kernel<false, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr);
+    }
+    if (write_ncontrib)
+        raster_combine_kernel<true, MV><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx, gy,
+                                                                      out_color, im.n_contrib, im.ranges, fill_tiles);
+    else
+        raster_combine_kernel<false, MV><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx, gy,
+                                                                       out_color, im.n_contrib, im.ranges, fill_tiles);
+}
+
+int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
                                  hipStream_t s)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    const uint32_t T = (uint32_t)gx * gy;
-    if (fused_combine && !write_ncontrib && im.NW > 0) {
-        // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
-        if (any_thin)
-            raster_render_forward_kernel<true, true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles);
-        else
-            raster_render_forward_kernel<false, true><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles);
-        return 0;
-    }
-    if (im.NW > 0) {
-        if (write_ncontrib)
-            raster_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, im.partial_last);
-        else if (any_thin)
-            raster_render_forward_kernel<true, false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, nullptr, nullptr, W, H, nullptr);
-        else
-            raster_render_forward_kernel<false, false><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, im.partial, nullptr, nullptr, W, H, nullptr);
-    }
-    if (write_ncontrib)
-        raster_combine_kernel<true><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
-                                                                  out_color, im.n_contrib, im.ranges, fill_tiles);
-    else
-        raster_combine_kernel<false><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx,
-                                                                   out_color, im.n_contrib, im.ranges, fill_tiles);
+    const uint32_t T = (uint32_t)gx * gy * (uint32_t)V;   // the views' tile grids, stacked
+    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s);
+    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s);
     return 0;
 }
 
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s)
 {
     if (R == 0) return 0;
@@ -715,9 +742,14 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     const uint32_t nslots = ((nchunks + 7u) >> 3) << 3;
     const uint32_t grid = (nslots <= slots || (slots & 7u)) ? nslots : (nslots / slots) * slots;
     const int gy = (H + TILE2D - 1) / TILE2D;
-    raster_render_backward_kernel<<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy,
-                                                                   nchunks, dL_dpix,
-                                                                   reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
+    if (V > 1)   // the view of an instance follows from its tile id
+        raster_render_backward_kernel<true><<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(
+            b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy, nchunks, dL_dpix,
+            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
+    else
+        raster_render_backward_kernel<false><<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(
+            b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy, nchunks, dL_dpix,
+            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
     return 0;
 }
 

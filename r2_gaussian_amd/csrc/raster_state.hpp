@@ -23,6 +23,21 @@ __device__ __forceinline__ void tile_rect(float px, float py, int rad, int gx, i
     y1 = min(gy, max(0, (int)((py + rad + TILE2D - 1) / TILE2D)));
 }
 
+// Batched views.  V views of the same Gaussians are rendered as ONE scene of V * P "view instances" (id = v * P + i) on a
+// tile grid that stacks the views' grids: tile id = (v * gy + ty) * gx + tx.  Everything between the preprocess and the
+// render kernels (depth order, instance emission, tile sort, ranges, work lists) is oblivious to it; records keep their
+// per-view pixel coordinates, so a batched view is evaluated with exactly the arithmetic of a single one.  V = 1 is the
+// reference's call.
+// MV = false: single view, compiled without the extra division (the kernels are instantiated for both).
+template <bool MV>
+__device__ __forceinline__ void tile_decode(uint32_t tile, int gx, int gy, int &tx, int &ty, int &v)
+{
+    tx = (int)(tile % (uint32_t)gx);
+    const int tyt = (int)(tile / (uint32_t)gx);
+    v = MV ? tyt / gy : 0;
+    ty = tyt - v * gy;
+}
+
 __device__ __forceinline__ int row_tier(float A2, float L, float hx)
 {
     // 0: recurrence over the whole 8-pixel row; 1: recurrence re-anchored every 4 pixels (3 steps: safe down to a
@@ -36,7 +51,9 @@ __device__ __forceinline__ int row_tier(float A2, float L, float hx)
     // These thresholds are also where the recurrence's ACCURACY ends: carrying alpha * 2^64 through the recurrence moves the
     // underflow out of reach (measured, round 2) and would allow |A2| <= ~2 on the 8-step path, but 7 ratio steps at
     // |A2| > ~1.1 put the covariance gradients of such Gaussians 1.3-2.6x outside the 1e-4 bound.
-    const float room = sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
+    // v_sqrt_f32 (1 ulp) is plenty for a threshold with this much margin; the correctly rounded sqrtf() expands to ~20
+    // instructions each, and this runs once per entry per 64-entry step in both render kernels (measured: +1.4 us each)
+    const float room = __builtin_amdgcn_sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - __builtin_amdgcn_sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
     const float s8 = room * (1.0f / 7.0f), s4 = room * (1.0f / 3.0f);
     const float a = fabsf(A2);
     if (!(hx < 3.0e38f) || !(room > 0.f)) return 2;
@@ -159,24 +176,24 @@ struct RasterImage {
 };
 
 // launchers (raster_geom.hip, raster_render.hip)
-int launch_raster_preprocess(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
+int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, const float *means3D, const float *scales, float scale_modifier,
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
-int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, const int *radii, int W, int H,
+int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P /* per view */, int V, const int *radii, int W, int H,
                             const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
-int launch_raster_geom_backward(int P, const float *means3D, const int *radii, const float *cov3D, const float *scales,
+int launch_raster_geom_backward(int P /* per view */, int V, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
                                 float tan_fovy, const float *view, const float *proj, float *dL_dconic,
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s);
-int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H,
+int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
                                  hipStream_t s);
-int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, size_t R,
+int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 
 }  // namespace r2

@@ -22,7 +22,7 @@ constexpr int VOX_RECUR_STEPS = 4;
 __device__ __forceinline__ bool needs_exact_row3(float F2, float L, float hx)
 {
     // head-room sqrt(126 + L), not sqrt(126): the exponent that underflows includes L (see row_tier in raster_state.hpp)
-    const float smax = (sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - sqrtf(fmaxf(L - LOG2_ALPHA_MIN_3D, 0.f) + 1.0f)) *
+    const float smax = (__builtin_amdgcn_sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - __builtin_amdgcn_sqrtf(fmaxf(L - LOG2_ALPHA_MIN_3D, 0.f) + 1.0f)) *
                        (1.0f / (float)(VOX_RECUR_STEPS - 1));
     return !(smax > 0.f && fabsf(F2) <= smax * smax) || !(hx < 3.0e38f);
 }

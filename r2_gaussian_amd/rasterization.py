@@ -116,3 +116,59 @@ class GaussianRasterizer(nn.Module):
             cov3D_precomp = torch.Tensor([])
         return rasterize_gaussians(means3D, means2D, opacities, scales, rotations, cov3D_precomp,
                                    self.raster_settings)
+
+
+# ---------------------------------------------------------------------------------------------- batched views (new)
+class _RasterizeGaussiansBatch(torch.autograd.Function):
+    """V views of the same Gaussians in one pass (``_C.rasterize_gaussians_batch``): ``raster_settings.viewmatrix`` /
+    ``.projmatrix`` are [V,4,4]; returns color [V,H,W], radii [V,P].  ``means2D`` is [V,P,3] (one screen-space gradient
+    holder per view: the densification statistics are per view); the parameter gradients are the sum over the views."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        rs = raster_settings
+        num_rendered, color, radii, geomBuffer, binningBuffer, imgBuffer = _C.rasterize_gaussians_batch(
+            means3D, opacities, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix,
+            rs.tanfovx, rs.tanfovy, rs.image_height, rs.image_width, rs.mode, rs.debug)
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer, imgBuffer)
+        ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, grad_out_color, _):
+        rs = ctx.raster_settings
+        means3D, scales, rotations, cov3Ds_precomp, radii, geomBuffer, binningBuffer, imgBuffer = ctx.saved_tensors
+        if grad_out_color is None:
+            return None, None, None, None, None, None, None
+        (grad_means2D, grad_opacities, _grad_mu, grad_means3D, grad_cov3Ds_precomp, grad_scales,
+         grad_rotations) = _C.rasterize_gaussians_backward_batch(
+            means3D, radii, scales, rotations, rs.scale_modifier, cov3Ds_precomp, rs.viewmatrix, rs.projmatrix, rs.tanfovx,
+            rs.tanfovy, grad_out_color, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, rs.mode, rs.debug)
+        if scales.numel() == 0:
+            grad_scales = None
+        if rotations.numel() == 0:
+            grad_rotations = None
+        if cov3Ds_precomp.numel() == 0:
+            grad_cov3Ds_precomp = None
+        return grad_means3D, grad_means2D, grad_opacities, grad_scales, grad_rotations, grad_cov3Ds_precomp, None
+
+
+class GaussianRasterizerBatch(nn.Module):
+    """``GaussianRasterizer`` for V views at once: settings with viewmatrix / projmatrix of shape [V,4,4]."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, scales=None, rotations=None, cov3D_precomp=None):
+        if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+                (scales is not None or rotations is not None) and cov3D_precomp is not None):
+            raise Exception(
+                "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!")
+        e = torch.Tensor([])
+        return _RasterizeGaussiansBatch.apply(means3D, means2D, opacities, e if scales is None else scales,
+                                              e if rotations is None else rotations,
+                                              e if cov3D_precomp is None else cov3D_precomp, self.raster_settings)

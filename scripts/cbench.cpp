@@ -5,6 +5,7 @@
 // Prints views/s of forward+backward, the per-stage HIP-event breakdown, and the voxelizer's 256^3 query time.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -135,6 +136,66 @@ int main(int argc, char **argv)
         }
     printf("  %-20s %8.2f us\n", "raster stage sum", sum);
     prof_enable(0);
+
+    // batched views (r2_raster_forward_batch / _backward_batch; absent from older builds of the library): BV views per call
+    if (void *pf = dlsym(h, "r2_raster_forward_batch")) {
+        auto bfwd = reinterpret_cast<decltype(&r2_raster_forward_batch)>(pf);
+        auto bbwd = sym<decltype(&r2_raster_backward_batch)>(h, "r2_raster_backward_batch");
+        for (int BV : {2, 4, 8}) {
+            if (BV > V) break;
+            float *bvm, *bpm, *bout, *bdL, *bg;
+            int *bradii;
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bvm), (size_t)V * 16 * 4));
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bpm), (size_t)V * 16 * 4));
+            for (int i = 0; i < V; ++i) {
+                CHECK(hipMemcpy(bvm + (size_t)i * 16, views[i].vm, 64, hipMemcpyHostToDevice));
+                CHECK(hipMemcpy(bpm + (size_t)i * 16, views[i].pm, 64, hipMemcpyHostToDevice));
+            }
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bout), (size_t)BV * H * W * 4));
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bdL), (size_t)BV * H * W * 4));
+            for (int i = 0; i < BV; ++i) CHECK(hipMemcpy(bdL + (size_t)i * H * W, dLh.data(), dLh.size() * 4, hipMemcpyHostToDevice));
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bradii), (size_t)BV * P * 4));
+            CHECK(hipMalloc(reinterpret_cast<void **>(&bg), ((size_t)8 * BV + 17) * P * 4));
+            float *q2d = bg, *qcon = bg + (size_t)3 * BV * P, *qmu = bg + (size_t)7 * BV * P, *qop = bg + (size_t)8 * BV * P,
+                  *q3d = qop + P, *qcov = q3d + (size_t)3 * P, *qsc = qcov + (size_t)6 * P, *qrot = qsc + (size_t)3 * P;
+            const int nb = V / BV;   // batches of consecutive views
+            long long Rb = 0;
+            auto bstep = [&](int k) {
+                const int v0 = (k % nb) * BV;
+                const ViewH &v = views[v0];
+                const int R = bfwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, BV, W, H, means, dens, scal, 1.f, rot, nullptr,
+                                   bvm + (size_t)v0 * 16, bpm + (size_t)v0 * 16, v.tanx, v.tany, v.mode, bout, bradii, 0, s);
+                if (R < 0) { fprintf(stderr, "batch forward: %d %s\n", R, last_error()); exit(1); }
+                Rb += R;
+                const int rc = bbwd(P, BV, R, W, H, means, scal, 1.f, rot, nullptr, bvm + (size_t)v0 * 16, bpm + (size_t)v0 * 16, v.tanx,
+                                    v.tany, bradii, slots[0].p, slots[1].p, slots[2].p, bdL, q2d, qcon, qop, qmu, q3d, qcov, qsc, qrot,
+                                    v.mode, 0, s);
+                if (rc < 0) { fprintf(stderr, "batch backward: %d %s\n", rc, last_error()); exit(1); }
+            };
+            for (int k = 0; k < 2 * nb + 4; ++k) bstep(k);
+            CHECK(hipStreamSynchronize(s));
+            double bbest = 1e30;
+            const int bsteps = std::max(20, steps / BV);
+            for (int rep = 0; rep < 3; ++rep) {
+                Rb = 0;
+                const auto tb = std::chrono::steady_clock::now();
+                for (int k = 0; k < bsteps; ++k) bstep(k);
+                CHECK(hipStreamSynchronize(s));
+                bbest = std::min(bbest, std::chrono::duration<double>(std::chrono::steady_clock::now() - tb).count());
+            }
+            printf("BATCH V=%d: %.1f views/s  %.2f us/view  (%.1f us per call, R avg per view %lld)\n", BV, bsteps * BV / bbest,
+                   1e6 * bbest / (bsteps * BV), 1e6 * bbest / bsteps, Rb / ((long long)bsteps * BV));
+            prof_enable(~0ull);
+            for (int k = 0; k < 20; ++k) bstep(k);
+            CHECK(hipStreamSynchronize(s));
+            prof_read(ms.data(), cnt.data(), 1);
+            for (int i = 0; i < ns; ++i)
+                if (cnt[i] && !strncmp(prof_name(i), "raster.", 7))
+                    printf("  V=%d %-18s %8.2f us/view\n", BV, prof_name(i), 1e3 * ms[i] / cnt[i] / BV);
+            prof_enable(0);
+            (void)hipFree(bvm); (void)hipFree(bpm); (void)hipFree(bout); (void)hipFree(bdL); (void)hipFree(bradii); (void)hipFree(bg);
+        }
+    }
 
     // voxelizer: the full 256^3 query
     auto vox = [&]() {
