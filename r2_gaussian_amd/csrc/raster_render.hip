@@ -89,7 +89,10 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
                     g = need4 ? g4 : g;
                     rt = need4 ? rt4 : rt;
                 }
-                acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;   // power <= 0 holds: positive definite conic
+                // power <= 0 holds: positive definite conic.  (The EXEC-mask form of this -- v_cmpx + add + s_mov exec, 2 VALU
+                // instead of 3 -- gains 2.7 us in the backward, which is issue-bound; here it was measured twice, rounds 1
+                // and 2: 1 us SLOWER.  This kernel waits on latency, not on the VALU.)
+                acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;
                 g *= rt;
                 rt *= rr;
             }
@@ -432,6 +435,36 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             // with it the cancellation in r3
             constexpr float mid = 0.5f * (float)(N - 1);
             float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#ifndef R2_EXP_NO_CMPX
+            // power <= 0 holds for a positive definite conic; the cut-off is applied as an EXEC mask: v_cmpx narrows EXEC
+            // to the lanes whose pixel passes, the product and the three moment updates run under it (a masked lane keeps
+            // its sums: the same as adding 0), s_mov restores EXEC on the scalar unit -- 5 VALU instead of the 6 of compare +
+            // select + multiply + 3 updates (this kernel is VALU-issue-bound).  (c - mid)^k enter as literal operands.
+            static_assert(N == 8, "the pixel macro below is written for 8-pixel rows");
+            const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
+#define R2_BWD_PX(c)                                                                                                      \
+            {                                                                                                             \
+                if (c == N / 2) {                                                                                         \
+                    G = need4 ? G4 : G;                                                                                   \
+                    rt = need4 ? rt4 : rt;                                                                                \
+                }                                                                                                         \
+                float w;                                                                                                  \
+                asm volatile("v_cmpx_le_f32_e32 %[thr], %[G]\n\t"                                                         \
+                             "v_mul_f32_e32 %[w], %[G], %[g]\n\t"                                                         \
+                             "v_add_f32_e32 %[t0], %[t0], %[w]\n\t"                                                       \
+                             "v_fmac_f32_e32 %[t1], %[k1], %[w]\n\t"                                                      \
+                             "v_fmac_f32_e32 %[t2], %[k2], %[w]\n\t"                                                      \
+                             "s_mov_b64 exec, %[ex]"                                                                      \
+                             : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [w] "=&v"(w)                                  \
+                             : [thr] "v"(gthr), [G] "v"(G), [g] "v"(g[c]), [k1] "n"(__builtin_bit_cast(int, (float)(c) - mid)), \
+                               [k2] "n"(__builtin_bit_cast(int, ((float)(c) - mid) * ((float)(c) - mid))), [ex] "s"(full_exec) \
+                             : "vcc");                                                                                    \
+                G *= rt;                                                                                                  \
+                rt *= rr;                                                                                                 \
+            }
+            R2_BWD_PX(0) R2_BWD_PX(1) R2_BWD_PX(2) R2_BWD_PX(3) R2_BWD_PX(4) R2_BWD_PX(5) R2_BWD_PX(6) R2_BWD_PX(7)
+#undef R2_BWD_PX
+#else
 #pragma unroll
             for (int c = 0; c < N; ++c) {
                 if (c == N / 2) {
@@ -445,6 +478,7 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
                 G *= rt;
                 rt *= rr;
             }
+#endif
             const float dm = dx0 - mid;
             r0 = t0;
             r1 = dm * t0 - t1;

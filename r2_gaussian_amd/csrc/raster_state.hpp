@@ -7,7 +7,10 @@
 
 namespace r2 {
 
-constexpr uint32_t FWD_CHUNK = 512;   // instances of one tile list rendered by one workgroup (load balance)
+#ifndef R2_EXP_FWD_CHUNK
+#define R2_EXP_FWD_CHUNK 512
+#endif
+constexpr uint32_t FWD_CHUNK = R2_EXP_FWD_CHUNK;   // instances of one tile list rendered by one workgroup (load balance)
 constexpr int PART_STRIDE = 8;        // floats per instance in the backward moment scratch (6 used)
 constexpr float ALPHA_MIN_2D = 0.00001f;               // RAS/forward.cu:374
 constexpr float LOG2_ALPHA_MIN_2D = -16.609640474436812f;   // log2(1e-5)
