@@ -442,6 +442,7 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             // select + multiply + 3 updates (this kernel is VALU-issue-bound).  (c - mid)^k enter as literal operands.
             static_assert(N == 8, "the pixel macro below is written for 8-pixel rows");
             const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
+#define R2_BWD_K(x) "n"(__builtin_bit_cast(int, (float)(x)))   /* literals: SGPR operands measured 1 us slower */
 #define R2_BWD_PX(c)                                                                                                      \
             {                                                                                                             \
                 if (c == N / 2) {                                                                                         \
@@ -456,14 +457,15 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
                              "v_fmac_f32_e32 %[t2], %[k2], %[w]\n\t"                                                      \
                              "s_mov_b64 exec, %[ex]"                                                                      \
                              : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [w] "=&v"(w)                                  \
-                             : [thr] "v"(gthr), [G] "v"(G), [g] "v"(g[c]), [k1] "n"(__builtin_bit_cast(int, (float)(c) - mid)), \
-                               [k2] "n"(__builtin_bit_cast(int, ((float)(c) - mid) * ((float)(c) - mid))), [ex] "s"(full_exec) \
+                             : [thr] "v"(gthr), [G] "v"(G), [g] "v"(g[c]), [k1] R2_BWD_K((float)(c) - mid),               \
+                               [k2] R2_BWD_K(((float)(c) - mid) * ((float)(c) - mid)), [ex] "s"(full_exec)                  \
                              : "vcc");                                                                                    \
                 G *= rt;                                                                                                  \
                 rt *= rr;                                                                                                 \
             }
             R2_BWD_PX(0) R2_BWD_PX(1) R2_BWD_PX(2) R2_BWD_PX(3) R2_BWD_PX(4) R2_BWD_PX(5) R2_BWD_PX(6) R2_BWD_PX(7)
 #undef R2_BWD_PX
+#undef R2_BWD_K
 #else
 #pragma unroll
             for (int c = 0; c < N; ++c) {

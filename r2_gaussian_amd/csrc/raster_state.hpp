@@ -71,6 +71,10 @@ __device__ __forceinline__ bool block_live(float px, float py, float hx, float h
     return (px - hx <= x0 + (n - 1.0f)) && (px + hx >= x0) && (py - hy <= y0 + (n - 1.0f)) && (py + hy >= y0);
 }
 
+// (An exact second stage -- does the ELLIPSE {alpha >= 1e-5}, not its bounding box, reach the block? 40.5 % instead of 46 %
+// of the (entry, block) pairs -- was built and measured in round 2: parity green, forward 47.5 -> 50.9 us (the test costs more
+// than the dropped entries save), backward unchanged (its rounds are quantised: 118 or 104 items per chunk are both 2 rounds).)
+
 struct RasterGeom {
     float4 *rec;              // [2P]  {px, py, A2, B2} {C2, L, hx, hy}: A2,B2,C2 = conic * (-log2e/2, -log2e, -log2e/2),
                               //       L = log2(opacity*mu), (hx, hy) = half-extents of the alpha >= 1e-5 bounding box
