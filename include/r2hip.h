@@ -157,6 +157,18 @@ R2_API int r2_raster_backward_batch(
     float *dL_drot,            /* [P,4]   summed */
     int mode, int debug, void *stream);
 
+/* ---- loss stack of the training iteration (r2_gaussian/utils/loss_utils.py:19-104, train.py:118-147) ----
+ * r2_loss_l1_ssim: loss = w_l1 * mean|img - gt| + w_ssim * (1 - SSIM(img, gt)) (11x11 Gaussian window, sigma 1.5, zero
+ * padding) of one [height,width] projection AND its gradient dL/dimg, in two launches; scalars = {l1 mean, ssim mean, loss}.
+ * r2_loss_tv3d: tv = tv_3d_loss(vol, "mean") of a [nx,ny,nz] volume and dL/dvol = weight * d tv / d vol; scalars = {tv,
+ * weight * tv}.  scratch: device floats, at least r2_loss_*_scratch_floats(...).  Sums are formed in a fixed order. */
+R2_API size_t r2_loss_l1_ssim_scratch_floats(int width, int height);
+R2_API int r2_loss_l1_ssim(int width, int height, const float *img, const float *gt, float w_l1, float w_ssim,
+                           float *dL_dimg, float *scratch, float *scalars /* [3] */, void *stream);
+R2_API size_t r2_loss_tv3d_scratch_floats(int nx, int ny, int nz);
+R2_API int r2_loss_tv3d(int nx, int ny, int nz, const float *vol, float weight, float *dL_dvol, float *scratch,
+                        float *scalars /* [2] */, void *stream);
+
 /* ---- voxelizer ------------------------------------------------------------------------------- */
 R2_API int r2_voxel_forward(
     r2_alloc_fn geometryBuffer, void *geometry_user,

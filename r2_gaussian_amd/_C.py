@@ -17,6 +17,7 @@ _F32 = torch.float32
 # interpreter time per training view than the ctypes path below.  Both drive the same libr2hip.so; R2_SHIM=0 forces ctypes.
 _SHIM = None
 _SHIM_TRIED = False
+_POISON = os.environ.get("R2_POISON", "0") == "1"   # ctypes boundary only (R2_SHIM=0)
 
 
 def _shim():
@@ -104,7 +105,10 @@ class _DeviceHooks:
                 if n > (1 << 20):
                     g = 1 << max(20, n.bit_length() - 4)   # 1/16 .. 1/8 of the size
                     n = (n + g - 1) // g * g
-                t = torch.empty(n, dtype=torch.uint8, device=self.device)
+                if _POISON:   # debugging aid: 0xFF-filled state, so that a read of never-written state shows up
+                    t = torch.full((n,), 255, dtype=torch.uint8, device=self.device)
+                else:
+                    t = torch.empty(n, dtype=torch.uint8, device=self.device)
                 self.current.bufs[i] = t
                 return t.data_ptr()
             except Exception:   # out of memory etc.: report NULL, the C side turns it into R2_ERR_ALLOC

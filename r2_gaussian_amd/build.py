@@ -35,6 +35,7 @@ SOURCES = {
     "voxel_render.hip": FAST,
     "voxel_api.hip": FAST,
     "knn.hip": EXACT,
+    "loss_ops.hip": FAST,
 }
 
 

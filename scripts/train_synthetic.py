@@ -19,6 +19,7 @@ if __name__ == "__main__":
     ap.add_argument("--detector", type=int, default=512)
     ap.add_argument("--nvol", type=int, default=256)
     ap.add_argument("--init", type=int, default=50000)
+    ap.add_argument("--fused-losses", action="store_true", help="loss stack on the HIP kernels (r2_gaussian_amd.losses)")
     args = ap.parse_args()
     from tests import mini_trainer as T
     t0 = time.time()
@@ -26,10 +27,11 @@ if __name__ == "__main__":
     t_case = time.time() - t0
     n = args.iterations
     opt = T.Opt(iterations=n, densify_from_iter=n // 6, densify_until_iter=n // 2, densification_interval=100)
-    out = T.train(case, opt, "hip", eval_every=max(100, n // 10), seed=0, log=print)
+    out = T.train(case, opt, "hip", eval_every=max(100, n // 10), seed=0, log=print, fused_losses=args.fused_losses)
+    out["fused_losses"] = bool(args.fused_losses)
     out.update(detector=args.detector, n_vol=args.nvol, init=args.init, gt_build_s=round(t_case, 1),
                note="whole training iteration incl. losses / Adam / densify in torch; GT projections + volume by the CPU oracle")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "train_synthetic.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "train_synthetic%s.json" % ("_fused" if args.fused_losses else "")), "w") as f:
         json.dump(out, f, indent=1)
     print("final psnr3d %.3f dB, P %d, %.1f it/s" % (out["psnr"][-1], out["P"][-1], out["it_per_s"]))

@@ -328,7 +328,12 @@ def ssim(img1, img2, window_size=11):
     """loss_utils.py:57-104: 11x11 Gaussian window (sigma 1.5), zero padding, mean of the SSIM map; img [1,H,W]."""
     g = torch.tensor([math.exp(-((x - window_size // 2) ** 2) / (2 * 1.5 ** 2)) for x in range(window_size)])
     g = (g / g.sum()).unsqueeze(1)
-    w = (g @ g.t()).float()[None, None].to(img1.device)
+    # The window lives at the START of a 4 KB buffer: the vendor convolution on this stack reads past the end of its
+    # 484-byte weight tensor (a pure-torch loop faults when the window is the last block of an allocator segment,
+    # scripts/miopen_overread_probe.py); the reference's own ssim() allocates it bare.
+    buf = torch.zeros(1024, device=img1.device)
+    buf[:window_size * window_size] = (g @ g.t()).float().reshape(-1).to(img1.device)
+    w = buf[:window_size * window_size].view(1, 1, window_size, window_size)
     a, b = img1[None], img2[None]
     pad = window_size // 2
     mu1, mu2 = F.conv2d(a, w, padding=pad), F.conv2d(b, w, padding=pad)
@@ -352,8 +357,9 @@ def psnr3d(case, model):
         return S.psnr3d(case.vol_gt, vol.detach().cpu())
 
 
-def train(case, opt, backend_name, eval_every=100, seed=0, log=None):
-    """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177."""
+def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False):
+    """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177.
+    fused_losses (hip backend): the loss stack through r2_gaussian_amd.losses (one autograd node each) instead of torch ops."""
     be = Backend(backend_name)
     gen = torch.Generator().manual_seed(seed)          # TV centres, split samples
     pyrng = random.Random(seed)                        # view order (train.py:104-106)
@@ -374,13 +380,17 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None):
         x, d, s, r = model.activated()
         pkg = be.render(case.views[vi], x, d, s, r)
         img = pkg["render"]
-        loss = (img - gts[vi]).abs().mean()
-        if opt.lambda_dssim > 0:
-            loss = loss + opt.lambda_dssim * (1.0 - ssim(img, gts[vi]))
+        if fused_losses:
+            from r2_gaussian_amd import losses as FL
+            loss, _parts = FL.image_loss(img, gts[vi], opt.lambda_dssim)
+        else:
+            loss = (img - gts[vi]).abs().mean()
+            if opt.lambda_dssim > 0:
+                loss = loss + opt.lambda_dssim * (1.0 - ssim(img, gts[vi]))
         if opt.lambda_tv > 0:
             c = (case.bbox[0] + tvS / 2) + (case.bbox[1] - tvS - case.bbox[0]) * torch.rand(3, generator=gen)
             vol = be.query(x, d, s, r, c, tvN, tvS)
-            loss = loss + opt.lambda_tv * tv3d_mean(vol)
+            loss = loss + opt.lambda_tv * (FL.tv_3d_loss(vol) if fused_losses else tv3d_mean(vol))
         loss.backward()
         with torch.no_grad():
             vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
@@ -403,7 +413,7 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None):
             out["psnr"].append(psnr3d(case, model))
             out["P"].append(model.P)
             if log:
-                log("it %5d  P %6d  psnr3d %.3f dB  loss %.4e  (%.1f it/s)" % (it, model.P, out["psnr"][-1], float(loss),
+                log("it %5d  P %6d  psnr3d %.3f dB  loss %.4e  (%.1f it/s)" % (it, model.P, out["psnr"][-1], float(loss.detach()),
                                                                               it / t_train))
     out["it_per_s"] = opt.iterations / t_train
     return out
