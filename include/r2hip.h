@@ -169,6 +169,31 @@ R2_API size_t r2_loss_tv3d_scratch_floats(int nx, int ny, int nz);
 R2_API int r2_loss_tv3d(int nx, int ny, int nz, const float *vol, float weight, float *dL_dvol, float *scratch,
                         float *scalars /* [2] */, void *stream);
 
+/* ---- adaptive density control on the device (r2_gaussian/gaussian/gaussian_model.py:320-556, train.py:151-168) ----
+ * r2_densify_stats: max_radii2D / xyz_gradient_accum / denom update of one rendered view (in place, one launch).
+ * r2_densify_classify + r2_densify_emit: densify_and_prune -- clone (small Gaussians with a large view-space gradient; both
+ * copies get half the density), split (large ones: two children sampled from N(0, scale) in the local frame, scale / 1.6,
+ * half the density, parent removed), prune (density below density_min, outside the box) -- with the Adam moments carried
+ * along (zeros for new rows) and the statistics reset, written in the reference's row order.  classify decides, counts and
+ * synchronises the stream ONCE to return the four survivor counts (originals, clones, first children, second children);
+ * the caller allocates sum(counts) rows and calls emit with the same arguments and the same scratch.  normals: [2,P,3]
+ * N(0,1) samples indexed by the PARENT's row (only rows of split parents are read).  scale_lo < scale_hi: bounded-sigmoid
+ * scaling activation, else exp.  max_screen_size / max_scale pruning (None by default in the reference) is not implemented.
+ * params / exp_avg / exp_avg_sq (+ _out): 4 device pointers each in the order xyz[.,3], density[.,1], scaling[.,3], rotation[.,4]. */
+R2_API int r2_densify_stats(int P, const int *radii, const float *dL_dmeans2D /* [P,3] */, float *max_radii2D, float *grad_accum,
+                            float *denom, void *stream);
+R2_API size_t r2_densify_scratch_bytes(int P);
+R2_API int r2_densify_classify(int P, const float *xyz, const float *density, const float *scaling, const float *rotation,
+                               const float *grad_accum, const float *denom, const float *normals, float grad_thr, float scale_thr,
+                               float density_min, const float *bbox_host /* 6 host floats: lo xyz, hi xyz */, float scale_lo,
+                               float scale_hi, int do_densify, void *scratch, unsigned int *counts_host /* [4] */, void *stream);
+R2_API int r2_densify_emit(int P, const float *const *params, const float *const *exp_avg, const float *const *exp_avg_sq,
+                           const float *max_radii2D, const float *grad_accum, const float *denom, const float *normals,
+                           float grad_thr, float scale_thr, float density_min, const float *bbox_host, float scale_lo,
+                           float scale_hi, int do_densify, const void *scratch, float *const *params_out, float *const *exp_avg_out,
+                           float *const *exp_avg_sq_out, float *max_radii2D_out, float *grad_accum_out, float *denom_out,
+                           void *stream);
+
 /* ---- voxelizer ------------------------------------------------------------------------------- */
 R2_API int r2_voxel_forward(
     r2_alloc_fn geometryBuffer, void *geometry_user,

@@ -36,6 +36,7 @@ SOURCES = {
     "voxel_api.hip": FAST,
     "knn.hip": EXACT,
     "loss_ops.hip": FAST,
+    "densify_ops.hip": EXACT,
 }
 
 

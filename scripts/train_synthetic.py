@@ -27,7 +27,8 @@ if __name__ == "__main__":
     t_case = time.time() - t0
     n = args.iterations
     opt = T.Opt(iterations=n, densify_from_iter=n // 6, densify_until_iter=n // 2, densification_interval=100)
-    out = T.train(case, opt, "hip", eval_every=max(100, n // 10), seed=0, log=print, fused_losses=args.fused_losses)
+    out = T.train(case, opt, "hip", eval_every=max(100, n // 10), seed=0, log=print, fused_losses=args.fused_losses,
+                  fused_densify=args.fused_losses)
     out["fused_losses"] = bool(args.fused_losses)
     out.update(detector=args.detector, n_vol=args.nvol, init=args.init, gt_build_s=round(t_case, 1),
                note="whole training iteration incl. losses / Adam / densify in torch; GT projections + volume by the CPU oracle")

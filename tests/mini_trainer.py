@@ -283,8 +283,22 @@ class Model:
                             2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
 
     @torch.no_grad()
-    def densify_and_prune(self, bbox):
-        """gaussian_model.py:503-550 with max_screen_size = max_scale = None (the defaults)."""
+    def densify_and_prune_fused(self, bbox, normals_full=None):
+        """The same through r2_gaussian_amd.densify (csrc/densify_ops.hip): one classify + one emit pass on the device."""
+        from r2_gaussian_amd import densify as D
+        opt = self.opt
+        if normals_full is None:
+            normals_full = torch.randn((2, self.P, 3), generator=self.gen)
+        new_p, self.max_radii2D, self.grad_accum, self.denom = D.densify_and_prune_optimizer(
+            self.optimizer, self.max_radii2D, self.grad_accum, self.denom, normals_full, opt.densify_grad_threshold,
+            opt.densify_scale_threshold * 2.0, opt.density_min_threshold, bbox, (self.lo, self.hi),
+            do_densify=self.P < opt.max_num_gaussians)
+        self.p = dict(new_p)
+
+    @torch.no_grad()
+    def densify_and_prune(self, bbox, normals_full=None):
+        """gaussian_model.py:503-550 with max_screen_size = max_scale = None (the defaults).  normals_full ([2,P,3], test
+        hook): the split samples of parent i are normals_full[:, i] instead of fresh draws."""
         opt = self.opt
         thr_scale = opt.densify_scale_threshold * 2.0
         grads = self.grad_accum / self.denom
@@ -307,7 +321,12 @@ class Model:
             _x, dens, scal, _r = self.activated()
             sel = (pad >= opt.densify_grad_threshold) & (scal.max(dim=1).values > thr_scale)
             stds = scal[sel].repeat(2, 1)
-            samples = (torch.randn(stds.shape, generator=self.gen) * stds.cpu()).to(stds.device)   # seeded CPU stream
+            if normals_full is not None:
+                nf = normals_full.to(stds.device)
+                so = sel[:nf.shape[1]]
+                samples = torch.cat([nf[0][so], nf[1][so]], 0) * stds
+            else:
+                samples = (torch.randn(stds.shape, generator=self.gen) * stds.cpu()).to(stds.device)   # seeded CPU stream
             R = self._rotmat(self.p["rotation"].detach()[sel]).repeat(2, 1, 1)
             ext = {"xyz": torch.bmm(R, samples.unsqueeze(-1)).squeeze(-1) + self.p["xyz"].detach()[sel].repeat(2, 1),
                    "density": self.inv_softplus(dens[sel].repeat(2, 1) * 0.5),
@@ -357,9 +376,10 @@ def psnr3d(case, model):
         return S.psnr3d(case.vol_gt, vol.detach().cpu())
 
 
-def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False):
+def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False, fused_densify=False):
     """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177.
-    fused_losses (hip backend): the loss stack through r2_gaussian_amd.losses (one autograd node each) instead of torch ops."""
+    fused_losses (hip backend): the loss stack through r2_gaussian_amd.losses (one autograd node each) instead of torch ops.
+    fused_densify (hip backend): densification statistics + densify / prune through r2_gaussian_amd.densify."""
     be = Backend(backend_name)
     gen = torch.Generator().manual_seed(seed)          # TV centres, split samples
     pyrng = random.Random(seed)                        # view order (train.py:104-106)
@@ -393,13 +413,21 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
             loss = loss + opt.lambda_tv * (FL.tv_3d_loss(vol) if fused_losses else tv3d_mean(vol))
         loss.backward()
         with torch.no_grad():
-            vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
-            model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
-            g2 = pkg["viewspace_points"].grad
-            model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
-            model.denom[vis] += 1
+            if fused_densify:
+                from r2_gaussian_amd import densify as FD
+                FD.densification_stats(pkg["radii"], pkg["viewspace_points"].grad, model.max_radii2D, model.grad_accum,
+                                       model.denom)
+            else:
+                vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
+                model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
+                g2 = pkg["viewspace_points"].grad
+                model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
+                model.denom[vis] += 1
             if it < opt.densify_until_iter and it > opt.densify_from_iter and it % opt.densification_interval == 0:
-                model.densify_and_prune(case.bbox)
+                if fused_densify:
+                    model.densify_and_prune_fused(case.bbox)
+                else:
+                    model.densify_and_prune(case.bbox)
             if model.P == 0:
                 raise ValueError("No Gaussian left")
             if it < opt.iterations:
