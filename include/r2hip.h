@@ -249,6 +249,23 @@ R2_API int r2_sync_wait_stats(double *total_us, long long *calls, int reset);
  * launching the rest), accumulated over `calls` forward passes */
 R2_API int r2_profile_host(double *pre_sync_us, double *post_sync_us, long long *calls, int reset);
 
+/* ---- FDK reconstruction for the initialisation --------------------------------------------------------
+ * Replaces tigre.algorithms.fdk as called by recon_volume() (r2_gaussian/utils/ct_utils.py:17-27) from init_pcd()
+ * (initialize_pcd.py:36-90); TIGRE is a third-party CUDA toolbox outside the reference tree.
+ * r2_fdk_filter: cosine pre-weight (cone != 0: DSD / sqrt(DSD^2 + u^2 + v^2) at the pixel centres, pixel size du x dv) and
+ *   ramp filter along detector rows: out[v][i] = scale * sum_j w(j,v) projs[v][j] * taps[i - j + W - 1], taps = the 2W-1
+ *   spatial taps of the (windowed) ramp (host side: r2_gaussian_amd/fdk.py:ramp_taps), scale = (DSD/DSO)(2 pi/V)/(4 du).
+ *   The result is stored transposed: filtered_t[V][W][H].
+ * r2_fdk_backproject: vol[nx][ny][nz] = sum over the views (in order) of the bilinear sample (zero outside the detector) of
+ *   filtered_t at the projection of the voxel centre, times (DSO / U)^2 for cone beams (U = p_hom.w, the depth along the
+ *   central ray).  projmatrices [V,16] are the full_proj_transform matrices the rasterizer takes (same memory layout), voxel
+ *   centres follow the voxelizer: center - sVoxel/2 + (i + 0.5) dVoxel. */
+R2_API int r2_fdk_filter(int V, int H, int W, const float *projs /* [V,H,W] */, const float *taps /* [2W-1] */, float scale,
+                         int cone, float DSD, float du, float dv, float *filtered_t /* [V,W,H] */, void *stream);
+R2_API int r2_fdk_backproject(int V, int H, int W, const float *filtered_t, const float *projmatrices, int cone, float DSO,
+                              int nx, int ny, int nz, float sVoxel_x, float sVoxel_y, float sVoxel_z, float center_x,
+                              float center_y, float center_z, float *vol /* [nx,ny,nz] */, void *stream);
+
 /* The forward passes order the Gaussians by depth with a bucket sort whose bucket boundaries follow the depth range seen
  * by the previous call with the same P (a per-thread hint: it saves five kernel launches and hides the num_rendered
  * read-back).  Results never depend on it -- both paths produce the exact (depth, id) order.  mode 0: never use hints,

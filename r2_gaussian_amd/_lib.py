@@ -44,6 +44,8 @@ _SIGNATURES = {
     "r2_loss_l1_ssim": (C.c_int, [_i, _i, _fp, _fp, _f, _f, _fp, _fp, _fp, _p]),
     "r2_loss_tv3d_scratch_floats": (C.c_size_t, [_i, _i, _i]),
     "r2_loss_tv3d": (C.c_int, [_i, _i, _i, _fp, _f, _fp, _fp, _fp, _p]),
+    "r2_fdk_filter": (C.c_int, [_i, _i, _i, _fp, _fp, _f, _i, _f, _f, _f, _fp, _p]),
+    "r2_fdk_backproject": (C.c_int, [_i, _i, _i, _fp, _fp, _i, _f, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _p]),
     "r2_profile_enable": (None, [C.c_ulonglong]),
     "r2_profile_stage_count": (C.c_int, []),
     "r2_profile_stage_name": (C.c_char_p, [_i]),

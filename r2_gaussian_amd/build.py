@@ -37,6 +37,7 @@ SOURCES = {
     "knn.hip": EXACT,
     "loss_ops.hip": FAST,
     "densify_ops.hip": EXACT,
+    "fdk.hip": FAST,
 }
 
 
