@@ -36,7 +36,9 @@ __device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h
            (pz + h.z >= z0 + 0.5f);
 }
 
-template <bool EXACT>
+// Measured and left out: a second step body that walks whole rows of 8 voxels with one recurrence for the entries that allow
+// it (85 % here; three compaction queues, one tier per step): 0.666 -> 0.718 ms at 256^3 -- two ~2000-instruction bodies and
+// more partly filled steps cost more than the two v_exp_f32 per row it saves.
 __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const float4 r, float xc, float y0, float z0,
                                           float (&acc)[64])
 {
@@ -46,41 +48,42 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
     const float bdx = q.y * dx, cdx = q.z * dx;
     const float dz0 = p.z - (z0 + 0.5f);
     const float kf1 = r.y * (1.0f - 2.0f * dz0);
-    const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * r.y);
+    const float rr = __builtin_amdgcn_exp2f(2.0f * r.y);
+    const unsigned long long full_exec = __builtin_amdgcn_read_exec();
 #pragma unroll
     for (int iy = 0; iy < TILE3D; ++iy) {
         const float dy = p.y - (y0 + (float)iy + 0.5f);
         const float k0 = dy * (q.w * dy + bdx) + adx2L;
         const float k1 = r.x * dy + cdx;
-        if (EXACT) {
 #pragma unroll
-            for (int iz = 0; iz < TILE3D; ++iz) {
-                const float dz = dz0 - (float)iz;
-                const float pl = dz * (r.y * dz + k1) + k0;
-                const float al = __builtin_amdgcn_exp2f(pl);
-                // power <= 0 (VOX/forward.cu:288) <=> pl <= L ; alpha >= 1e-6 (VOX/forward.cu:293)
-                const bool ok = (pl <= r.z) && (al >= ALPHA_MIN_3D);
-                acc[iy * TILE3D + iz] += ok ? al : 0.f;
-            }
-        } else {
+        for (int seg = 0; seg < TILE3D; seg += VOX_RECUR_STEPS) {   // re-anchor every VOX_RECUR_STEPS voxels
+            const float dzs = dz0 - (float)seg;
+            float g = __builtin_amdgcn_exp2f(dzs * (r.y * dzs + k1) + k0);
+            float rt = __builtin_amdgcn_exp2f(fminf(kf1 + (2.0f * (float)seg) * r.y - k1, 120.0f));
 #pragma unroll
-            for (int seg = 0; seg < TILE3D; seg += VOX_RECUR_STEPS) {   // re-anchor every VOX_RECUR_STEPS voxels
-                const float dzs = dz0 - (float)seg;
-                float g = __builtin_amdgcn_exp2f(dzs * (r.y * dzs + k1) + k0);
-                float rt = __builtin_amdgcn_exp2f(fminf(kf1 + (2.0f * (float)seg) * r.y - k1, 120.0f));
-#pragma unroll
-                for (int c = 0; c < VOX_RECUR_STEPS; ++c) {
-                    acc[iy * TILE3D + seg + c] += (g >= ALPHA_MIN_3D) ? g : 0.f;   // power <= 0 holds: positive definite
-                    g *= rt;
-                    rt *= rr;
-                }
+            for (int c = 0; c < VOX_RECUR_STEPS; ++c) {
+                // power <= 0 (VOX/forward.cu:288) holds: entries that reach this path have a positive definite conic;
+                // alpha >= 1e-6: VOX/forward.cu:293
+                // acc += (g >= 1e-6) ? g : 0 as an EXEC mask: compare + masked add instead of compare + select + add (487 ->
+                // 467 us at 256^3 once the kernel runs 4 waves/SIMD; it changed nothing at 3)
+                asm volatile("v_cmpx_le_f32_e32 %[thr], %[g]\n\t"
+                             "v_add_f32_e32 %[a], %[a], %[g]\n\t"
+                             "s_mov_b64 exec, %[ex]"
+                             : [a] "+v"(acc[iy * TILE3D + seg + c])
+                             : [thr] "n"(0x358637bd), [g] "v"(g), [ex] "s"(full_exec)
+                             : "vcc");
+                g *= rt;
+                rt *= rr;
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-__global__ void __launch_bounds__(256, 3) voxel_render_forward_kernel(
+#ifndef R2_VFWD_WGS
+#define R2_VFWD_WGS 4
+#endif
+__global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
     VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
@@ -158,39 +161,43 @@ __global__ void __launch_bounds__(256, 3) voxel_render_forward_kernel(
         }
         __syncthreads();
         const int nbatch = (int)min((uint32_t)VFWD_BATCH, end - base);
-        int cnt = 0;
+        // compaction: entries that may use the row recurrence queue up from the front of sQ, the few that need the exact
+        // evaluation (needs_exact_row3: very thin along z, or no finite culling box) from the back -- they are evaluated
+        // voxel-parallel with the tail, so that the lane-per-entry step is straight-line code (the exact variant of the step
+        // cost 24 VGPRs = one wave per SIMD, and 50 us at 256^3 whenever a single lane of a step asked for it)
+        int cnt = 0, cntx = 0;
 #pragma unroll
         for (int r = 0; r < VFWD_BATCH / 64; ++r) {
             const int e = r * 64 + lane;
             const float4 p = s0[e], h = s3[e];
-            const bool keep = e < nbatch && slab_live(p.x, p.y, p.z, h, xc, y0, z0);
-            const unsigned long long m = __ballot(keep);
+            const float4 g = s2[e];
+            const bool live = e < nbatch && slab_live(p.x, p.y, p.z, h, xc, y0, z0);
+            const bool ex = live && needs_exact_row3(g.y, g.z, h.z);
+            const bool keep = live && !ex;
+            const unsigned long long m = __ballot(keep), mx = __ballot(ex);
             if (keep) sQ[wave][cnt + __popcll(m & lt_mask)] = (uint16_t)e;
+            if (ex) sQ[wave][VFWD_BATCH - 1 - (cntx + __popcll(mx & lt_mask))] = (uint16_t)e;
             cnt += __popcll(m);
+            cntx += __popcll(mx);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         int head = 0;
         for (; cnt - head >= VFWD_MIN_STEP; head += 64) {
             float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = make_float4(0.f, 0.f, -INFINITY, 0.f);   // idle lane
-            bool exact = false;
             if (head + lane < cnt) {
                 const int e = sQ[wave][head + lane];
                 ep = s0[e]; eq = s1[e]; er = s2[e];
-                exact = needs_exact_row3(er.y, er.z, s3[e].z);
             }
-            const float Lr = er.z;
-            er.z = exact ? -INFINITY : Lr;
-            vfwd_item<false>(ep, eq, er, xc, y0, z0, acc);
-            if (__any(exact)) {
-                er.z = exact ? Lr : -INFINITY;
-                vfwd_item<true>(ep, eq, er, xc, y0, z0, acc);
-            }
+            vfwd_item(ep, eq, er, xc, y0, z0, acc);
             stepped = true;
         }
-        // a tail too short to fill a lane-per-entry step is evaluated voxel-parallel instead (lane = voxel y*8+z of the
-        // slab, entries broadcast from LDS, exact exp): ~20 instructions per entry instead of a ~500-instruction step
-        for (int j = head; j < cnt; ++j) {
+        // a tail too short to fill a lane-per-entry step, and the exact entries, are evaluated voxel-parallel instead (lane =
+        // voxel y*8+z of the slab, entries broadcast from LDS, exact exp): ~20 instructions per entry instead of a
+        // ~500-instruction step
+        const int ntail = (cnt - head) + cntx;
+        for (int t = 0; t < ntail; ++t) {
+            const int j = t < cnt - head ? head + t : VFWD_BATCH - 1 - (t - (cnt - head));
             const int e = sQ[wave][j];
             const float4 p = s0[e], q = s1[e], r = s2[e];
             const float dx = p.x - xc, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);

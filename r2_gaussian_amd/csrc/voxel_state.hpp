@@ -14,17 +14,22 @@ constexpr int VPART_STRIDE = 12;      // floats per instance in the backward mom
 constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
 constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)
 
-// Row recurrence along z (see raster_render.hip: needs_exact_row), re-anchored every VOX_RECUR_STEPS voxels: safe unless
-// the Gaussian is so thin along z that (VOX_RECUR_STEPS - 1) steps could climb from an underflowed start (p0 < -126)
-// back above the alpha cut-off, or it has no finite culling box.  Voxel-space Gaussians are small (sigma ~ 1-3
-// voxels), hence the short segments: with 3 steps the bound is |F2| <= ~5 (sigma_z >= 0.37 voxel).
+// Row recurrence along z (see raster_render.hip: row_tier): G(c+1) = G(c) r(c), r(c+1) = r(c) exp2(2 F2).  A row of 8 voxels
+// is walked in one piece (tier 0) or re-anchored after 4 voxels (tier 1).  The recurrence is safe unless the Gaussian is so
+// thin along z that `steps` steps could climb from an underflowed start (exponent < -126) back above the alpha cut-off, or it
+// has no finite culling box: such entries are evaluated exactly.  Voxel-space Gaussians are small (sigma ~ 1-3 voxels): with
+// 3 steps the bound is |F2| <= ~5 (sigma_z >= 0.37 voxel), with 7 steps |F2| <= ~0.95 (sigma_z >= 0.87 voxel).
 constexpr int VOX_RECUR_STEPS = 4;
-__device__ __forceinline__ bool needs_exact_row3(float F2, float L, float hx)
+__device__ __forceinline__ bool recurrence_safe3(float F2, float L, int steps)
 {
     // head-room sqrt(126 + L), not sqrt(126): the exponent that underflows includes L (see row_tier in raster_state.hpp)
     const float smax = (__builtin_amdgcn_sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - __builtin_amdgcn_sqrtf(fmaxf(L - LOG2_ALPHA_MIN_3D, 0.f) + 1.0f)) *
-                       (1.0f / (float)(VOX_RECUR_STEPS - 1));
-    return !(smax > 0.f && fabsf(F2) <= smax * smax) || !(hx < 3.0e38f);
+                       (1.0f / (float)steps);
+    return smax > 0.f && fabsf(F2) <= smax * smax;
+}
+__device__ __forceinline__ bool needs_exact_row3(float F2, float L, float hx)
+{
+    return !recurrence_safe3(F2, L, VOX_RECUR_STEPS - 1) || !(hx < 3.0e38f);
 }
 
 struct VoxelGeom {
