@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cmath>
 
+R2_TS_DEFINE(order)
+
 namespace r2 {
 
 namespace {
@@ -182,6 +184,7 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_reduce_kernel(const uint2 *_
                                                                   const uint32_t *__restrict__ wgmm, uint32_t nwg)
 {
     __shared__ uint2 sh[S2_THREADS / 64];
+    R2_TS_AT(order, 2);
     if (blockIdx.x == gridDim.x - 1) {   // extra workgroup: extrema
         uint32_t m[4] = { 0u, 0u, 0u, 0u };
         for (uint32_t g = threadIdx.x; g < nwg; g += S2_THREADS) {
@@ -216,6 +219,7 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_reduce_kernel(const uint2 *_
     if (over) c->overflow = 1u;   // benign race: everybody stores 1
     const uint2 t = block_reduce2_1024(v, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    R2_TS_AT(order, 3);
 }
 
 // inclusive prefix sums of both arrays; the last element's sums are the number of visible keys and of instances
@@ -226,6 +230,7 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_apply_kernel(const uint2 *__
 {
     __shared__ uint2 sh[S2_THREADS / 64];
     __shared__ uint2 wsum[S2_THREADS / 64];
+    R2_TS_AT(order, 4);
     uint2 pre = make_uint2(0u, 0u);
     for (uint32_t g = threadIdx.x; g < blockIdx.x; g += S2_THREADS) {
         const uint2 q = partial[g];
@@ -267,11 +272,14 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_apply_kernel(const uint2 *__
             __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
+    R2_TS_AT(order, 5);
 }
 
 __global__ void __launch_bounds__(256) zero_kernel(uint4 *__restrict__ p, size_t n16)
 {
+    R2_TS_AT(order, 0);
     for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256u) p[i] = make_uint4(0u, 0u, 0u, 0u);
+    R2_TS_AT(order, 1);
 }
 
 // every visible key takes its slot: bucket base + ticket.  One 16-byte record {key, id, instances, bucket} per slot.
@@ -280,12 +288,14 @@ __global__ void __launch_bounds__(256) fast_place_kernel(uint32_t n, const uint3
                                                          uint4 *__restrict__ slot)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    R2_TS_AT(order, 6);
     if (i >= n) return;
     const uint32_t k = keys[i], m = n_inst[i];
     if (k == CULLED_KEY || m == 0u) return;
     const uint2 b = bt[i];
     const uint32_t beg = b.x ? incl_c[b.x - 1u] : 0u;
     slot[beg + b.y] = make_uint4(k, i, m, b.x);
+    R2_TS_AT(order, 7);
 }
 
 // every slot ranks its key among the (key, id) pairs of its bucket, which also gives the instances emitted before it
@@ -294,6 +304,7 @@ __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, co
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ offsets)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    R2_TS_AT(order, 8);
     if (p >= c->nvis) return;
     const uint4 me = slot[p];
     const uint32_t b = me.w;
@@ -314,6 +325,7 @@ __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, co
     }
     order[beg + rank] = me.y;
     offsets[beg + rank] = tbeg + before + me.z;   // inclusive, like the scan of the un-hinted path
+    R2_TS_AT(order, 9);
 }
 
 struct Temp {

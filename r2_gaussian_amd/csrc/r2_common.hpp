@@ -36,6 +36,30 @@ void set_error(const char *fmt, ...);
         }                                                                                         \
     } while (0)
 
+// ---- experiment builds only (-DR2_EXP_TS): s_memrealtime (100 MHz) stamps per phase and workgroup, one table per
+// translation unit, read back by scripts/cbench through r2_debug_ts_<unit>() -- the timeline inside and between kernels
+#ifdef R2_EXP_TS
+#define R2_TS_DEFINE(unit)                                                                                              \
+    namespace r2 { __device__ unsigned long long g_ts_##unit[16][2048]; }                                               \
+    extern "C" __attribute__((visibility("default"))) int r2_debug_ts_##unit(unsigned long long *out)                   \
+    {                                                                                                                   \
+        return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(r2::g_ts_##unit), sizeof(unsigned long long) * 16 * 2048);      \
+    }
+// slots 0..2046: the stamp of that workgroup (larger grids: only their first 2047 workgroups); slot 2047: the latest stamp
+// of every 32nd workgroup (atomic max) -- the end of a phase over the whole grid
+#define R2_TS_AT(unit, ph)                                                                                              \
+    do {                                                                                                                \
+        if (threadIdx.x == 0) {                                                                                         \
+            const unsigned long long _t = wall_clock64();                                                               \
+            if (blockIdx.x < 2047u) r2::g_ts_##unit[ph][blockIdx.x] = _t;                                               \
+            if ((blockIdx.x & 31u) == 31u) atomicMax(&r2::g_ts_##unit[ph][2047], _t);                                                                  \
+        }                                                                                                               \
+    } while (0)
+#else
+#define R2_TS_DEFINE(unit)
+#define R2_TS_AT(unit, ph)
+#endif
+
 // ---- optional per-stage timing with HIP events on the caller's stream (r2_profile_* in r2hip.h)
 enum Stage {
     ST_RAS_PREPROCESS = 0, ST_RAS_SCAN, ST_RAS_DUPLICATE, ST_RAS_SORT, ST_RAS_RANGES, ST_RAS_RENDER_FWD,

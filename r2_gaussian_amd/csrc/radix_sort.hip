@@ -18,7 +18,19 @@
 #include "r2_common.hpp"
 #include <algorithm>
 
+R2_TS_DEFINE(sort)
+
 namespace r2 {
+
+// Experiment builds (python -m r2_gaussian_amd.build -DR2_EXP_TS --out=libr2hip_ts.so; scripts/cbench prints the table):
+// s_memrealtime stamps per phase and workgroup -- the timeline INSIDE and BETWEEN the three kernels of a pass.  What it showed
+// for the single-pass tile sort of 1.16 M instances (284 workgroups, 33 us from the upsweep's launch to the downsweep's end):
+// upsweep 0 -> 3.3 us, 1 us gap, scan 4.5 -> 8.1, 1.8 us gap, downsweep 10.0 -> 21.5 (median workgroup: loads 3.8, ranking 3.8,
+// per-digit epilogue 1.7, scatter 1.5) but -> 27.5 for the 28 CUs that host two workgroups, which is the kernel's end.
+// Tried on that evidence, none better than +-1 us: 2048-key tiles (twice the workgroups, half the chain), 1024-thread
+// workgroups, peer masks of all rows before the LDS chain, all loads issued up front, the range/work-list job in an extra
+// workgroup instead of workgroup 0's prologue (7.4 us, but the two-workgroup CUs finish later anyway).
+#define R2_TS(ph) R2_TS_AT(sort, ph)
 
 namespace {
 
@@ -94,6 +106,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uin
                                                                 uint32_t *__restrict__ H, uint32_t *__restrict__ clear_skip)
 {
     __shared__ uint32_t hist[RS_MAX_RADIX];
+    R2_TS(8);
     const uint32_t radix = 1u << bits;
     const int e = executed_before(skip, pass);
     const uint32_t *__restrict__ keys = rd_k(buf, e == 0 ? 0 : target_of(e - 1, phase));
@@ -109,6 +122,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uin
     __syncthreads();
     uint32_t *__restrict__ row = H + (size_t)blockIdx.x * radix;
     for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) row[d] = hist[d];
+    R2_TS(9);
 }
 
 // ------------------------------------------------------------------------------------------------------------- scan
@@ -119,6 +133,7 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
                                                              uint32_t *__restrict__ totals)
 {
     __shared__ uint32_t part[RS_SCAN_ROWS][RS_SCAN_DIGITS];
+    R2_TS(10);
     const uint32_t radix = 1u << bits;
     const uint32_t dl = threadIdx.x % RS_SCAN_DIGITS, row = threadIdx.x / RS_SCAN_DIGITS;
     const uint32_t d = blockIdx.x * RS_SCAN_DIGITS + dl;
@@ -152,6 +167,7 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
             if (allow_skip && total == n) skip[pass] = 1u;   // every key has this digit: the pass would be the identity
         }
     }
+    R2_TS(11);
 }
 
 // -------------------------------------------------------------------------------------------------------- downsweep
@@ -174,10 +190,12 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     uint32_t *digit_off = smem + RS_WAVES * prad;      // [prad] global position of this tile's first key of each digit
     __shared__ uint32_t wsum[RS_WAVES];
 
+    R2_TS(0);
     if (skip[pass]) return;
     // single-pass tile sort: the digit totals are the per-tile instance counts -- block 0 also turns them into the tile
     // ranges and the render kernels' work list (one launch less on the forward's critical path)
     if (INV && wo.ranges != nullptr && blockIdx.x == 0) ranges_and_work_block<RS_THREADS>(totals, wo);
+    R2_TS(1);
     const int e = executed_before(skip, pass);
     const int src = e == 0 ? 0 : target_of(e - 1, phase), dst = target_of(e, phase);
     const uint32_t *__restrict__ kin = rd_k(buf, src);
@@ -206,6 +224,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
         wal[i] = (HAS_W && idx < n) ? win[idx] : 0u;
     }
     __syncthreads();
+    R2_TS(2);
     // ---- rank: rows in key order; lanes holding the same digit find each other with one ballot per digit bit
     uint32_t *wh = wave_hist + wave * prad;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -231,6 +250,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+    R2_TS(3);
 
     // ---- per digit: exclusive offsets of the waves inside the tile; digit base = exclusive scan of the totals
     const uint32_t dpt = radix / RS_THREADS > 0 ? radix / RS_THREADS : 1;   // consecutive digits per thread
@@ -267,6 +287,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
         }
     }
     __syncthreads();
+    R2_TS(4);
 
     // Narrow digits (<= 8 bits: a 4096-key tile holds ~16 keys per digit): regroup the tile by digit in LDS first, so
     // that a wave's stores fall into a few contiguous runs instead of 64 scattered words -- scattered 4-byte stores from
@@ -333,6 +354,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
             if (HAS_W) wout[pos] = wal[i];
         }
     }
+    R2_TS(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------- finalize

@@ -7,6 +7,8 @@
 #include "r2_math.hpp"
 #include "raster_state.hpp"
 
+R2_TS_DEFINE(geom)
+
 #ifndef M_PI
 #define M_PI 3.14159265358979323846
 #endif
@@ -165,6 +167,7 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 {
     // one lane per VIEW INSTANCE: idx = v * P + src (V = 1: the reference's one lane per Gaussian); view v's matrices
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    R2_TS_AT(geom, 0);
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P * V) {
@@ -173,7 +176,9 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
                               projs + 16 * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds,
                               tiles_touched, op_mu, thin_flag, reg, key, bt);
     }
+    R2_TS_AT(geom, 1);
     depth_register_end(reg, (uint32_t)idx, key, bt);
+    R2_TS_AT(geom, 2);
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -198,6 +203,7 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
     const int *__restrict__ radii, int gx, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
     uint32_t *__restrict__ vals, const uint32_t *__restrict__ nvis)
 {
+    R2_TS_AT(geom, 4);
     if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -251,6 +257,7 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
             vals[k] = o_id;
         }
     }
+    R2_TS_AT(geom, 5);
 }
 
 // ------------------------------------------------------------------ backward: fused geometry gradient
@@ -277,6 +284,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     // that order (deterministic).  Per view: dL/dmean2D, dL/dconic, dL/dmu (rows g); summed over the views: dL/dopacity,
     // dL/dmean3D, dL/dcov3D and, through ONE covariance backward on the sum (it is linear), dL/dscale, dL/drot (rows idx).
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    R2_TS_AT(geom, 6);
     if (idx >= P) return;
     const int V = MV ? Vn : 1;   // single view: a compile-time trip count (the loop folds away)
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
@@ -448,6 +456,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
         if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
         if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    R2_TS_AT(geom, 7);
 }
 
 // ------------------------------------------------------------------ host launchers

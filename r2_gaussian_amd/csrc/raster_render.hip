@@ -23,6 +23,8 @@
 //           forward tests; re-evaluating the tests prunes the same pairs, so n_contrib is not needed.
 #include "raster_state.hpp"
 
+R2_TS_DEFINE(render)
+
 namespace r2 {
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -114,6 +116,7 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     uint32_t *__restrict__ tiles)
 {
     const uint32_t w = blockIdx.x;
+    R2_TS_AT(render, 0);
     if (w >= chunk_base[FUSED ? T + 1 : T]) return;
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
@@ -224,6 +227,7 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
         partial[(size_t)w * 256 + (ly * TILE2D + lx)] = acc[0];
         return;
     }
+    R2_TS_AT(render, 1);
     if (wd.w == 1u) {   // the tile's only work item: the image pixel itself
         const int px = tx * TILE2D + lx, py = ty * TILE2D + ly;
         if (px < W && py < H) out_color[py * W + px] = acc[0];
@@ -563,6 +567,7 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     float4 a, b;
     int rad;
     uint32_t first_row;
+    R2_TS_AT(render, 2);
     load1(blockIdx.x, tile, id, live);
     load1(blockIdx.x + G, tile1, id1, live1);
     load2(id, a, b, rad, first_row);
@@ -714,6 +719,7 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     tile1 = tile2; id1 = id2; live1 = live2;
     a = a1; b = b1; rad = rad1; first_row = first_row1;
     }   // chunk loop
+    R2_TS_AT(render, 3);
 }
 
 // ------------------------------------------------------------------------------------------------ launchers

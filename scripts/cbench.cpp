@@ -137,6 +137,42 @@ int main(int argc, char **argv)
     printf("  %-20s %8.2f us\n", "raster stage sum", sum);
     prof_enable(0);
 
+    // experiment builds (-DR2_EXP_TS) stamp s_memrealtime at phase boundaries inside selected kernels: one [phase][block]
+    // table per translation unit; printed as one timeline of the last step (us since the earliest stamp)
+    {
+        const char *units[] = {"order", "geom", "sort", "render"};
+        std::vector<std::vector<unsigned long long>> tabs;
+        std::vector<std::string> names;
+        bool any = false;
+        for (const char *u : units)
+            if (dlsym(h, (std::string("r2_debug_ts_") + u).c_str())) any = true;
+        if (any) {
+            step(7);
+            CHECK(hipStreamSynchronize(s));
+            unsigned long long t0 = ~0ull;
+            for (const char *u : units) {
+                void *pt = dlsym(h, (std::string("r2_debug_ts_") + u).c_str());
+                if (!pt) continue;
+                std::vector<unsigned long long> ts(16 * 2048);
+                reinterpret_cast<int (*)(unsigned long long *)>(pt)(ts.data());
+                for (unsigned long long v : ts)
+                    if (v && v < t0) t0 = v;
+                tabs.push_back(ts);
+                names.push_back(u);
+            }
+            for (size_t k = 0; k < tabs.size(); ++k)
+                for (int ph = 0; ph < 16; ++ph) {
+                    std::vector<double> v;
+                    for (int b = 0; b < 2048; ++b)
+                        if (tabs[k][ph * 2048 + b]) v.push_back((double)(tabs[k][ph * 2048 + b] - t0) * 0.01);   // 100 MHz -> us
+                    if (v.empty()) continue;
+                    std::sort(v.begin(), v.end());
+                    printf("  TS %-6s %2d: n %4zu  min %7.2f  med %7.2f  max %7.2f us\n", names[k].c_str(), ph, v.size(), v.front(),
+                           v[v.size() / 2], v.back());
+                }
+        }
+    }
+
     // batched views (r2_raster_forward_batch / _backward_batch; absent from older builds of the library): BV views per call
     if (void *pf = dlsym(h, "r2_raster_forward_batch")) {
         auto bfwd = reinterpret_cast<decltype(&r2_raster_forward_batch)>(pf);
