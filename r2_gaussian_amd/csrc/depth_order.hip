@@ -258,6 +258,11 @@ __global__ void __launch_bounds__(S2_THREADS) scan2_apply_kernel(const uint2 *__
     *reinterpret_cast<uint4 *>(incl_c + base) = oc;
     *reinterpret_cast<uint4 *>(incl_t + base) = ot;
     if (base + S2_IPT == nb) {
+        // the instance counts are scanned in 32 bits; their total in 64, so that a sum beyond the 31-bit num_rendered of
+        // the API is reported (as an out-of-range total the host rejects) instead of wrapping silently
+        unsigned long long total64 = 0;
+        for (uint32_t g = 0; g < gridDim.x; ++g) total64 += partial[g].y;
+        if (total64 > 0x7FFFFFFFull) ot.w = 0xFFFFFFFFu;
         c->nvis = oc.w;
         c->total = ot.w;
         if (mailbox) {   // post the host-read words (the others were written by earlier kernels) straight to pinned host memory

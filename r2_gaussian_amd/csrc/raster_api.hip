@@ -110,7 +110,7 @@ static int raster_forward_impl(
     }
     depth_hint_update(0, (size_t)PV, hw, overflow);
     if (num_rendered > 0x7FFFFFFFu) {   // the API returns it as a non-negative int (like the reference's int num_rendered)
-        set_error("%s: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", what, num_rendered);
+        set_error("%s: more than 2147483647 (tile, Gaussian) instances: they do not fit the 31-bit num_rendered", what);
         return R2_ERR_INVALID;
     }
     const size_t R = num_rendered;
