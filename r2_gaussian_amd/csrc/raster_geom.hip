@@ -268,6 +268,7 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
 //   2. turn the moments into dL/dmean2D, dL/dconic, dL/dopacity, dL/dmu (the 7 sums of the reference);
 //   3. computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA backward (RAS/backward.cu:402-444).
 // Outputs are ASSIGNED; the caller's zero-initialisation covers the rows of culled Gaussians.
+constexpr int GB_ROWS = 256;   // moment rows a wave streams per pass (4 per lane)
 template <bool MV>
 __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     int P, int Vn, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
@@ -283,9 +284,15 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     // one lane per Gaussian; its V view instances g = v * P + idx are visited in view order and their gradients summed in
     // that order (deterministic).  Per view: dL/dmean2D, dL/dconic, dL/dmu (rows g); summed over the views: dL/dopacity,
     // dL/dmean3D, dL/dcov3D and, through ONE covariance backward on the sum (it is linear), dL/dscale, dL/drot (rows idx).
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // (lanes past the end stay in the kernel: the row streaming below is a wave-cooperative step; they work on a clamped
+    // index and store nothing)
+    const int idx_raw = blockIdx.x * 256 + threadIdx.x;
+    const bool in_range = idx_raw < P;
+    const int idx = in_range ? idx_raw : P - 1;
+    const int lane = threadIdx.x & 63;
+    __shared__ float4 s_rows[256 / 64][GB_ROWS * 2];   // per wave: one pass of moment rows (32 bytes each)
+    float4 *const wrows = s_rows[threadIdx.x >> 6];
     R2_TS_AT(geom, 6);
-    if (idx >= P) return;
     const int V = MV ? Vn : 1;   // single view: a compile-time trip count (the loop folds away)
     const float3 mean = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     float sc_in[3] = { 0.f, 0.f, 0.f };
@@ -299,19 +306,12 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     const int g = v * P + idx;
     const float *__restrict__ view = views + 16 * v;
     const float *__restrict__ proj = projs + 16 * v;
-    if (!(radii[g] > 0)) {
-        // culled in this view: all-zero per-view rows.  The reference gets them from the torch boundary's zero-filled
-        // tensors (SUB/rasterize_points.cu:124-131); writing them here spares the caller a memset.
-        dL_dmean2D[3 * g + 0] = 0.f; dL_dmean2D[3 * g + 1] = 0.f; dL_dmean2D[3 * g + 2] = 0.f;
-        dL_dmus[g] = 0.f;
-        reinterpret_cast<float4 *>(dL_dconics)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-        continue;
-    }
+    const bool live = in_range && radii[g] > 0;
 
     // ---- 1. moments of w = G * dL/dpix over all tiles of this view instance
     // every per-instance input is requested up front so that its latency overlaps the (dependent) row gathers
     const float4 ra = rec[2 * g], rb = rec[2 * g + 1];
-    const uint32_t first = first_inst[g], ninst = tiles_touched[g];
+    const uint32_t first = first_inst[g], ninst = live ? tiles_touched[g] : 0u;
     const float2 om = op_mu[g];
     float cov3D[6];
     // the covariance comes from the forward's state (recomputing it from scales / rotations instead -- 24 B/Gaussian less
@@ -320,23 +320,68 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
 #pragma unroll
     for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * cbase + k];
     float S0 = 0.f, S1 = 0.f, S2 = 0.f, S3 = 0.f, S4 = 0.f, S5 = 0.f;
-    // this Gaussian's rows are contiguous: the render backward stores each instance's row at its EMISSION index
-    // four rows per trip, all eight loads in flight before the first add (the adds keep the row order: bit-reproducible);
-    // the trip count of a wave is that of its widest Gaussian, so cutting it 4x cuts the wave's dependent round trips 4x
-    for (uint32_t j = 0; j < ninst; j += 4) {
-        float4 m0[4], m1[4];
+#ifdef R2_EXP_TS
+    if (ninst == 0xFFFFFFFFu) S0 = cov3D[0] + ra.x + om.x;   // keep the loads ahead of the stamp
+    R2_TS_AT(geom, 8);
+#endif
+    // This Gaussian's rows are contiguous (the render backward stores each instance's row at its EMISSION index), but a lane
+    // that walks its own run makes its wave wait one gather round trip per step of its WIDEST Gaussian: stamped inside the
+    // kernel, that loop was 11 of the 16 us a workgroup lives.  So the wave streams the rows of its 64 Gaussians together:
+    // the concatenated runs are dealt out 64 * 4 rows at a time, one row per lane and load (owner = last lane whose exclusive
+    // offset is <= k, found like in the duplicate kernel), parked in LDS, and every lane then adds ITS rows from LDS in row
+    // order -- the same sums in the same order as before (bit-reproducible, bit-identical to the per-lane walk), one gather
+    // round trip per 256 rows instead of one per 4 rows of the widest lane.
+    {
+        uint32_t incl = ninst;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const size_t row = (size_t)first + min(j + (uint32_t)i, ninst - 1u);   // clamped: branch-free loads
-            m0[i] = part[2 * row];
-            m1[i] = part[2 * row + 1];
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
         }
+        const uint32_t excl = incl - ninst;
+        const uint32_t total = __shfl(incl, 63);
+        for (uint32_t base = 0; base < total; base += GB_ROWS) {   // wave-uniform
+            float4 m0[GB_ROWS / 64], m1[GB_ROWS / 64];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (j + (uint32_t)i < ninst) {
-                S0 += m0[i].x; S1 += m0[i].y; S2 += m0[i].z; S3 += m0[i].w; S4 += m1[i].x; S5 += m1[i].y;
+            for (int u = 0; u < GB_ROWS / 64; ++u) {
+                const uint32_t k = min(base + (uint32_t)(u * 64 + lane), total - 1u);   // clamped: branch-free loads
+                int lo = 0;
+#pragma unroll
+                for (int step = 32; step >= 1; step >>= 1) {
+                    const int probe = lo + step;
+                    const uint32_t e = __shfl(excl, probe & 63);
+                    if (probe <= 63 && e <= k) lo = probe;
+                }
+                const size_t row = (size_t)__shfl(first, lo) + (k - __shfl(excl, lo));
+                m0[u] = part[2 * row];
+                m1[u] = part[2 * row + 1];
             }
+            __builtin_amdgcn_wave_barrier();   // the previous pass has been read
+#pragma unroll
+            for (int u = 0; u < GB_ROWS / 64; ++u) {
+                wrows[2 * (u * 64 + lane)] = m0[u];
+                wrows[2 * (u * 64 + lane) + 1] = m1[u];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t r0 = max(excl, base), r1 = min(excl + ninst, base + (uint32_t)GB_ROWS);
+            for (uint32_t r = r0; r < r1; ++r) {
+                const float4 a0 = wrows[2 * (r - base)], a1 = wrows[2 * (r - base) + 1];
+                S0 += a0.x; S1 += a0.y; S2 += a0.z; S3 += a0.w; S4 += a1.x; S5 += a1.y;
+            }
+        }
     }
+    if (!live) {
+        if (in_range) {
+            // culled in this view: all-zero per-view rows.  The reference gets them from the torch boundary's zero-filled
+            // tensors (SUB/rasterize_points.cu:124-131); writing them here spares the caller a memset.
+            dL_dmean2D[3 * g + 0] = 0.f; dL_dmean2D[3 * g + 1] = 0.f; dL_dmean2D[3 * g + 2] = 0.f;
+            dL_dmus[g] = 0.f;
+            reinterpret_cast<float4 *>(dL_dconics)[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        continue;
+    }
+    R2_TS_AT(geom, 9);
     // ---- 2. the reference's accumulated sums (RAS/backward.cu:556-572), conic un-scaled from log2e units
     const float op = om.x, mu_f = om.y, opmu = op * mu_f;
     const float cA = ra.z * (-2.0f * LN2), cB = ra.w * (-LN2), cC = rb.x * (-2.0f * LN2);
@@ -437,6 +482,7 @@ __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     acc_mean[1] += gmean.y + ddy;
     acc_mean[2] += gmean.z + ddz;
     }   // views
+    if (!in_range) return;
 
     dL_dopacity[idx] = acc_op;
     dL_dmeans[3 * idx + 0] = acc_mean[0];
