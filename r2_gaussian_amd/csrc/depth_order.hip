@@ -177,6 +177,9 @@ __device__ __forceinline__ uint2 block_reduce2_1024(uint2 v, uint2 *sh /* [16] *
     return t;
 }
 
+// (Measured and left out, round 2: ONE kernel for the dual prefix sum -- every workgroup publishes its two sums as a 64-bit word
+// with agent-scope atomics and waits only for the words of the workgroups before it, no chain.  Parity green; the cross-XCD
+// publish / wait round trip costs what the kernel boundary costs: the place kernel started 0.9 us LATER.)
 // per-4096-bucket partial sums of both arrays; flags over-full buckets; the last workgroup + 1 folds the producer's
 // per-workgroup key extrema into the control block (the next call's hint)
 __global__ void __launch_bounds__(S2_THREADS) scan2_reduce_kernel(const uint2 *__restrict__ ct /* {instances, keys} */,
