@@ -376,6 +376,70 @@ def main():
         batched.update(views_per_call=BV, note="r2_raster_forward_batch + _backward_batch, %d views per call; no gradient "
                                                "exchange in this loop; each view bit-identical to the single-view call" % BV)
 
+    # ---- two independent views in flight: one host thread + one HIP stream each (the library's state is per host thread,
+    # the compiled torch boundary releases the GIL inside the calls).  The launch- and latency-bound binning chain of one
+    # view overlaps the render kernels of the other: what a trainer that accumulates the gradients of two views per
+    # optimiser step can do with the UNCHANGED drop-in classes.  Reported next to `value`, never instead of it.
+    concurrent = None
+    from r2_gaussian_amd import _C
+    if (rank == 0 or world > 1) and _C._shim() is not None:
+        import threading
+        NT = 2
+        nsteps = max(20, min(args.steps, 400))
+        # per thread: its own autograd leaves over the same storage (separate .grad), its own stream
+        leaves = [[t.detach().requires_grad_(True) for t in (xyz, dens, scal, rot)] for _ in range(NT)]
+        m2s = [torch.zeros_like(xyz, requires_grad=True) for _ in range(NT)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(NT)]
+        gate = threading.Barrier(NT + 1)
+        errs = []
+
+        def tworker(t):
+            try:
+                with torch.cuda.stream(streams[t]):
+                    lx, ld, ls, lr = leaves[t]
+
+                    def one(j):
+                        vi = ((j * NT + t) * world + rank) % len(views)
+                        img, _r = rasterizers[vi](means3D=lx, means2D=m2s[t], opacities=ld, scales=ls, rotations=lr)
+                        m2s[t].grad = None
+                        for p_ in leaves[t]:
+                            p_.grad = None
+                        img.backward(dL)
+                    for j in range(20):
+                        one(j)
+                    streams[t].synchronize()
+                    for _rep in range(5):
+                        gate.wait()
+                        for j in range(nsteps):
+                            one(j)
+                        streams[t].synchronize()
+                        gate.wait()
+            except Exception as ex:   # noqa: BLE001
+                errs.append(ex)
+                gate.abort()
+
+        torch.cuda.synchronize()
+        ths = [threading.Thread(target=tworker, args=(t,)) for t in range(NT)]
+        for th_ in ths:
+            th_.start()
+        crs = []
+        try:
+            for _rep in range(5):
+                gate.wait()
+                t0 = time.perf_counter()
+                gate.wait()
+                crs.append(max_over_ranks(time.perf_counter() - t0))
+        except threading.BrokenBarrierError:
+            pass
+        for th_ in ths:
+            th_.join()
+        if not errs and len(crs) == 5:
+            concurrent = summarize(crs, nsteps * NT, world)
+            concurrent.update(streams=NT, note="%d host threads, one HIP stream each, independent views through the drop-in "
+                                               "classes (gradients per thread, to be summed by the trainer)" % NT)
+        elif errs and rank == 0:
+            print("concurrent-streams section failed: %r" % (errs[0],), file=sys.stderr)
+
     # ---- instrumented pass: per-stage breakdown (not part of `value`)
     _lib.profile_enable(None)
     for _ in range(min(args.steps, 50)):
@@ -544,6 +608,7 @@ def main():
             "overlapped": overlapped,
             "forward_only": fwd_only,
             "batched": batched,
+            "concurrent_streams": concurrent,
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note, "us_per_launch": round(dom_us, 2), "launches_timed": int(dom[1]),
