@@ -298,6 +298,79 @@ int main(int argc, char **argv)
         }
     }
 
+    // both: two host threads / streams, each pushing BATCHES of BV views through the batched entry points
+    if (void *pf2 = dlsym(h, "r2_raster_forward_batch")) {
+        auto bfwd = reinterpret_cast<decltype(&r2_raster_forward_batch)>(pf2);
+        auto bbwd = sym<decltype(&r2_raster_backward_batch)>(h, "r2_raster_backward_batch");
+        float *bvm, *bpm;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&bvm), (size_t)V * 16 * 4));
+        CHECK(hipMalloc(reinterpret_cast<void **>(&bpm), (size_t)V * 16 * 4));
+        for (int i = 0; i < V; ++i) {
+            CHECK(hipMemcpy(bvm + (size_t)i * 16, views[i].vm, 64, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(bpm + (size_t)i * 16, views[i].pm, 64, hipMemcpyHostToDevice));
+        }
+        for (int BV : {2, 4}) {
+            const int nth = 2, nb = V / BV, bsteps = std::max(20, steps / BV);
+            struct BCtx { float *out, *dL, *g; int *radii; Slot slots[3]; hipStream_t s; };
+            std::vector<BCtx> ctx(nth);
+            for (auto &c : ctx) {
+                CHECK(hipMalloc(reinterpret_cast<void **>(&c.out), (size_t)BV * H * W * 4));
+                CHECK(hipMalloc(reinterpret_cast<void **>(&c.dL), (size_t)BV * H * W * 4));
+                for (int i = 0; i < BV; ++i) CHECK(hipMemcpy(c.dL + (size_t)i * H * W, dLh.data(), dLh.size() * 4, hipMemcpyHostToDevice));
+                CHECK(hipMalloc(reinterpret_cast<void **>(&c.radii), (size_t)BV * P * 4));
+                CHECK(hipMalloc(reinterpret_cast<void **>(&c.g), ((size_t)8 * BV + 17) * P * 4));
+                CHECK(hipStreamCreate(&c.s));
+            }
+            auto worker = [&](int t, int n) {
+                BCtx &c = ctx[t];
+                float *q2d = c.g, *qcon = c.g + (size_t)3 * BV * P, *qmu = c.g + (size_t)7 * BV * P, *qop = c.g + (size_t)8 * BV * P,
+                      *q3d = qop + P, *qcov = q3d + (size_t)3 * P, *qsc = qcov + (size_t)6 * P, *qrot = qsc + (size_t)3 * P;
+                for (int k = 0; k < n; ++k) {
+                    const int v0 = ((k * nth + t) % nb) * BV;
+                    const ViewH &v = views[v0];
+                    const int R = bfwd(grow, &c.slots[0], grow, &c.slots[1], grow, &c.slots[2], P, BV, W, H, means, dens, scal, 1.f, rot,
+                                       nullptr, bvm + (size_t)v0 * 16, bpm + (size_t)v0 * 16, v.tanx, v.tany, v.mode, c.out, c.radii, 0, c.s);
+                    if (R < 0) { fprintf(stderr, "batch forward (thread %d): %d %s\n", t, R, last_error()); exit(1); }
+                    const int rc = bbwd(P, BV, R, W, H, means, scal, 1.f, rot, nullptr, bvm + (size_t)v0 * 16, bpm + (size_t)v0 * 16,
+                                        v.tanx, v.tany, c.radii, c.slots[0].p, c.slots[1].p, c.slots[2].p, c.dL, q2d, qcon, qop, qmu, q3d,
+                                        qcov, qsc, qrot, v.mode, 0, c.s);
+                    if (rc < 0) { fprintf(stderr, "batch backward (thread %d): %d %s\n", t, rc, last_error()); exit(1); }
+                }
+                CHECK(hipStreamSynchronize(c.s));
+            };
+            std::atomic<int> arrived{0};
+            auto barrier = [&](int round) {
+                arrived.fetch_add(1);
+                while (arrived.load() < round * (nth + 1)) std::this_thread::yield();
+            };
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; ++t)
+                th.emplace_back([&, t]() {
+                    worker(t, 2 * nb + 4);
+                    for (int rep = 0; rep < 3; ++rep) {
+                        barrier(2 * rep + 1);
+                        worker(t, bsteps);
+                        barrier(2 * rep + 2);
+                    }
+                });
+            double bestn = 1e30;
+            for (int rep = 0; rep < 3; ++rep) {
+                barrier(2 * rep + 1);
+                const auto t0 = std::chrono::steady_clock::now();
+                barrier(2 * rep + 2);
+                bestn = std::min(bestn, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+            }
+            for (auto &x : th) x.join();
+            printf("STREAMS 2 x BATCH V=%d: %.1f views/s  %.2f us/view\n", BV, (double)nth * bsteps * BV / bestn,
+                   1e6 * bestn / ((double)nth * bsteps * BV));
+            for (auto &c : ctx) {
+                (void)hipFree(c.out); (void)hipFree(c.dL); (void)hipFree(c.radii); (void)hipFree(c.g); (void)hipStreamDestroy(c.s);
+                for (auto &sl : c.slots) if (sl.p) (void)hipFree(sl.p);
+            }
+        }
+        (void)hipFree(bvm); (void)hipFree(bpm);
+    }
+
     // voxelizer: the full 256^3 query
     auto vox = [&]() {
         const int R3 = vfwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, 256, 256, 256, 2.f, 2.f, 2.f, 0.f, 0.f, 0.f, means,
