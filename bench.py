@@ -29,6 +29,9 @@ The JSON line also carries
   parity_checked the SAME view's GPU image and gradients checked against that oracle result (pure 1e-4 relative bound +
                  attributed cut-off flips, oracle/parity.py); the run FAILS when it is out of tolerance
   forward_only   views/s of the forward alone
+  batched        views/s with four views per call (r2_raster_forward_batch / _backward_batch)
+  concurrent_streams  views/s with two independent views in flight: two host threads, one HIP stream each, through the same
+                 drop-in classes (the binning chain of one view overlaps the render kernels of the other)
   kernels        per-stage HIP-event breakdown + achieved fraction of the HBM peak, from an instrumented pass (not in `value`)
 Synthetic seeded data (no datasets offline), random Gaussian cloud of the named size.
 """
