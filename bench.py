@@ -385,7 +385,7 @@ def main():
     # optimiser step can do with the UNCHANGED drop-in classes.  Reported next to `value`, never instead of it.
     concurrent = None
     from r2_gaussian_amd import _C
-    if (rank == 0 or world > 1) and _C._shim() is not None:
+    if world == 1 and _C._shim() is not None:   # single-GPU runs only: an extra, kept out of the multi-rank collectives
         import threading
         NT = 2
         nsteps = max(20, min(args.steps, 400))
