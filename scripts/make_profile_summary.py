@@ -36,7 +36,9 @@ with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
             ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
             ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else ""))
     f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
-            "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  PMC "
-            "rows exist only for kernels of the raster step.  Kernels named bucket_* / minmax / scan_* belong to the un-hinted "
+            "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  The calls "
+            "column mixes the bench's sections: `<false>` kernels are the single-view step (`value`), `<true>` ones the batched "
+            "calls (V = 4), voxel kernels the 256^3 query and the 32^3 TV patch; average durations of kernels used by several "
+            "sections are averages over all of them.  Kernels named bucket_* / minmax / scan_* belong to the un-hinted "
             "depth order (first call for a given P, and the separate `_C` calls bench.py makes to count num_rendered).\n")
 print(open(os.path.join(P, "%s_summary.md" % tag)).read()[:1800])
