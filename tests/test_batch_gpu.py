@@ -24,8 +24,9 @@ def _batch(c, views, dev, debug=False):
     return args, _C.rasterize_gaussians_batch(*args)
 
 
-@pytest.mark.parametrize("P,hw,V", [(6000, (80, 96), 3), (3000, (50, 70), 4), (20000, (256, 256), 4), (4000, (64, 64), 9)],
-                         ids=["3x80x96", "4x50x70_ragged", "4x256x256", "9x64x64_multipass_sort"])
+@pytest.mark.parametrize("P,hw,V", [(6000, (80, 96), 3), (3000, (50, 70), 4), (20000, (256, 256), 4), (4000, (64, 64), 9),
+                                    (300000, (512, 512), 4)],
+                         ids=["3x80x96", "4x50x70_ragged", "4x256x256", "9x64x64_multipass_sort", "4x512x512_300k_as_benchmarked"])
 def test_batch_equals_single_views_and_oracle(P, hw, V, oracle, gpu):
     from r2_gaussian_amd import _C
     c = S.make_cloud(P, seed=P % 101)
