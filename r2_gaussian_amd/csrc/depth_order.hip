@@ -307,6 +307,10 @@ __global__ void __launch_bounds__(256) fast_place_kernel(uint32_t n, const uint3
 }
 
 // every slot ranks its key among the (key, id) pairs of its bucket, which also gives the instances emitted before it
+// (Measured and left out, round 2: a lane per BUCKET instead of per slot -- bucket bounds first, the wave's slot range
+// staged in LDS, two dependent round trips instead of three, 1.4 us for the median workgroup -- but the clamped end buckets of
+// a hinted range routinely hold up to MAX_BUCKET keys, and the lane that owns one ranks n^2 pairs alone: 90-140 us for that
+// workgroup.  A lane per slot spreads exactly those buckets over many lanes.)
 __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, const uint4 *__restrict__ slot,
                                                         const uint32_t *__restrict__ incl_c, const uint32_t *__restrict__ incl_t,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ offsets)
