@@ -41,18 +41,41 @@ SOURCES = {
 }
 
 
+def _strip_comments(text):
+    """C / C++ source without comments and blank lines (string and character literals are left alone)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":   # literal: copy through the closing quote
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+        else:
+            out.append(c)
+            i += 1
+    return "\n".join(ln.rstrip() for ln in "".join(out).splitlines() if ln.strip())
+
+
 def source_hash():
-    """sha256 over the kernel sources + build flags: identifies WHICH kernels a measurement (e.g. the PMC summary under
-    profiles/) belongs to, independently of rebuilds."""
+    """sha256 over the kernel sources (comments and blank lines stripped) + build flags: identifies WHICH kernels a
+    measurement (e.g. the PMC summary under profiles/) belongs to, independently of rebuilds and of edits to comments."""
     import hashlib
     h = hashlib.sha256()
     files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".cpp")))
     for f in files:
         h.update(f.encode())
-        with open(os.path.join(CSRC, f), "rb") as fh:
-            h.update(fh.read())
-    with open(os.path.join(HERE, "..", "include", "r2hip.h"), "rb") as fh:
-        h.update(fh.read())
+        with open(os.path.join(CSRC, f), "r", encoding="utf-8", errors="replace") as fh:
+            h.update(_strip_comments(fh.read()).encode())
+    with open(os.path.join(HERE, "..", "include", "r2hip.h"), "r", encoding="utf-8", errors="replace") as fh:
+        h.update(_strip_comments(fh.read()).encode())
     h.update(repr((COMMON[:7], EXACT, FAST, sorted(SOURCES.items()))).encode())
     return h.hexdigest()
 
