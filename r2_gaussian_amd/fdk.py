@@ -104,8 +104,13 @@ def fdk(projs, angles, scanner_cfg, filter_name=None, device="cuda"):
     views = [S.make_view(float(a), (H, W), cfg) for a in np.asarray(angles).reshape(-1)]
     assert len(views) == V, "one angle per projection"
     M = torch.stack([v.full_proj_transform for v in views])
-    sDet = [s * scale for s in cfg["sDetector"]]
-    dv, du = sDet[0] / H, sDet[1] / W   # sDetector is [v, u] (dataset_readers.py:130)
+    if cone:
+        sDet = [s * scale for s in cfg["sDetector"]]
+        dv, du = sDet[0] / H, sDet[1] / W   # sDetector is [v, u] (dataset_readers.py:130)
+    else:
+        # parallel beams: the reference's orthographic camera maps view-space [-1, 1] onto the detector whatever sDetector
+        # says (identity projection, graphics_utils.py:98-101), so that IS the pixel pitch the projections were taken with
+        dv, du = 2.0 / H, 2.0 / W
     name = filter_name if filter_name is not None else cfg.get("filter")
     q = fdk_filter(p * scale, du, dv, cfg["DSD"] * scale, cfg["DSO"] * scale, name, cone)
     return fdk_backproject(q, M, cfg["DSO"] * scale, cfg["nVoxel"], [s * scale for s in cfg["sVoxel"]],

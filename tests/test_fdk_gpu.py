@@ -80,21 +80,31 @@ def _corr(a, b):
     return float((a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum()))
 
 
-def test_rasterizer_projections_reconstruct_to_the_voxelizer_volume(gpu, oracle):
+@pytest.mark.parametrize("scanner", [S.CONE_BEAM, S.PARALLEL_BEAM], ids=["cone", "parallel"])
+def test_rasterizer_projections_reconstruct_to_the_voxelizer_volume(gpu, oracle, scanner):
     """The physical anchor that stands in for TIGRE's output: FDK(X-ray projections of a cloud) ~ voxelisation of the cloud,
-    same orientation, same amplitude."""
+    same orientation, same amplitude -- for both beam geometries of the reference."""
     c = S.make_cloud(4000, seed=7, scale_mult=2.5)
     n_det, V = 128, 180
-    views = S.make_views(V, (n_det, n_det))
+    views = S.make_views(V, (n_det, n_det), scanner)
     projs = torch.stack([torch.as_tensor(Hh.hip_raster(c, v, gpu)["color"]).reshape(n_det, n_det) for v in views])
-    cfg = dict(S.CONE_BEAM, nVoxel=[64, 64, 64], filter=None)
+    cfg = dict(scanner, nVoxel=[64, 64, 64], filter=None)
     vol = K.fdk(projs.to(gpu), [v.angle for v in views], cfg).cpu().numpy()
     truth = Hh.hip_voxel(c, (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0), gpu)["vol"]
     r = _corr(vol, truth)
     gain = float((vol * truth).sum() / (truth * truth).sum())
     psnr = S.psnr3d(torch.as_tensor(truth), torch.as_tensor(vol), pixel_max=float(truth.max()))
-    Hh._log("fdk", "raster->fdk vs voxelizer", lambda: {"corr": r, "gain": gain, "psnr_db": psnr})
-    assert r > 0.999 and abs(gain - 1.0) < 0.01 and psnr > 40.0, (r, gain, psnr)   # CPU restatement: 0.99977, 0.9955, 45.3 dB
+    Hh._log("fdk", "raster->fdk vs voxelizer (%s)" % scanner["mode"], lambda: {"corr": r, "gain": gain, "psnr_db": psnr})
+    if scanner["mode"] == "cone":
+        assert r > 0.999 and abs(gain - 1.0) < 0.01 and psnr > 40.0, (r, gain, psnr)   # CPU restatement: 0.99977, 0.9955, 45.3 dB
+    else:
+        # the orthographic detector spans exactly the volume's [-1, 1]: the cloud's 5 % of points in the cube's corners leave
+        # it at oblique angles (truncated projections), which costs the border -- CPU restatement: 0.99539, 1.00256, 31.4 dB
+        # overall, and 0.999997 / 60.5 dB inside [12:52]^3
+        inner = slice(12, 52)
+        ri = _corr(vol[inner, inner, inner], truth[inner, inner, inner])
+        pi_ = S.psnr3d(torch.as_tensor(truth[inner, inner, inner]), torch.as_tensor(vol[inner, inner, inner]), pixel_max=float(truth.max()))
+        assert r > 0.99 and abs(gain - 1.0) < 0.01 and ri > 0.9999 and pi_ > 50.0, (r, gain, psnr, ri, pi_)
     for flipped in (vol[::-1], vol[:, ::-1], vol[:, :, ::-1], vol.transpose(1, 0, 2), vol.transpose(2, 1, 0)):
         assert _corr(np.ascontiguousarray(flipped), truth) < r - 0.005   # a dense blob: mirrored copies still reach 0.93-0.99
     # init_pcd on top: the sampled centres lie where the density is, their densities are the rescaled FDK values
@@ -103,7 +113,7 @@ def test_rasterizer_projections_reconstruct_to_the_voxelizer_volume(gpu, oracle)
     assert pts.shape == (2000, 4)
     idx = np.rint((pts[:, :3] + 1.0) / (2.0 / 64)).astype(int)
     assert np.allclose(pts[:, 3], vol[idx[:, 0], idx[:, 1], idx[:, 2]] * 0.15, rtol=1e-6)
-    assert (truth[idx[:, 0], idx[:, 1], idx[:, 2]] > 0.005).mean() > 0.95
+    assert (truth[idx[:, 0], idx[:, 1], idx[:, 2]] > 0.005).mean() > (0.95 if scanner["mode"] == "cone" else 0.9)
 
 
 def test_headline_size_timing(gpu):
