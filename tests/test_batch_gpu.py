@@ -28,9 +28,17 @@ def _batch(c, views, dev, debug=False):
                                     (300000, (512, 512), 4)],
                          ids=["3x80x96", "4x50x70_ragged", "4x256x256", "9x64x64_multipass_sort", "4x512x512_300k_as_benchmarked"])
 def test_batch_equals_single_views_and_oracle(P, hw, V, oracle, gpu):
+    _batch_case(P, hw, V, S.CONE_BEAM, oracle, gpu)
+
+
+def test_batch_parallel_beam(oracle, gpu):
+    _batch_case(5000, (72, 88), 3, S.PARALLEL_BEAM, oracle, gpu)
+
+
+def _batch_case(P, hw, V, scanner, oracle, gpu):
     from r2_gaussian_amd import _C
     c = S.make_cloud(P, seed=P % 101)
-    views = [S.make_view(0.3 + 0.9 * k, hw) for k in range(V)]
+    views = [S.make_view(0.3 + 0.9 * k, hw, scanner) for k in range(V)]
     args, (R, color, radii, gb, bb, ib) = _batch(c, views, gpu)
     torch.cuda.synchronize()
     assert color.shape == (V,) + hw and radii.shape == (V, P)
