@@ -141,3 +141,13 @@ def test_headline_size_timing(gpu):
     os.makedirs("gpurun_out", exist_ok=True)
     json.dump(out, open("gpurun_out/fdk_timing.json", "w"), indent=1)
     print(out)
+
+
+def test_argument_errors(gpu):
+    from r2_gaussian_amd._lib import R2HipError
+    with pytest.raises(R2HipError, match="4096"):
+        K.fdk_filter(torch.zeros(1, 2, 4100, device=gpu), 0.01, 0.01, 7.0, 5.0)
+    with pytest.raises(ValueError):
+        K.fdk_filter(torch.zeros(1, 8, 8, device=gpu), 0.01, 0.01, 7.0, 5.0, "butterworth")
+    with pytest.raises(R2HipError):
+        K.fdk_filter(torch.zeros(1, 8, 8), 0.01, 0.01, 7.0, 5.0)   # CPU tensor: no fallback
