@@ -412,11 +412,11 @@ def main():
                         one(j)
                     streams[t].synchronize()
                     for _rep in range(5):
-                        gate.wait()
+                        gate.wait(timeout=180)
                         for j in range(nsteps):
                             one(j)
                         streams[t].synchronize()
-                        gate.wait()
+                        gate.wait(timeout=180)
             except Exception as ex:   # noqa: BLE001
                 errs.append(ex)
                 gate.abort()
@@ -428,9 +428,9 @@ def main():
         crs = []
         try:
             for _rep in range(5):
-                gate.wait()
+                gate.wait(timeout=180)
                 t0 = time.perf_counter()
-                gate.wait()
+                gate.wait(timeout=180)
                 crs.append(max_over_ranks(time.perf_counter() - t0))
         except threading.BrokenBarrierError:
             pass
