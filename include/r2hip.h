@@ -47,7 +47,7 @@ extern "C" {
 #define R2_API
 #endif
 
-#define R2_ABI_VERSION 1
+#define R2_ABI_VERSION 2
 #define R2_ERR_INVALID (-10001) /* bad argument (NULL where data is required, negative size ...) */
 #define R2_ERR_ALLOC   (-10002) /* an r2_alloc_fn callback returned NULL */
 
@@ -178,19 +178,23 @@ R2_API int r2_loss_tv3d(int nx, int ny, int nz, const float *vol, float weight, 
  * synchronises the stream ONCE to return the four survivor counts (originals, clones, first children, second children);
  * the caller allocates sum(counts) rows and calls emit with the same arguments and the same scratch.  normals: [2,P,3]
  * N(0,1) samples indexed by the PARENT's row (only rows of split parents are read).  scale_lo < scale_hi: bounded-sigmoid
- * scaling activation, else exp.  max_screen_size / max_scale pruning (None by default in the reference) is not implemented.
+ * scaling activation, else exp.  max_screen_size / max_scale: the reference's optional prune thresholds (rows whose
+ * max_radii2D / largest activated scale exceed them are pruned, gaussian_model.py:540-545); <= 0 switches them off (None).
  * params / exp_avg / exp_avg_sq (+ _out): 4 device pointers each in the order xyz[.,3], density[.,1], scaling[.,3], rotation[.,4]. */
 R2_API int r2_densify_stats(int P, const int *radii, const float *dL_dmeans2D /* [P,3] */, float *max_radii2D, float *grad_accum,
                             float *denom, void *stream);
 R2_API size_t r2_densify_scratch_bytes(int P);
 R2_API int r2_densify_classify(int P, const float *xyz, const float *density, const float *scaling, const float *rotation,
-                               const float *grad_accum, const float *denom, const float *normals, float grad_thr, float scale_thr,
-                               float density_min, const float *bbox_host /* 6 host floats: lo xyz, hi xyz */, float scale_lo,
-                               float scale_hi, int do_densify, void *scratch, unsigned int *counts_host /* [4] */, void *stream);
+                               const float *max_radii2D, const float *grad_accum, const float *denom, const float *normals,
+                               float grad_thr, float scale_thr, float density_min,
+                               const float *bbox_host /* 6 host floats: lo xyz, hi xyz */, float scale_lo, float scale_hi,
+                               int do_densify, float max_screen_size, float max_scale, void *scratch,
+                               unsigned int *counts_host /* [4] */, void *stream);
 R2_API int r2_densify_emit(int P, const float *const *params, const float *const *exp_avg, const float *const *exp_avg_sq,
                            const float *max_radii2D, const float *grad_accum, const float *denom, const float *normals,
                            float grad_thr, float scale_thr, float density_min, const float *bbox_host, float scale_lo,
-                           float scale_hi, int do_densify, const void *scratch, float *const *params_out, float *const *exp_avg_out,
+                           float scale_hi, int do_densify, float max_screen_size, float max_scale, const void *scratch,
+                           float *const *params_out, float *const *exp_avg_out,
                            float *const *exp_avg_sq_out, float *max_radii2D_out, float *grad_accum_out, float *denom_out,
                            void *stream);
 

@@ -7,6 +7,8 @@ raw device pointers + the current HIP stream down.
 """
 import os
 
+import threading
+
 import torch
 
 from . import _lib
@@ -79,8 +81,10 @@ class _State:
     """The three opaque state buffers of one forward call, filled through the allocation callbacks (SUB/utility.h:7-13).
 
     The ctypes callback objects are expensive to create (tens of microseconds) and every forward call needs three, so
-    they are created once per device and write into whichever ``_State`` is current; a forward call is synchronous on
-    the host (it returns num_rendered), so there is exactly one current state per device at any time."""
+    they are created once per device and write into whichever ``_State`` is current FOR THE CALLING THREAD: a forward call
+    is synchronous on its host thread (it returns num_rendered), but ctypes releases the GIL inside the call, so several
+    threads (multistream.StreamPool) can be inside a forward on the same device at once -- the current state is
+    thread-local (a callback runs on the thread that made the C call)."""
 
     __slots__ = ("bufs",)
 
@@ -91,7 +95,7 @@ class _State:
 class _DeviceHooks:
     def __init__(self, device):
         self.device = device
-        self.current = None
+        self._tls = threading.local()
         self.empty = torch.empty(0, dtype=torch.uint8, device=device)
         self.cbs = [_lib.ALLOC_FN(self._make(i)) for i in range(3)]
 
@@ -109,7 +113,7 @@ class _DeviceHooks:
                     t = torch.full((n,), 255, dtype=torch.uint8, device=self.device)
                 else:
                     t = torch.empty(n, dtype=torch.uint8, device=self.device)
-                self.current.bufs[i] = t
+                self._tls.current.bufs[i] = t
                 return t.data_ptr()
             except Exception:   # out of memory etc.: report NULL, the C side turns it into R2_ERR_ALLOC
                 return None
@@ -117,11 +121,11 @@ class _DeviceHooks:
 
     def begin(self):
         st = _State()
-        self.current = st
+        self._tls.current = st
         return st
 
     def finish(self, st):
-        self.current = None
+        self._tls.current = None
         return [b if b is not None else self.empty for b in st.bufs]
 
 

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("R2HIP_LIB") or os.path.join(_HERE, "libr2hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
-R2_ABI_VERSION = 1
+R2_ABI_VERSION = 2
 R2_ERR_INVALID = -10001
 R2_ERR_ALLOC = -10002
 
@@ -37,9 +37,9 @@ _SIGNATURES = {
     "r2_knn_dist2": (C.c_int, [_i, _fp, _fp, _p]),
     "r2_densify_stats": (C.c_int, [_i, _p, _fp, _fp, _fp, _fp, _p]),
     "r2_densify_scratch_bytes": (C.c_size_t, [_i]),
-    "r2_densify_classify": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _p, _p, _p]),
-    "r2_densify_emit": (C.c_int, [_i, _p, _p, _p, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _p, _p, _p, _p, _fp, _fp,
-                                  _fp, _p]),
+    "r2_densify_classify": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _f, _f, _p, _p, _p]),
+    "r2_densify_emit": (C.c_int, [_i, _p, _p, _p, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _f, _f, _p, _p, _p, _p, _fp,
+                                  _fp, _fp, _p]),
     "r2_loss_l1_ssim_scratch_floats": (C.c_size_t, [_i, _i]),
     "r2_loss_l1_ssim": (C.c_int, [_i, _i, _fp, _fp, _f, _f, _fp, _fp, _fp, _p]),
     "r2_loss_tv3d_scratch_floats": (C.c_size_t, [_i, _i, _i]),

@@ -17,6 +17,7 @@ struct DensifyCfg {
     float lo[3], hi[3];          // bounding box
     float s_lo, s_hi;            // bounded-sigmoid scaling activation; s_lo >= s_hi: exp activation (no bound)
     int do_densify;
+    float max_screen, max_scale; // optional prune thresholds (gaussian_model.py:540-545); <= 0: off (the reference's None)
 };
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }   // torch.nn.Softplus()
@@ -45,8 +46,8 @@ struct Decision {
 // everything densify_and_prune decides about Gaussian i (gaussian_model.py:430-550), recomputed by both passes
 __device__ __forceinline__ Decision decide(int i, int P, const float *__restrict__ xyz, const float *__restrict__ density,
                                            const float *__restrict__ scaling, const float *__restrict__ rotation,
-                                           const float *__restrict__ grad_accum, const float *__restrict__ denom,
-                                           const float *__restrict__ normals, const DensifyCfg &c)
+                                           const float *__restrict__ max_radii, const float *__restrict__ grad_accum,
+                                           const float *__restrict__ denom, const float *__restrict__ normals, const DensifyCfg &c)
 {
     Decision d;
     const float p[3] = { xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2] };
@@ -59,7 +60,11 @@ __device__ __forceinline__ Decision decide(int i, int P, const float *__restrict
     d.clone = hot && smax <= c.scale_thr;                  // :474-483
     d.split = hot && smax > c.scale_thr;                   // :430-441
     d.density_raw_orig = d.clone ? inv_softplus_f(dens * 0.5f) : density[i];   // :486-493: both copies get half the density
-    const bool pruned = softplus_f(d.density_raw_orig) < c.density_min || outside(p, c);   // :524-540
+    // the prune mask is evaluated AFTER clone / split on all rows (:524-546); a clone shares its original's scale and
+    // max_radii2D, split children inherit the parent's max_radii2D (:468) and get scale / 1.6
+    const bool big_screen = c.max_screen > 0.f && max_radii[i] > c.max_screen;   // :540-542
+    const bool pruned = softplus_f(d.density_raw_orig) < c.density_min || outside(p, c) || big_screen ||
+                        (c.max_scale > 0.f && smax > c.max_scale);               // :543-545
     d.keep_orig = !d.split && !pruned;
     d.keep_clone = d.clone && !pruned;
     d.keep_child[0] = d.keep_child[1] = false;
@@ -73,7 +78,10 @@ __device__ __forceinline__ Decision decide(int i, int P, const float *__restrict
                                 { 2 * (q1 * q3 - q0 * q2), 2 * (q2 * q3 + q0 * q1), 1 - 2 * (q1 * q1 + q2 * q2) } };
         d.child_density_raw = inv_softplus_f(dens * 0.5f);
         for (int k = 0; k < 3; ++k) d.child_scaling_raw[k] = scale_inv(s[k] / 1.6f, c);   // / (0.8 N), N = 2
-        const bool low = softplus_f(d.child_density_raw) < c.density_min;
+        bool low = softplus_f(d.child_density_raw) < c.density_min || big_screen;
+        if (c.max_scale > 0.f)
+            low = low || fmaxf(fmaxf(scale_act(d.child_scaling_raw[0], c), scale_act(d.child_scaling_raw[1], c)),
+                               scale_act(d.child_scaling_raw[2], c)) > c.max_scale;
         for (int ch = 0; ch < 2; ++ch) {
             const float *nn = normals + ((size_t)ch * P + i) * 3;
             const float v[3] = { nn[0] * s[0], nn[1] * s[1], nn[2] * s[2] };   // N(0, scale) in the local frame
@@ -86,13 +94,14 @@ __device__ __forceinline__ Decision decide(int i, int P, const float *__restrict
 
 __global__ void __launch_bounds__(256) densify_classify_kernel(int P, const float *__restrict__ xyz, const float *__restrict__ density,
                                                                const float *__restrict__ scaling, const float *__restrict__ rotation,
+                                                               const float *__restrict__ max_radii,
                                                                const float *__restrict__ grad_accum, const float *__restrict__ denom,
                                                                const float *__restrict__ normals, DensifyCfg c,
                                                                uint32_t *__restrict__ keep /* [4][P] */)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const Decision d = decide(i, P, xyz, density, scaling, rotation, grad_accum, denom, normals, c);
+    const Decision d = decide(i, P, xyz, density, scaling, rotation, max_radii, grad_accum, denom, normals, c);
     keep[i] = d.keep_orig;
     keep[(size_t)P + i] = d.keep_clone;
     keep[2 * (size_t)P + i] = d.keep_child[0];
@@ -114,7 +123,7 @@ __global__ void __launch_bounds__(256) densify_emit_kernel(int P, Rows r, const 
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= P) return;
-    const Decision d = decide(i, P, r.p[0], r.p[1], r.p[2], r.p[3], grad_accum, denom, normals, c);
+    const Decision d = decide(i, P, r.p[0], r.p[1], r.p[2], r.p[3], r.max_radii, grad_accum, denom, normals, c);
     const uint32_t n0 = pos[P - 1], n1 = pos[2 * (size_t)P - 1], n2 = pos[3 * (size_t)P - 1];
     auto write_stats = [&](size_t o) {
         r.max_radii_out[o] = r.max_radii[i];
@@ -189,34 +198,36 @@ extern "C" size_t r2_densify_scratch_bytes(int P)
 }
 
 static r2::DensifyCfg make_cfg(float grad_thr, float scale_thr, float density_min, const float *bbox, float scale_lo, float scale_hi,
-                               int do_densify)
+                               int do_densify, float max_screen_size, float max_scale)
 {
     r2::DensifyCfg c;
     c.grad_thr = grad_thr; c.scale_thr = scale_thr; c.density_min = density_min;
     for (int k = 0; k < 3; ++k) { c.lo[k] = bbox[k]; c.hi[k] = bbox[3 + k]; }
     c.s_lo = scale_lo; c.s_hi = scale_hi; c.do_densify = do_densify;
+    c.max_screen = max_screen_size; c.max_scale = max_scale;
     return c;
 }
 
 // pass 1: decide and count.  counts_host[4] = surviving {originals, clones, first children, second children}; the call
 // synchronises the stream once to read them (the caller sizes the outputs with them).
 extern "C" int r2_densify_classify(int P, const float *xyz, const float *density, const float *scaling, const float *rotation,
-                                   const float *grad_accum, const float *denom, const float *normals, float grad_thr,
-                                   float scale_thr, float density_min, const float *bbox_host, float scale_lo, float scale_hi,
-                                   int do_densify, void *scratch, unsigned int *counts_host, void *stream)
+                                   const float *max_radii2D, const float *grad_accum, const float *denom, const float *normals,
+                                   float grad_thr, float scale_thr, float density_min, const float *bbox_host, float scale_lo,
+                                   float scale_hi, int do_densify, float max_screen_size, float max_scale, void *scratch,
+                                   unsigned int *counts_host, void *stream)
 {
     using namespace r2;
-    if (P <= 0 || !xyz || !density || !scaling || !rotation || !grad_accum || !denom || !normals || !bbox_host || !scratch ||
-        !counts_host) {
+    if (P <= 0 || !xyz || !density || !scaling || !rotation || !max_radii2D || !grad_accum || !denom || !normals || !bbox_host ||
+        !scratch || !counts_host) {
         set_error("r2_densify_classify: invalid argument");
         return R2_ERR_INVALID;
     }
     hipStream_t s = (hipStream_t)stream;
-    const DensifyCfg c = make_cfg(grad_thr, scale_thr, density_min, bbox_host, scale_lo, scale_hi, do_densify);
+    const DensifyCfg c = make_cfg(grad_thr, scale_thr, density_min, bbox_host, scale_lo, scale_hi, do_densify, max_screen_size, max_scale);
     uint32_t *keep = reinterpret_cast<uint32_t *>(scratch), *pos = keep + 4 * (size_t)P;
     char *scan_temp = reinterpret_cast<char *>(pos + 4 * (size_t)P);
-    densify_classify_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, xyz, density, scaling, rotation, grad_accum, denom,
-                                                                       normals, c, keep);
+    densify_classify_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, xyz, density, scaling, rotation, max_radii2D, grad_accum,
+                                                                       denom, normals, c, keep);
     for (int a = 0; a < 4; ++a) {
         const int rc = inclusive_scan_u32(scan_temp, scan_temp_bytes(4 * P), keep + (size_t)a * P, pos + (size_t)a * P, P, s);
         if (rc) return rc;
@@ -235,7 +246,8 @@ extern "C" int r2_densify_classify(int P, const float *xyz, const float *density
 extern "C" int r2_densify_emit(int P, const float *const *params, const float *const *exp_avg, const float *const *exp_avg_sq,
                                const float *max_radii2D, const float *grad_accum, const float *denom, const float *normals,
                                float grad_thr, float scale_thr, float density_min, const float *bbox_host, float scale_lo,
-                               float scale_hi, int do_densify, const void *scratch, float *const *params_out,
+                               float scale_hi, int do_densify, float max_screen_size, float max_scale, const void *scratch,
+                               float *const *params_out,
                                float *const *exp_avg_out, float *const *exp_avg_sq_out, float *max_radii2D_out,
                                float *grad_accum_out, float *denom_out, void *stream)
 {
@@ -255,7 +267,7 @@ extern "C" int r2_densify_emit(int P, const float *const *params, const float *c
         }
     }
     r.max_radii = max_radii2D; r.max_radii_out = max_radii2D_out; r.grad_accum_out = grad_accum_out; r.denom_out = denom_out;
-    const DensifyCfg c = make_cfg(grad_thr, scale_thr, density_min, bbox_host, scale_lo, scale_hi, do_densify);
+    const DensifyCfg c = make_cfg(grad_thr, scale_thr, density_min, bbox_host, scale_lo, scale_hi, do_densify, max_screen_size, max_scale);
     const uint32_t *pos = reinterpret_cast<const uint32_t *>(scratch) + 4 * (size_t)P;
     densify_emit_kernel<<<dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(P, r, grad_accum, denom, normals, c, pos);
     R2_STAGE_CHECK(0, (hipStream_t)stream, "densify emit");

@@ -103,7 +103,8 @@ __device__ __host__ __forceinline__ uint32_t pidx(uint32_t d) { return d + (d >>
 // ---------------------------------------------------------------------------------------------------------- upsweep
 __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
                                                                 int phase, const uint32_t *__restrict__ skip,
-                                                                uint32_t *__restrict__ H, uint32_t *__restrict__ clear_skip)
+                                                                uint32_t *__restrict__ H, uint32_t *__restrict__ clear_skip,
+                                                                int ipt = RS_IPT /* rows of RS_THREADS keys per workgroup */)
 {
     __shared__ uint32_t hist[RS_MAX_RADIX];
     R2_TS(8);
@@ -113,11 +114,18 @@ __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uin
     for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) hist[d] = 0;
     if (clear_skip && blockIdx.x == 0 && threadIdx.x == 0) clear_skip[0] = 0u;   // single-pass sorts: spares a memset launch
     __syncthreads();
-    const uint32_t base = blockIdx.x * RS_TILE;
+    const uint32_t base = blockIdx.x * (uint32_t)(ipt * RS_THREADS);
+    if (ipt == RS_IPT) {
 #pragma unroll
-    for (int i = 0; i < RS_IPT; ++i) {
-        const uint32_t idx = base + (uint32_t)i * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & (radix - 1u)], 1u);
+        for (int i = 0; i < RS_IPT; ++i) {
+            const uint32_t idx = base + (uint32_t)i * RS_THREADS + threadIdx.x;
+            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & (radix - 1u)], 1u);
+        }
+    } else {
+        for (int i = 0; i < ipt; ++i) {
+            const uint32_t idx = base + (uint32_t)i * RS_THREADS + threadIdx.x;
+            if (idx < n) atomicAdd(&hist[(keys[idx] >> shift) & (radix - 1u)], 1u);
+        }
     }
     __syncthreads();
     uint32_t *__restrict__ row = H + (size_t)blockIdx.x * radix;
@@ -176,7 +184,10 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
 // from 8 XCDs into the same cache lines are the expensive part of a wide-digit pass; this cuts them by 3x.
 // INVV (last pass of a multi-pass sort whose value payload is the original index): write inv[value] = pos instead of
 // out[pos] = value -- the same number of scattered stores, but it replaces a separate permutation-inversion kernel.
-template <bool HAS_W, bool INV, bool INVV = false>
+// IPT: rows of 64 keys per wave, i.e. a workgroup sorts IPT * RS_THREADS consecutive keys.  The single-pass tile sort picks it so
+// that the workgroups fill the CUs in whole rounds (284 workgroups of 4096 keys on 256 CUs ran as long as 512 would: the CUs
+// hosting two of them finish last; 252 workgroups of 4608 keys are one round).
+template <bool HAS_W, bool INV, bool INVV = false, int IPT = RS_IPT>
 __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, uint32_t n, int shift, int bits, int pass,
                                                                   int phase, const uint32_t *__restrict__ skip,
                                                                   const uint32_t *__restrict__ H,
@@ -190,35 +201,45 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     uint32_t *digit_off = smem + RS_WAVES * prad;      // [prad] global position of this tile's first key of each digit
     __shared__ uint32_t wsum[RS_WAVES];
 
+    constexpr uint32_t TILE = (uint32_t)IPT * RS_THREADS;   // keys per workgroup
     R2_TS(0);
     if (skip[pass]) return;
-    // single-pass tile sort: the digit totals are the per-tile instance counts -- block 0 also turns them into the tile
-    // ranges and the render kernels' work list (one launch less on the forward's critical path)
-    if (INV && wo.ranges != nullptr && blockIdx.x == 0) ranges_and_work_block<RS_THREADS>(totals, wo);
+    // single-pass tile sort: the digit totals are the per-tile instance counts -- ONE EXTRA workgroup (the last) turns them
+    // into the tile ranges and the render kernels' work list (one launch less on the forward's critical path; as a
+    // prologue of workgroup 0 the 7 us job delayed that workgroup's own tile, which is the kernel's end once the
+    // workgroups run in a single round)
+    if (INV && wo.ranges != nullptr && blockIdx.x == gridDim.x - 1) {
+        ranges_and_work_block<RS_THREADS>(totals, wo);
+        return;
+    }
     R2_TS(1);
-    const int e = executed_before(skip, pass);
-    const int src = e == 0 ? 0 : target_of(e - 1, phase), dst = target_of(e, phase);
-    const uint32_t *__restrict__ kin = rd_k(buf, src);
-    const uint32_t *__restrict__ vin = rd_v(buf, src);
-    const uint32_t *__restrict__ win = rd_w(buf, src);
-    uint32_t *__restrict__ kout = wr_k(buf, dst);
-    uint32_t *__restrict__ vout = wr_v(buf, dst);
-    uint32_t *__restrict__ wout = wr_w(buf, dst);
+    // Buffer set of this pass.  Selecting among the three sets with a run-time index made the compiler copy the nine
+    // pointers to scratch (80 bytes per lane: a kernel with scratch pays ~4 us more at dispatch); the single-pass sort
+    // knows its sets at compile time, the general passes pick their pointers with scalar selects.
+    const int e = INV ? 0 : executed_before(skip, pass);
+    const int src = e == 0 ? 0 : target_of(e - 1, phase), dst = INV ? 2 : target_of(e, phase);
+    const bool s0 = src == 0, s1 = src == 1, d1 = dst == 1;
+    const uint32_t *__restrict__ kin = INV ? buf.k0 : (s0 ? buf.k0 : (s1 ? (const uint32_t *)buf.k1 : (const uint32_t *)buf.k2));
+    const uint32_t *__restrict__ vin = INV ? buf.v0 : (s0 ? buf.v0 : (s1 ? (const uint32_t *)buf.v1 : (const uint32_t *)buf.v2));
+    const uint32_t *__restrict__ win = INV ? buf.w0 : (s0 ? buf.w0 : (s1 ? (const uint32_t *)buf.w1 : (const uint32_t *)buf.w2));
+    uint32_t *__restrict__ kout = INV ? buf.k2 : (d1 ? buf.k1 : buf.k2);
+    uint32_t *__restrict__ vout = INV ? buf.v2 : (d1 ? buf.v1 : buf.v2);
+    uint32_t *__restrict__ wout = INV ? buf.w2 : (d1 ? buf.w1 : buf.w2);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t i = tid; i < RS_WAVES * prad; i += RS_THREADS) wave_hist[i] = 0;
     const uint32_t tile = blockIdx.x;
-    const uint32_t base = tile * RS_TILE + (uint32_t)wave * (64u * RS_IPT);
+    const uint32_t base = tile * TILE + (uint32_t)wave * (64u * IPT);
 
-    // ---- load the wave's 1024 consecutive keys (rows of 64), every load in flight before the first use
-    uint32_t key[RS_IPT], val[RS_IPT], wal[RS_IPT], rank[RS_IPT];
+    // ---- load the wave's 64 * IPT consecutive keys (rows of 64), every load in flight before the first use
+    uint32_t key[IPT], val[IPT], wal[IPT], rank[IPT];
 #pragma unroll
-    for (int i = 0; i < RS_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
         key[i] = idx < n ? kin[idx] : 0xFFFFFFFFu;
     }
 #pragma unroll
-    for (int i = 0; i < RS_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
         val[i] = (!INV && vin && idx < n) ? vin[idx] : idx;   // absent value array = identity (only ever the input set)
         wal[i] = (HAS_W && idx < n) ? win[idx] : 0u;
@@ -229,7 +250,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     uint32_t *wh = wave_hist + wave * prad;
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
-    for (int i = 0; i < RS_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
         const bool valid = idx < n;
         const uint32_t d = (key[i] >> shift) & (radix - 1u);
@@ -295,7 +316,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
     const bool regroup = !INV && bits <= 8;   // wave-uniform, radix <= 256 <= RS_THREADS: one digit per thread
     if (regroup) {
         uint32_t *tstart = digit_off + prad;              // [prad] first slot of each digit inside the regrouped tile
-        uint32_t *sK = tstart + prad, *sV = sK + RS_TILE, *sW = sV + RS_TILE;
+        uint32_t *sK = tstart + prad, *sV = sK + TILE, *sW = sV + TILE;
         uint32_t incl2 = mytot;
 #pragma unroll
         for (int s2 = 1; s2 < 64; s2 <<= 1) {
@@ -309,7 +330,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
         if ((uint32_t)tid < radix) tstart[pidx(tid)] = lstart;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < RS_IPT; ++i) {
+        for (int i = 0; i < IPT; ++i) {
             const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
             if (idx < n) {
                 const uint32_t d = (key[i] >> shift) & (radix - 1u);
@@ -320,9 +341,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
             }
         }
         __syncthreads();
-        const uint32_t tile_n = min((uint32_t)RS_TILE, n - tile * RS_TILE);
+        const uint32_t tile_n = min(TILE, n - tile * TILE);
 #pragma unroll
-        for (int i = 0; i < RS_IPT; ++i) {
+        for (int i = 0; i < IPT; ++i) {
             const uint32_t j = (uint32_t)i * RS_THREADS + (uint32_t)tid;
             if (j < tile_n) {
                 const uint32_t k = sK[j];
@@ -339,7 +360,7 @@ __global__ void __launch_bounds__(RS_THREADS) rs_downsweep_kernel(Buffers buf, u
 
     // ---- scatter
 #pragma unroll
-    for (int i = 0; i < RS_IPT; ++i) {
+    for (int i = 0; i < IPT; ++i) {
         const uint32_t idx = base + (uint32_t)i * 64u + (uint32_t)lane;
         if (idx < n) {
             const uint32_t d = (key[i] >> shift) & (radix - 1u);
@@ -472,15 +493,35 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
         set_error("sort_by_tile_single_pass: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
         return R2_ERR_INVALID;
     }
-    const uint32_t ntiles = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
+    // keys per workgroup: the sort's two big kernels run one workgroup per key tile and a CU hosts them one after the other in
+    // practice, so the kernel lasts ceil(tiles / CUs) rounds of a workgroup's life (~ its keys); pick the tile size with the
+    // least rounds x keys (1.16 M instances: 284 tiles of 4096 = two rounds, 252 tiles of 4608 = one)
+    const int cus = device_cu_count();
+    int ipt = RS_IPT;
+    {
+        static const int cand[] = { 8, 9, 10, 12 };
+        size_t best = ~(size_t)0;
+        for (int c : cand) {
+            const size_t tiles = (n + (size_t)c * RS_THREADS - 1) / ((size_t)c * RS_THREADS);
+            const size_t cost = ((tiles + (size_t)cus - 1) / (size_t)cus) * (size_t)c;
+            if (cost < best) { best = cost; ipt = c; }
+        }
+    }
+    const uint32_t ntiles = (uint32_t)((n + (size_t)ipt * RS_THREADS - 1) / ((size_t)ipt * RS_THREADS));
     const int bits = plan.bits[0], radix = 1 << bits, phase = 1;
     Buffers buf{tiles, nullptr, ids, nullptr, nullptr, nullptr, nullptr, nullptr, ids_out};
-    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.skip);
+    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.skip, ipt);
     rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
         t.H, ntiles, bits, (uint32_t)n, 0, 0, t.skip, t.totals);
     const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);
-    rs_downsweep_kernel<true, true><<<dim3(ntiles), dim3(RS_THREADS), lds, s>>>(
-        buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, work_out ? *work_out : WorkListOut{});
+    const WorkListOut wo = work_out ? *work_out : WorkListOut{};
+    const dim3 grid(ntiles + (wo.ranges ? 1u : 0u));   // + the workgroup that builds tile ranges and the work list
+    switch (ipt) {
+    case 9: rs_downsweep_kernel<true, true, false, 9><<<grid, dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, wo); break;
+    case 10: rs_downsweep_kernel<true, true, false, 10><<<grid, dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, wo); break;
+    case 12: rs_downsweep_kernel<true, true, false, 12><<<grid, dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, wo); break;
+    default: rs_downsweep_kernel<true, true, false, 8><<<grid, dim3(RS_THREADS), lds, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.totals, inv_out, wo); break;
+    }
     if (counts_out) *counts_out = t.totals;
     R2_HIP_TRY(hipGetLastError());
     return 0;

@@ -204,6 +204,10 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
     uint32_t *__restrict__ vals, const uint32_t *__restrict__ nvis)
 {
     R2_TS_AT(geom, 4);
+    // several views in this call?  Decided on the caller's counts, BEFORE P is trimmed to the visible prefix: a batched call
+    // whose visible count happened to equal the per-view Gaussian count would otherwise be taken for a single view and every
+    // instance would get view 0's tile rows
+    const bool multi_view = Pview != P;
     if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -252,7 +256,7 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
             const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
             const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
             // the views' tile grids are stacked: view v = o_id / Pview owns tile rows [v * gy, (v + 1) * gy)
-            const int vrow = Pview == P ? 0 : (int)(o_id / (uint32_t)Pview) * gy;
+            const int vrow = multi_view ? (int)(o_id / (uint32_t)Pview) * gy : 0;
             tiles[k] = (uint32_t)((vrow + ty) * gx + tx);
             vals[k] = o_id;
         }

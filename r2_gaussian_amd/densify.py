@@ -40,10 +40,13 @@ def _ptrs(ts):
 
 
 def densify_and_prune(params, moments, max_radii2D, grad_accum, denom, normals, grad_threshold, scale_threshold, density_min,
-                      bbox, scale_bound=None, do_densify=True):
+                      bbox, scale_bound=None, do_densify=True, max_screen_size=None, max_scale=None):
     """params: dict name -> raw parameter tensor ([P,3], [P,1], [P,3], [P,4]); moments: dict name -> (exp_avg, exp_avg_sq) or
     None; normals: [2,P,3] N(0,1).  -> (new_params, new_moments, new_max_radii2D, new_grad_accum, new_denom, counts) with
-    rows ordered like the reference's result; counts = surviving (originals, clones, first children, second children)."""
+    rows ordered like the reference's result; counts = surviving (originals, clones, first children, second children).
+    max_screen_size / max_scale: the reference's optional prune thresholds (gaussian_model.py:540-545; None / 0 = off):
+    rows whose max_radii2D exceeds the first or whose largest activated scale exceeds the second are pruned -- children of a
+    split inherit the parent's max_radii2D and get its scale / 1.6.  Raises ValueError when nothing survives (train.py:169-172)."""
     xyz = params["xyz"]
     _require_gpu(xyz, "xyz")
     dev, P = xyz.device, xyz.shape[0]
@@ -59,13 +62,16 @@ def densify_and_prune(params, moments, max_radii2D, grad_accum, denom, normals, 
     box = (C.c_float * 6)(*[float(v) for v in torch.as_tensor(bbox).reshape(-1).tolist()])
     scratch = torch.empty(L.r2_densify_scratch_bytes(P), dtype=torch.uint8, device=dev)
     counts = (C.c_uint * 4)()
-    common = (float(grad_threshold), float(scale_threshold), float(density_min), box, lo, hi, int(bool(do_densify)))
+    common = (float(grad_threshold), float(scale_threshold), float(density_min), box, lo, hi, int(bool(do_densify)),
+              float(max_screen_size or 0.0), float(max_scale or 0.0))
     with _on_device(dev):
-        rc = L.r2_densify_classify(P, ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), ga.data_ptr(),
-                                   dn.data_ptr(), nrm.data_ptr(), *common, scratch.data_ptr(), counts, _stream(dev))
+        rc = L.r2_densify_classify(P, ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(), ps[3].data_ptr(), mr.data_ptr(),
+                                   ga.data_ptr(), dn.data_ptr(), nrm.data_ptr(), *common, scratch.data_ptr(), counts, _stream(dev))
         _lib.check(rc, "r2_densify_classify")
         cnt = tuple(int(c) for c in counts)
         Pn = sum(cnt)
+        if Pn == 0:
+            raise ValueError("No Gaussian left. Change adaptive control hyperparameters!")   # train.py:169-172
         widths = (3, 1, 3, 4)
         po = [torch.empty((Pn, w), dtype=_F32, device=dev) for w in widths]
         mo = [torch.empty((Pn, w), dtype=_F32, device=dev) if have_m else None for w in widths]
@@ -82,7 +88,7 @@ def densify_and_prune(params, moments, max_radii2D, grad_accum, denom, normals, 
 
 
 def densify_and_prune_optimizer(optimizer, max_radii2D, grad_accum, denom, normals, grad_threshold, scale_threshold,
-                                density_min, bbox, scale_bound=None, do_densify=True):
+                                density_min, bbox, scale_bound=None, do_densify=True, max_screen_size=None, max_scale=None):
     """The same on a ``torch.optim.Adam`` with parameter groups named xyz / density / scaling / rotation (one tensor each):
     parameters and ``exp_avg`` / ``exp_avg_sq`` are replaced like cat_tensors_to_optimizer / _prune_optimizer do
     (gaussian_model.py:335-403).  -> (dict name -> new parameter, new max_radii2D, new grad_accum [P,1], new denom [P,1])."""
@@ -92,7 +98,8 @@ def densify_and_prune_optimizer(optimizer, max_radii2D, grad_accum, denom, norma
     moments = {n: (states[n]["exp_avg"], states[n]["exp_avg_sq"]) for n in NAMES} if all(
         s is not None and "exp_avg" in s for s in states.values()) else None
     new_p, new_m, mr, ga, dn, _cnt = densify_and_prune(params, moments, max_radii2D, grad_accum, denom, normals, grad_threshold,
-                                                       scale_threshold, density_min, bbox, scale_bound, do_densify)
+                                                       scale_threshold, density_min, bbox, scale_bound, do_densify,
+                                                       max_screen_size, max_scale)
     out = {}
     for n in NAMES:
         old = params[n]

@@ -64,17 +64,18 @@ class StreamPool:
             slot, done = [None, None], threading.Event()
             self._q[k % self.n].put((fn, (k, it), slot, done))
             jobs.append((slot, done))
-        out = []
-        for slot, done in jobs:
+        # every job is waited for and the caller's stream is ordered after the workers' BEFORE a failure is re-raised: no
+        # worker may still be enqueueing or running on shared parameter storage when the caller carries on
+        for _slot, done in jobs:
             done.wait()
-            if slot[1] is not None:
-                raise slot[1]
-            out.append(slot[0])
         for s in self.streams:
             ev = torch.cuda.Event()
             ev.record(s)
             cur.wait_event(ev)
-        return out
+        for slot, _done in jobs:
+            if slot[1] is not None:
+                raise slot[1]
+        return [slot[0] for slot, _done in jobs]
 
     @staticmethod
     def leaves_like(params):

@@ -43,6 +43,10 @@ int main(int argc, char **argv)
 {
     const int steps = argc > 1 ? atoi(argv[1]) : 200;
     const std::string libpath = argc > 2 ? argv[2] : "r2_gaussian_amd/libr2hip.so";
+    // sections to run (argv[3], comma separated; default all): single,streams,stages,batch,sbatch,voxel -- a profiler pass over
+    // "single" alone attributes every kernel row to the single-view step
+    const std::string sections = argc > 3 ? std::string(",") + argv[3] + "," : "";
+    auto want = [&](const char *name) { return sections.empty() || sections.find(std::string(",") + name + ",") != std::string::npos; };
     void *h = dlopen(libpath.c_str(), RTLD_NOW | RTLD_LOCAL);
     if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 1; }
     auto fwd = sym<decltype(&r2_raster_forward)>(h, "r2_raster_forward");
@@ -107,7 +111,7 @@ int main(int argc, char **argv)
     for (int k = 0; k < 20; ++k) step(k);
     CHECK(hipStreamSynchronize(s));
     double best = 1e30;
-    for (int rep = 0; rep < 3; ++rep) {
+    for (int rep = 0; want("single") && rep < 3; ++rep) {
         Rsum = 0;
         wait_stats(nullptr, nullptr, 1);
         const auto t0 = std::chrono::steady_clock::now();
@@ -121,12 +125,13 @@ int main(int argc, char **argv)
                Rsum / steps, wus / steps);
         if (dt < best) best = dt;
     }
-    printf("BEST %.1f views/s  %.2f us/step\n", steps / best, 1e6 * best / steps);
+    if (want("single")) printf("BEST %.1f views/s  %.2f us/step\n", steps / best, 1e6 * best / steps);
 
     // independent views in flight on several streams, one host thread each (the library's state is per host thread): the
     // launch- and latency-bound binning chain of one view overlaps the render kernels of another.  What a trainer that
     // accumulates the gradients of several views per optimiser step can do without the batched entry point.
     for (int nth : {2, 3}) {
+        if (!want("streams")) break;
         struct Ctx { float *out, *grads; int *radii; Slot slots[3]; hipStream_t s; };
         std::vector<Ctx> ctx(nth);
         for (auto &c : ctx) {
@@ -189,6 +194,7 @@ int main(int argc, char **argv)
     const int ns = prof_count();
     std::vector<double> ms(ns);
     std::vector<long long> cnt(ns);
+    if (want("stages")) {
     prof_enable(~0ull);
     for (int k = 0; k < 50; ++k) step(20 + k);
     CHECK(hipStreamSynchronize(s));
@@ -201,6 +207,7 @@ int main(int argc, char **argv)
         }
     printf("  %-20s %8.2f us\n", "raster stage sum", sum);
     prof_enable(0);
+    }
 
     // experiment builds (-DR2_EXP_TS) stamp s_memrealtime at phase boundaries inside selected kernels: one [phase][block]
     // table per translation unit; printed as one timeline of the last step (us since the earliest stamp)
@@ -239,7 +246,7 @@ int main(int argc, char **argv)
     }
 
     // batched views (r2_raster_forward_batch / _backward_batch; absent from older builds of the library): BV views per call
-    if (void *pf = dlsym(h, "r2_raster_forward_batch")) {
+    if (void *pf = want("batch") ? dlsym(h, "r2_raster_forward_batch") : nullptr) {
         auto bfwd = reinterpret_cast<decltype(&r2_raster_forward_batch)>(pf);
         auto bbwd = sym<decltype(&r2_raster_backward_batch)>(h, "r2_raster_backward_batch");
         for (int BV : {2, 4, 8}) {
@@ -299,7 +306,7 @@ int main(int argc, char **argv)
     }
 
     // both: two host threads / streams, each pushing BATCHES of BV views through the batched entry points
-    if (void *pf2 = dlsym(h, "r2_raster_forward_batch")) {
+    if (void *pf2 = want("sbatch") ? dlsym(h, "r2_raster_forward_batch") : nullptr) {
         auto bfwd = reinterpret_cast<decltype(&r2_raster_forward_batch)>(pf2);
         auto bbwd = sym<decltype(&r2_raster_backward_batch)>(h, "r2_raster_backward_batch");
         float *bvm, *bpm;
@@ -371,6 +378,7 @@ int main(int argc, char **argv)
         (void)hipFree(bvm); (void)hipFree(bpm);
     }
 
+    if (!want("voxel")) return 0;
     // voxelizer: the full 256^3 query
     auto vox = [&]() {
         const int R3 = vfwd(grow, &slots[0], grow, &slots[1], grow, &slots[2], P, 256, 256, 256, 2.f, 2.f, 2.f, 0.f, 0.f, 0.f, means,

@@ -43,6 +43,7 @@ class Opt:
     densification_interval, densify_from_iter, densify_until_iter = 100, 500, 15000
     densify_grad_threshold, densify_scale_threshold = 5.0e-5, 0.1
     max_num_gaussians = 500000
+    max_screen_size, max_scale = None, None      # optional prune thresholds (arguments/__init__.py:67-68); max_scale in % of volume
     scale_min, scale_max = 0.0005, 0.5
 
     def __init__(self, **kw):
@@ -212,6 +213,29 @@ class Model:
                                           lr=0.0, eps=1e-15)
         self._reset_stats()
 
+    @classmethod
+    def from_tensors(cls, opt, backend, raw, moments=None, steps=None, max_radii2D=None, grad_accum=None, denom=None, gen=None):
+        """A model around given raw parameters / Adam state (tests: the reference's fixtures, tests/golden/train/)."""
+        m = cls.__new__(cls)
+        m.opt, m.be, m.gen = opt, backend, gen
+        dev = backend.device
+        m.lo, m.hi = opt.scale_min * 2.0, opt.scale_max * 2.0
+        m.p = {n: raw[n].to(dev).clone().requires_grad_(True) for n in cls.NAMES}
+        m.lr = {"xyz": expon_lr(opt.position_lr_init, opt.position_lr_final, opt.lr_max_steps),
+                "density": expon_lr(opt.density_lr_init, opt.density_lr_final, opt.lr_max_steps),
+                "scaling": expon_lr(opt.scaling_lr_init, opt.scaling_lr_final, opt.lr_max_steps),
+                "rotation": expon_lr(opt.rotation_lr_init, opt.rotation_lr_final, opt.lr_max_steps)}
+        m.optimizer = torch.optim.Adam([{"params": [m.p[n]], "lr": m.lr[n](0), "name": n} for n in cls.NAMES], lr=0.0, eps=1e-15)
+        if moments is not None:
+            for n in cls.NAMES:
+                m.optimizer.state[m.p[n]] = {"step": torch.as_tensor(steps[n] if steps is not None else 1.0),
+                                             "exp_avg": moments[n][0].to(dev).clone(), "exp_avg_sq": moments[n][1].to(dev).clone()}
+        P = m.p["xyz"].shape[0]
+        m.max_radii2D = max_radii2D.to(dev).clone() if max_radii2D is not None else torch.zeros(P, device=dev)
+        m.grad_accum = grad_accum.to(dev).clone() if grad_accum is not None else torch.zeros((P, 1), device=dev)
+        m.denom = denom.to(dev).clone() if denom is not None else torch.zeros((P, 1), device=dev)
+        return m
+
     # activations (gaussian_model.py:38-64)
     @staticmethod
     def inv_softplus(x):
@@ -292,13 +316,14 @@ class Model:
         new_p, self.max_radii2D, self.grad_accum, self.denom = D.densify_and_prune_optimizer(
             self.optimizer, self.max_radii2D, self.grad_accum, self.denom, normals_full, opt.densify_grad_threshold,
             opt.densify_scale_threshold * 2.0, opt.density_min_threshold, bbox, (self.lo, self.hi),
-            do_densify=self.P < opt.max_num_gaussians)
+            do_densify=self.P < opt.max_num_gaussians, max_screen_size=opt.max_screen_size,
+            max_scale=opt.max_scale * 2.0 if opt.max_scale else None)
         self.p = dict(new_p)
 
     @torch.no_grad()
     def densify_and_prune(self, bbox, normals_full=None):
-        """gaussian_model.py:503-550 with max_screen_size = max_scale = None (the defaults).  normals_full ([2,P,3], test
-        hook): the split samples of parent i are normals_full[:, i] instead of fresh draws."""
+        """gaussian_model.py:503-550.  normals_full ([2,P,3], test hook): the split samples of parent i are normals_full[:, i]
+        instead of fresh draws."""
         opt = self.opt
         thr_scale = opt.densify_scale_threshold * 2.0
         grads = self.grad_accum / self.denom
@@ -337,9 +362,13 @@ class Model:
             self.max_radii2D = torch.cat([self.max_radii2D, new_r])
             keep = ~torch.cat([sel, torch.zeros(2 * int(sel.sum()), dtype=torch.bool, device=sel.device)])
             self._keep(keep)
-        xyz, dens, _s, _r = self.activated()
+        xyz, dens, scal, _r = self.activated()
         b = bbox.to(xyz.device)
         prune = (dens < opt.density_min_threshold).squeeze(-1) | ((xyz < b[0]) | (xyz > b[1])).any(dim=1)
+        if opt.max_screen_size:                                  # gaussian_model.py:540-542
+            prune = prune | (self.max_radii2D > opt.max_screen_size)
+        if opt.max_scale:                                        # :543-545, threshold x volume_to_world (train.py:53)
+            prune = prune | (scal.max(dim=1).values > opt.max_scale * 2.0)
         self._keep(~prune)
 
 

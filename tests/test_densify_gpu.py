@@ -109,3 +109,31 @@ def test_trainer_with_fused_densify_follows_the_torch_version(gpu):
     assert a["iters"] == b["iters"]
     assert max(abs(x - y) for x, y in zip(a["psnr"], b["psnr"])) < 0.15      # different split samples: not the same run
     assert abs(a["P"][-1] - b["P"][-1]) <= 0.1 * a["P"][-1] and b["P"][-1] > 1500
+
+
+# ---- against the reference's own GaussianModel.densify_and_prune (tests/golden/train/densify_*.npz, make_golden_train.py):
+# A default thresholds, B max_screen_size + max_scale set, C prune only (max_num_gaussians reached)
+@pytest.mark.parametrize("case", ["A", "B", "C"])
+def test_fused_densify_and_prune_matches_the_reference_fixture(case, gpu):
+    import os
+    from tests.test_train_golden_cpu import compare_with_fixture, model_from_fixture, snapshot
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train", "densify_%s.npz" % case))
+    m = model_from_fixture(g, T.Backend("hip"))
+    P0 = m.P
+    m.densify_and_prune_fused(torch.from_numpy(g["bbox"]), normals_full=torch.from_numpy(g["normals"]))
+    torch.cuda.synchronize()
+    assert m.P == g["out.xyz"].shape[0] and m.P != P0
+    compare_with_fixture(snapshot(m), g, exact=True)
+    for n in m.NAMES:   # the optimizer still steps on the new parameters
+        m.p[n].grad = torch.ones_like(m.p[n])
+    m.optimizer.step()
+
+
+def test_nothing_left_raises_like_the_reference(gpu):
+    import os
+    from tests.test_train_golden_cpu import model_from_fixture
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train", "densify_C.npz"))
+    m = model_from_fixture(g, T.Backend("hip"))
+    m.opt.density_min_threshold = 1e9            # everything is pruned: train.py:169-172 raises
+    with pytest.raises(ValueError, match="No Gaussian left"):
+        m.densify_and_prune_fused(torch.from_numpy(g["bbox"]))

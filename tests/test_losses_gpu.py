@@ -58,3 +58,32 @@ def test_trainer_with_fused_losses_follows_the_torch_losses(gpu):
     assert a["iters"] == b["iters"]
     assert max(abs(x - y) for x, y in zip(a["psnr"], b["psnr"])) < 0.05
     assert b["psnr"][-1] > b["psnr"][0] + 1.0
+
+
+# ---- against the reference's own Python (tests/golden/train/losses.npz, written by loss_utils.py itself: make_golden_train.py)
+def test_fused_losses_match_the_reference_fixtures(gpu):
+    import os
+    from r2_gaussian_amd.losses import image_loss, tv_3d_loss
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "train", "losses.npz"))
+    lam = 0.25
+    for i in range(3):
+        img = torch.from_numpy(g["img%d" % i]).to(gpu).requires_grad_(True)
+        gt = torch.from_numpy(g["gt%d" % i]).to(gpu)
+        loss, parts = image_loss(img, gt, lam)
+        loss.backward()
+        torch.cuda.synchronize()
+        l1, ssim = float(g["l1_%d" % i]), float(g["ssim_%d" % i])
+        assert abs(float(parts[0]) - l1) <= 1e-6 * abs(l1) + 1e-8
+        assert abs(float(parts[1]) - ssim) <= 2e-6
+        assert abs(float(loss) - (l1 + lam * (1.0 - ssim))) <= 2e-6
+        want = g["l1_grad%d" % i] - lam * g["ssim_grad%d" % i]       # d/dimg of L1 + lam (1 - SSIM)
+        got = img.grad.cpu().numpy()
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
+    for i in range(2):
+        vol = torch.from_numpy(g["vol%d" % i]).to(gpu).requires_grad_(True)
+        tv = tv_3d_loss(vol)
+        tv.backward()
+        torch.cuda.synchronize()
+        assert abs(float(tv) - float(g["tv_%d" % i])) <= 2e-6 * float(g["tv_%d" % i])
+        want = g["tv_grad%d" % i]
+        assert np.abs(vol.grad.cpu().numpy() - want).max() <= 1e-6 * np.abs(want).max() + 1e-12

@@ -50,3 +50,53 @@ def test_pool_equals_serial(gpu):
                 assert float((a - b).abs().max()) <= 1e-6 * scale   # same addends, different association of the sum over views
         with pytest.raises(ZeroDivisionError):
             pool.map(lambda k, _v: 1 // 0, [0])
+
+
+def test_a_failed_job_is_raised_only_after_every_worker_has_finished(gpu):
+    """map() must not hand control back while other workers still run on shared storage."""
+    import time
+    done = []
+
+    def job(k, _item):
+        if k == 0:
+            raise ValueError("first job fails at once")
+        time.sleep(0.2)
+        done.append(k)
+        return k
+
+    with StreamPool(2, gpu) as pool:
+        with pytest.raises(ValueError):
+            pool.map(job, range(4))
+        assert sorted(done) == [1, 2, 3]          # the slower jobs completed before the exception surfaced
+
+
+def test_ctypes_boundary_keeps_the_state_buffers_of_concurrent_threads_apart(gpu, monkeypatch):
+    """Without the compiled boundary the allocation callbacks are Python functions shared per device; with several host
+    threads inside a forward at once (ctypes releases the GIL) each must fill ITS call's state."""
+    monkeypatch.setattr(_C, "_SHIM", None)          # force the ctypes boundary for this test
+    monkeypatch.setattr(_C, "_SHIM_TRIED", True)
+    assert _C._shim() is None
+    c = S.make_cloud(30000, seed=7)
+    views = S.make_views(4, (96, 96))
+    params = [t.to(gpu) for t in (c.xyz, c.density, c.scales, c.rotations)]
+    rast = [GaussianRasterizer(GaussianRasterizationSettings(
+        image_height=96, image_width=96, tanfovx=v.tanfovx, tanfovy=v.tanfovy, scale_modifier=1.0,
+        viewmatrix=v.world_view_transform.to(gpu), projmatrix=v.full_proj_transform.to(gpu), campos=v.camera_center.to(gpu),
+        prefiltered=False, mode=v.mode, debug=False)) for v in views]
+    dL = S.make_pixel_grad(96, 96).to(gpu)
+
+    def one(k, leaves):
+        m2d = torch.zeros(30000, 3, device=gpu, requires_grad=True)
+        img, _radii = rast[k](leaves[0], m2d, leaves[1], leaves[2], leaves[3])
+        img.backward(dL)
+        return img.detach()
+
+    ser = [one(k, StreamPool.leaves_like(params)) for k in range(len(views))]
+    torch.cuda.synchronize()
+    with StreamPool(2, gpu) as pool:
+        leaves = [pool.leaves_like(params) for _ in range(pool.n)]
+        for _rep in range(5):
+            out = pool.map(lambda k, _v: one(k, leaves[k % pool.n]), views)
+            torch.cuda.synchronize()
+            for a, b in zip(ser, out):
+                assert torch.equal(a, b)
