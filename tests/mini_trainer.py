@@ -405,10 +405,17 @@ def psnr3d(case, model):
         return S.psnr3d(case.vol_gt, vol.detach().cpu())
 
 
-def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False, fused_densify=False):
+def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False, fused_densify=False, views_per_step=1,
+          data_parallel=False, return_model=False):
     """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177.
     fused_losses (hip backend): the loss stack through r2_gaussian_amd.losses (one autograd node each) instead of torch ops.
-    fused_densify (hip backend): densification statistics + densify / prune through r2_gaussian_amd.densify."""
+    fused_densify (hip backend): densification statistics + densify / prune through r2_gaussian_amd.densify.
+    views_per_step = W > 1: W views per optimiser step, gradients averaged -- rendered one after the other by this process, or
+    with data_parallel (torch.distributed initialised, world size W) ONE per rank with r2_gaussian_amd.dist doing the exchange:
+    one all-reduce of the parameter gradients, sum / max reductions of the densification statistics.  Both
+    orders of evaluation draw the same random stream (view order, TV centre, split samples), so every rank and the
+    single-process run hold the same model."""
+    from r2_gaussian_amd import dist as D
     be = Backend(backend_name)
     gen = torch.Generator().manual_seed(seed)          # TV centres, split samples
     pyrng = random.Random(seed)                        # view order (train.py:104-106)
@@ -417,46 +424,76 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
     gts = [p.to(dev) for p in case.projs]
     tvN = torch.tensor([opt.tv_vol_size] * 3)
     tvS = case.dVoxel * tvN
+    W = int(views_per_step)
+    if data_parallel:
+        assert D.world() == W, (D.world(), W)
     out = {"iters": [0], "psnr": [psnr3d(case, model)], "P": [model.P], "backend": backend_name}
     stack = []
     t_train = 0.0
     for it in range(1, opt.iterations + 1):
         t0 = time.perf_counter()
         model.update_lr(it)
-        if not stack:
-            stack = list(range(len(case.views)))
-        vi = stack.pop(pyrng.randint(0, len(stack) - 1))
-        x, d, s, r = model.activated()
-        pkg = be.render(case.views[vi], x, d, s, r)
-        img = pkg["render"]
-        if fused_losses:
-            from r2_gaussian_amd import losses as FL
-            loss, _parts = FL.image_loss(img, gts[vi], opt.lambda_dssim)
-        else:
-            loss = (img - gts[vi]).abs().mean()
-            if opt.lambda_dssim > 0:
-                loss = loss + opt.lambda_dssim * (1.0 - ssim(img, gts[vi]))
-        if opt.lambda_tv > 0:
+        step_views = []
+        for _ in range(W):
+            if not stack:
+                stack = list(range(len(case.views)))
+            step_views.append(stack.pop(pyrng.randint(0, len(stack) - 1)))
+        mine = [step_views[D.rank()]] if data_parallel else step_views
+        c = None
+        if opt.lambda_tv > 0:   # one TV patch per optimiser step: the same centre for all of the step's views / ranks
             c = (case.bbox[0] + tvS / 2) + (case.bbox[1] - tvS - case.bbox[0]) * torch.rand(3, generator=gen)
-            vol = be.query(x, d, s, r, c, tvN, tvS)
-            loss = loss + opt.lambda_tv * (FL.tv_3d_loss(vol) if fused_losses else tv3d_mean(vol))
-        loss.backward()
-        with torch.no_grad():
-            if fused_densify:
-                from r2_gaussian_amd import densify as FD
-                FD.densification_stats(pkg["radii"], pkg["viewspace_points"].grad, model.max_radii2D, model.grad_accum,
-                                       model.denom)
+        inc_gn = inc_dn = rad_max = None
+        for vi in mine:
+            x, d, s, r = model.activated()
+            pkg = be.render(case.views[vi], x, d, s, r)
+            img = pkg["render"]
+            if fused_losses:
+                from r2_gaussian_amd import losses as FL
+                loss, _parts = FL.image_loss(img, gts[vi], opt.lambda_dssim)
             else:
-                vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
-                model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
-                g2 = pkg["viewspace_points"].grad
-                model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
-                model.denom[vis] += 1
+                loss = (img - gts[vi]).abs().mean()
+                if opt.lambda_dssim > 0:
+                    loss = loss + opt.lambda_dssim * (1.0 - ssim(img, gts[vi]))
+            if c is not None:
+                vol = be.query(x, d, s, r, c, tvN, tvS)
+                loss = loss + opt.lambda_tv * (FL.tv_3d_loss(vol) if fused_losses else tv3d_mean(vol))
+            loss.backward()   # a step's views accumulate into .grad
+            with torch.no_grad():
+                if W == 1 and fused_densify:
+                    from r2_gaussian_amd import densify as FD
+                    FD.densification_stats(pkg["radii"], pkg["viewspace_points"].grad, model.max_radii2D, model.grad_accum,
+                                           model.denom)
+                elif W == 1:
+                    vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev)
+                    model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
+                    g2 = pkg["viewspace_points"].grad
+                    model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
+                    model.denom[vis] += 1
+                else:   # the step's statistics increments (train.py:151-154 per view), reduced over ranks below
+                    vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev).float()
+                    gn = torch.where(vis, pkg["viewspace_points"].grad[:, :2].norm(dim=-1), torch.zeros((), device=dev))
+                    inc_gn = gn if inc_gn is None else inc_gn + gn
+                    inc_dn = vis.float() if inc_dn is None else inc_dn + vis.float()
+                    rad_max = radii if rad_max is None else torch.max(rad_max, radii)
+        with torch.no_grad():
+            if W > 1:
+                params = [model.p[n] for n in model.NAMES]
+                if data_parallel:
+                    D.allreduce_param_grads(params, average=False)      # ONE all-reduce of the [P,11] gradient block
+                    inc_gn, inc_dn, rad_max = D.allreduce_densify_stats(inc_gn, inc_dn, rad_max)
+                for p_ in params:
+                    p_.grad.div_(W)
+                model.max_radii2D = torch.max(model.max_radii2D, rad_max)
+                model.grad_accum += inc_gn[:, None]
+                model.denom += inc_dn[:, None]
             if it < opt.densify_until_iter and it > opt.densify_from_iter and it % opt.densification_interval == 0:
                 if fused_densify:
                     model.densify_and_prune_fused(case.bbox)
                 else:
                     model.densify_and_prune(case.bbox)
+                if data_parallel:   # every rank took the same decisions (SURVEY.md 8e "consistency")
+                    for n in model.NAMES:
+                        D.assert_replicas_equal(model.p[n].detach(), n)
             if model.P == 0:
                 raise ValueError("No Gaussian left")
             if it < opt.iterations:
@@ -473,4 +510,6 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
                 log("it %5d  P %6d  psnr3d %.3f dB  loss %.4e  (%.1f it/s)" % (it, model.P, out["psnr"][-1], float(loss.detach()),
                                                                               it / t_train))
     out["it_per_s"] = opt.iterations / t_train
+    if return_model:
+        out["model"] = model
     return out

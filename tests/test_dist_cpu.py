@@ -230,3 +230,76 @@ def test_bench_step_runner_sync_and_overlap_order():
     assert log == [("render", 0, 0)]
     s = bench.summarize([0.010, 0.012, 0.011], 10, 2)
     assert s["value"] == round(10 * 2 / 0.011, 2) and s["ms_per_step"] == 1.1 and s["regions"] == 3
+
+
+# ------------------------------------------------------------------------------------------------ data-parallel trainer
+# SURVEY.md 8(e) "consistency": the whole training loop (tests/mini_trainer.py: render, L1 + DSSIM + TV, Adam, densify / prune)
+# run view-sharded over 2 ranks with the ORACLE backend -- one view per rank and step, ONE all-reduce of the [P,11] gradient
+# block, sum / max reductions of the densification statistics (r2_gaussian_amd.dist) -- must leave bit-identical models on both
+# ranks after several densification rounds, identical to a single process that renders the same two views per step.
+def _dp_case_and_opt():
+    from tests import mini_trainer as T
+    case = T.Case(detector=32, n_vol=16, n_views=8, p_gt=600, n_init=400, seed=2)
+    opt = T.Opt(iterations=120, densify_from_iter=20, densify_until_iter=110, densification_interval=30, tv_vol_size=8,
+                densify_grad_threshold=2.0e-5, densify_scale_threshold=0.02)
+    return case, opt
+
+
+def _model_signature(model):
+    import hashlib
+    h = hashlib.sha256()
+    for n in model.NAMES:
+        h.update(model.p[n].detach().cpu().numpy().tobytes())
+        st = model.optimizer.state[model.p[n]]
+        h.update(st["exp_avg"].cpu().numpy().tobytes())
+        h.update(st["exp_avg_sq"].cpu().numpy().tobytes())
+    h.update(model.max_radii2D.cpu().numpy().tobytes())
+    return model.P, h.hexdigest()
+
+
+def _dp_train_worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.set_num_threads(2)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from tests import mini_trainer as T
+        case, opt = _dp_case_and_opt()
+        out = T.train(case, opt, "oracle", eval_every=60, seed=0, views_per_step=world, data_parallel=True, return_model=True)
+        sig = _model_signature(out["model"])
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok", sig, out["P"], out["psnr"]))
+    except Exception as e:
+        import traceback
+        q.put((rank, "FAIL %r\n%s" % (e, traceback.format_exc()), None, None, None))
+
+
+@pytest.mark.timeout(600)
+def test_data_parallel_trainer_world2_equals_single_process():
+    from tests import mini_trainer as T
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_train_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    # meanwhile: the single process that renders both views of every step itself (with the workers' thread count: the
+    # oracle's float accumulation -- like the reference's atomics -- associates by OpenMP thread, torch.set_num_threads sets it)
+    case, opt = _dp_case_and_opt()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        ref = T.train(case, opt, "oracle", eval_every=60, seed=0, views_per_step=world, return_model=True)
+    finally:
+        torch.set_num_threads(nthreads)
+    ref_sig = _model_signature(ref["model"])
+    res = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[0][2] == res[1][2], "the two ranks hold different models"
+    assert len(set(ref["P"])) >= 3, ref["P"]                       # the run went through densification rounds that changed P
+    assert res[0][3] == ref["P"] and res[0][2] == ref_sig, (res[0][3], ref["P"])   # bit-identical to the single-process run
+    assert res[0][4] == ref["psnr"]
