@@ -158,7 +158,14 @@ def main():
     ap.add_argument("--views", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-voxel", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batched-views section")
+    ap.add_argument("--no-streams", action="store_true", help="skip the concurrent-streams section")
+    ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only section")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="the single-view step and nothing else (profiler passes: every kernel row is the headline step)")
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_voxel = args.no_batched = args.no_streams = args.no_forward_only = args.no_cpu_baseline = True
     repeats = args.repeats or (5 if args.steps >= 500 else 25)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -286,16 +293,24 @@ def main():
         pre = _lib.profile_read(reset=True)
         if pre:
             DOMINANT = max(pre.items(), key=lambda kv: kv[1][0] / max(kv[1][1], 1))[0]
-        _lib.profile_enable([DOMINANT])
+        _lib.profile_enable([])
         _lib.sync_wait_stats(reset=True)
 
-    # ---- the measurement
+    # ---- the measurement: NO instrumentation inside these regions
     region_s, k = timed_regions(sync_runner, args.steps, repeats, k, barrier, max_over_ranks)
     dom, wait_us, wait_n = (0.0, 0), 0.0, 0
+    dom_regions = None
     if not stub:
         wait_us, wait_n = _lib.sync_wait_stats(reset=True)
+        # ---- the dominant kernel's launches, bracketed by HIP events on the launch stream, in regions of the same shape that
+        # follow immediately (same steps, same barriers; their wall time is reported next to the un-instrumented one so that
+        # the two measurements can be told apart -- round 2 bracketed the kernel inside the regions that produced `value`)
+        _lib.profile_read(reset=True)
+        _lib.profile_enable([DOMINANT])
+        dom_s, k = timed_regions(sync_runner, args.steps, min(repeats, 5), k, barrier, max_over_ranks)
         dom = _lib.profile_read(reset=True).get(DOMINANT, (0.0, 0))
         _lib.profile_enable([])
+        dom_regions = summarize(dom_s, args.steps, world)
     main_t = summarize(region_s, args.steps, world)
     overlapped = None
     if use_comm:   # the pipelined mode, labelled as such, next to the synchronous number
@@ -325,11 +340,11 @@ def main():
     # ---- forward-only views/s, same views, no autograd
     fwd_only = None
     with torch.no_grad():
-        for j in range(10):
+        for j in range(0 if args.no_forward_only else 10):
             rasterizers[j % len(views)](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
         fr = []
         nf = max(20, min(args.steps, 200))
-        for _ in range(5):
+        for _ in range(0 if args.no_forward_only else 5):
             barrier()
             t0 = time.perf_counter()
             for j in range(nf):
@@ -337,13 +352,13 @@ def main():
                 rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
             barrier()
             fr.append(max_over_ranks(time.perf_counter() - t0))
-        fwd_only = summarize(fr, nf, world)
+        fwd_only = summarize(fr, nf, world) if fr else None
 
     # ---- batched views (new functionality, reported NEXT TO the per-view drop-in number, never instead of it): BV views of
     # the same Gaussians per call through r2_raster_forward_batch / _backward_batch -- what a trainer that accumulates
     # several views per optimiser step calls.  Same views, same upstream gradient, forward + backward.
     batched = None
-    if rank == 0 or world > 1:
+    if (rank == 0 or world > 1) and not args.no_batched:
         from r2_gaussian_amd import GaussianRasterizerBatch
         BV = 4
         nbt = len(views) // BV
@@ -385,7 +400,7 @@ def main():
     # optimiser step can do with the UNCHANGED drop-in classes.  Reported next to `value`, never instead of it.
     concurrent = None
     from r2_gaussian_amd import _C
-    if world == 1 and _C._shim() is not None:   # single-GPU runs only: an extra, kept out of the multi-rank collectives
+    if world == 1 and _C._shim() is not None and not args.no_streams:   # single-GPU runs only: an extra, kept out of the multi-rank collectives
         import threading
         NT = 2
         nsteps = max(20, min(args.steps, 400))
@@ -615,6 +630,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": DOMINANT, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "traffic_note": traffic_note, "us_per_launch": round(dom_us, 2), "launches_timed": int(dom[1]),
+                         "timed_in": "separate regions of the same shape right after the ones that produce `value` "
+                                     "(HIP events around this kernel's launches only)",
+                         "instrumented_regions": dom_regions,
                          "alg_bytes_per_launch": dom_bytes,
                          "pipeline_frac": round(total_bytes / dt_step / 1e9 / HBM_PEAK_GBS, 4),
                          "pipeline_alg_bytes": total_bytes},

@@ -63,6 +63,11 @@ def _sum_check(name, got, ref64, tol, stats, flagged):
     unfl = np.broadcast_to(unfl, err.shape)
     stats[name] = {
         "max_err_over_tol": float(ratio.max()) if ratio.size else 0.0,
+        # ... over the rows WITHOUT a borderline pair: the margin of the arithmetic itself.  (A row whose pair really flipped
+        # differs by that pair's whole contribution, which is what its budget holds: such rows sit just below 1 by
+        # construction and say nothing about rounding.)
+        "max_err_over_tol_unflagged": float(ratio[unfl].max()) if unfl.any() else 0.0,
+        "n_flagged_rows": int(flagged.sum()),
         "max_err_over_scale_unflagged": float(err[unfl].max() / scale) if scale > 0 and unfl.any() else 0.0,
         "n_bad": int(bad.sum()),
     }

@@ -1,54 +1,148 @@
-"""Where does a training iteration spend its time?  Coarse host-side breakdown (synchronising after every phase) of the
-miniature trainer on the HIP backend at 512^2 / 256^3 / 90k Gaussians.  gpurun_out/profile_train.json"""
-import json, os, sys, time
+"""Timeline of ONE steady-state training iteration on the HIP kernels (train.py:97-177, 204-209) at the
+headline sizes -- 512^2 detector, 32^3 TV patch, N_INIT Gaussians (default 300k), fused losses + fused densification
+statistics -- and what running the TV-voxelizer branch on a second stream buys.
+
+  phases   device time of each phase from HIP events recorded on the stream at the phase boundaries (no host synchronisation
+           inside the iteration), next to the HOST time spent issuing it: where the device waits for the host, the host column
+           is the larger one
+  loops    iterations/s of the whole loop, without any per-iteration synchronisation (the reference synchronises every
+           iteration, train.py:147, and reads three losses back with .item(), train.py:204-209):
+             serial      raster fwd -> image loss -> TV query -> TV loss -> backward -> statistics -> Adam, one stream
+             tv_stream   the TV branch (voxelizer forward + TV loss, and through autograd its backward) on a second stream;
+                         it is independent of the raster branch until the gradients are summed
+             sync_each   serial + torch.cuda.synchronize() per iteration (the reference's loop shape)
+
+    python scripts/profile_train.py            -> gpurun_out/profile_train.json + a markdown table on stdout
+"""
+import json
+import os
+import sys
+import time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import torch
-from tests import mini_trainer as T
+import torch  # noqa: E402
 
-case = T.Case(detector=512, n_vol=256, n_views=50, p_gt=20000, n_init=int(os.environ.get('N_INIT', '90000')), seed=2)
-opt = T.Opt(iterations=400, densify_from_iter=10**9, densify_until_iter=0)
-be = T.Backend("hip")
-gen = torch.Generator().manual_seed(0)
-model = T.Model(case, opt, be, gen)
-dev = be.device
-gts = [p.to(dev) for p in case.projs]
-tvN = torch.tensor([32] * 3); tvS = case.dVoxel * tvN
-acc = {}
-def tick(name, t0):
-    torch.cuda.synchronize(); t = time.perf_counter()
-    if os.environ.get('TRACE') == '1':
-        print(it, name, flush=True)
-    acc[name] = acc.get(name, 0.0) + t - t0
-    return t
-for it in range(1, 301):
-    if it == 101:
-        acc.clear()
-    torch.cuda.synchronize(); t = time.perf_counter()
+from r2_gaussian_amd import densify as FD  # noqa: E402
+from r2_gaussian_amd import losses as FL  # noqa: E402
+from r2_gaussian_amd import scene as S  # noqa: E402
+from tests import mini_trainer as T  # noqa: E402
+
+
+def build(n_init, detector):
+    """Model + views + targets without the CPU oracle (a timing run needs shapes, not a meaningful target)."""
+    be = T.Backend("hip")
+    dev = be.device
+    views = S.make_views(50, (detector, detector))
+    cloud = S.make_cloud(n_init, seed=0)
+    opt = T.Opt(iterations=30000)
+    raw = {"xyz": cloud.xyz, "density": T.Model.inv_softplus(cloud.density),
+           "scaling": torch.log((cloud.scales - 0.001) / (1.0 - 0.001) / (1 - (cloud.scales - 0.001) / (1.0 - 0.001))),
+           "rotation": cloud.rotations}
+    model = T.Model.from_tensors(opt, be, raw)
+    gts = [torch.rand(1, detector, detector, device=dev) * 0.5 for _ in range(4)]
+    return be, dev, views, model, gts, opt
+
+
+class Phases:
+    def __init__(self):
+        self.names, self.ev, self.host = [], [], []
+
+    def mark(self, name):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.names.append(name)
+        self.ev.append(e)
+        self.host.append(time.perf_counter())
+
+
+def iteration(it, be, dev, views, model, gts, opt, gen, tvN, tvS, bbox, ph=None, tv_stream=None):
+    mark = ph.mark if ph is not None else (lambda _n: None)
+    mark("start")
     model.update_lr(it)
-    x, d, s, r = model.activated(); t = tick("activations", t)
-    pkg = be.render(case.views[it % 50], x, d, s, r); img = pkg["render"]; t = tick("render_fwd", t)
-    loss = (img - gts[it % 50]).abs().mean()
-    if os.environ.get('NO_SSIM') != '1':
-        loss = loss + 0.25 * (1.0 - T.ssim(img, gts[it % 50]))
-    t = tick("l1+ssim_fwd", t)
-    c = (case.bbox[0] + tvS / 2) + (case.bbox[1] - tvS - case.bbox[0]) * torch.rand(3, generator=gen)
-    if os.environ.get('NO_TV') != '1':
-        vol = be.query(x, d, s, r, c, tvN, tvS); t = tick("tv_query_fwd", t)
-        loss = loss + 0.05 * T.tv3d_mean(vol); t = tick("tv_loss_fwd", t)
-    loss.backward(); t = tick("backward_all", t)
+    x, d, s, r = model.activated()
+    mark("activations")
+    c = (bbox[0] + tvS / 2) + (bbox[1] - tvS - bbox[0]) * torch.rand(3, generator=gen)
+    vol_loss = None
+    if tv_stream is not None:   # the TV branch first, on its own stream (its forward blocks the host only until num_rendered)
+        tv_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(tv_stream):
+            vol = be.query(x, d, s, r, c, tvN, tvS)
+            vol_loss = opt.lambda_tv * FL.tv_3d_loss(vol)
+    vi = it % len(views)
+    pkg = be.render(views[vi], x, d, s, r)
+    mark("raster_fwd")
+    loss, _parts = FL.image_loss(pkg["render"], gts[it % len(gts)], opt.lambda_dssim)
+    mark("image_loss")
+    if tv_stream is None:
+        vol = be.query(x, d, s, r, c, tvN, tvS)
+        mark("tv_query_fwd")
+        vol_loss = opt.lambda_tv * FL.tv_3d_loss(vol)
+        mark("tv_loss")
+    else:
+        torch.cuda.current_stream().wait_stream(tv_stream)
+    (loss + vol_loss).backward()
+    mark("backward")
     with torch.no_grad():
-        if os.environ.get('NO_STATS') != '1':
-            vis, radii = pkg["visibility_filter"], pkg["radii"]
-            model.max_radii2D[vis] = torch.max(model.max_radii2D[vis], radii[vis].float())
-            g2 = pkg["viewspace_points"].grad
-            model.grad_accum[vis] += g2[vis, :2].norm(dim=-1, keepdim=True)
-            model.denom[vis] += 1; t = tick("densify_stats", t)
-        if os.environ.get('NO_ADAM') != '1':
-            model.optimizer.step()
-        model.optimizer.zero_grad(set_to_none=True); t = tick("adam", t)
-n = 200
-out = {k: round(1e6 * v / n, 1) for k, v in acc.items()}
-out["total_us"] = round(sum(out.values()), 1)
-print(json.dumps(out, indent=1))
-json.dump(out, open(os.path.join(ROOT, "gpurun_out", "profile_train.json"), "w"), indent=1)
+        FD.densification_stats(pkg["radii"], pkg["viewspace_points"].grad, model.max_radii2D, model.grad_accum, model.denom)
+        mark("densify_stats")
+        model.optimizer.step()
+        model.optimizer.zero_grad(set_to_none=True)
+    mark("adam")
+
+
+def main():
+    n_init = int(os.environ.get("N_INIT", "300000"))
+    detector = int(os.environ.get("DETECTOR", "512"))
+    be, dev, views, model, gts, opt = build(n_init, detector)
+    gen = torch.Generator().manual_seed(0)
+    tvN = torch.tensor([32] * 3)
+    tvS = torch.tensor([2.0 / 256] * 3) * tvN
+    bbox = torch.tensor([[-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]])
+    args = (be, dev, views, model, gts, opt, gen, tvN, tvS, bbox)
+    for it in range(1, 60):
+        iteration(it, *args)
+    torch.cuda.synchronize()
+
+    # ---- phases of steady-state iterations (events on the stream; host stamps beside them)
+    acc_dev, acc_host, n = {}, {}, 0
+    for it in range(60, 160):
+        ph = Phases()
+        iteration(it, *args, ph=ph)
+        torch.cuda.synchronize()
+        for i in range(1, len(ph.names)):
+            acc_dev[ph.names[i]] = acc_dev.get(ph.names[i], 0.0) + ph.ev[i - 1].elapsed_time(ph.ev[i]) * 1e3
+            acc_host[ph.names[i]] = acc_host.get(ph.names[i], 0.0) + (ph.host[i] - ph.host[i - 1]) * 1e6
+        n += 1
+    phases = {k: {"device_us": round(acc_dev[k] / n, 1), "host_issue_us": round(acc_host[k] / n, 1)} for k in acc_dev}
+
+    # ---- whole loops
+    def loop(nit, tv_stream=None, sync_each=False):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(1000, 1000 + nit):
+            iteration(it, *args, tv_stream=tv_stream)
+            if sync_each:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return nit / (time.perf_counter() - t0)
+    sB = torch.cuda.Stream(device=dev)
+    loops = {}
+    for name, kw in (("serial", {}), ("tv_stream", {"tv_stream": sB}), ("sync_each", {"sync_each": True}), ("serial_again", {})):
+        loop(50, **kw)
+        loops[name] = round(max(loop(300, **kw) for _ in range(3)), 1)
+    out = {"P": n_init, "detector": detector, "phases": phases,
+           "device_us_per_iteration": round(sum(v["device_us"] for v in phases.values()), 1),
+           "host_issue_us_per_iteration": round(sum(v["host_issue_us"] for v in phases.values()), 1),
+           "iterations_per_s": loops}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    json.dump(out, open(os.path.join(ROOT, "gpurun_out", "profile_train.json"), "w"), indent=1)
+    print("| phase | device us | host issue us |\n|---|---|---|")
+    for k, v in phases.items():
+        print("| %s | %.1f | %.1f |" % (k, v["device_us"], v["host_issue_us"]))
+    print("| **sum** | %.1f | %.1f |" % (out["device_us_per_iteration"], out["host_issue_us_per_iteration"]))
+    print(json.dumps(loops))
+
+
+if __name__ == "__main__":
+    main()

@@ -79,3 +79,37 @@ def test_tv_patch_300k_32cube_forward_backward(oracle, gpu):
     sg = Hh.parity_voxel_grads(oracle, o, gh, c, dL, "TV patch 300k/32^3")
     for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
         assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])
+
+
+# ---- gradient parity beyond one cloud: other seeds, half / double the Gaussian size, scale_modifier 1.5.
+# Every case logs its margins (max_err_over_tol per gradient) to gpurun_out/parity_report.json; the committed copy is
+# profiles/r03_parity_report.json.
+@pytest.mark.parametrize("scale_modifier", [1.0, 1.5], ids=["mod1", "mod1.5"])
+@pytest.mark.parametrize("scale_mult", [0.5, 1.0, 2.0], ids=["half", "unit", "double"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_gradient_parity_sweep_300k_512(seed, scale_mult, scale_modifier, oracle, gpu):
+    if seed == 0 and scale_mult == 1.0 and scale_modifier == 1.0:
+        pytest.skip("the headline case above")
+    c = S.make_cloud(300000, seed=seed, scale_mult=scale_mult)
+    v = S.make_views(50, (512, 512))[(7 * seed + 3) % 50]
+    label = "SWEEP 300k/512^2 seed %d scale x%g modifier %g" % (seed, scale_mult, scale_modifier)
+    o = Hh.oracle_raster(oracle, c, v, scale_modifier=scale_modifier)
+    h = Hh.hip_raster(c, v, gpu, scale_modifier=scale_modifier)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    assert np.array_equal(h["radii"], o["radii"])
+    Hh.check_binning(h, o)
+    Hh.parity_image(oracle, o, h["color"], label)
+    dL = S.make_pixel_grad(512, 512, seed=seed + 1).numpy()
+    gh = Hh.hip_raster_backward(h, c, v, dL, gpu)
+    sg = Hh.parity_raster_grads(oracle, o, gh, c, v, dL, label, scale_modifier=scale_modifier)
+    for k in ("dL_dmeans2D", "dL_dopacity", "dL_dmu", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])
+
+
+def test_config_C_300k_560(oracle, gpu):
+    """BASELINE config C (pine-like): ~300k Gaussians, 560^2 detector (data_generator/real_dataset/README.md:68) -- T = 35 x 35
+    = 1225 tiles, 11 tile-id bits."""
+    c = S.make_cloud(300000, seed=3)
+    v = S.make_views(50, (560, 560))[11]
+    o, _h = _raster_full(oracle, gpu, c, v, "config C 300k/560^2")
+    assert o["ranges"].shape[0] == 1225
