@@ -34,6 +34,7 @@ SOURCES = {
     "voxel_geom.hip": EXACT,
     "voxel_render.hip": FAST,
     "voxel_api.hip": FAST,
+    "voxel_small.hip": FAST,
     "knn.hip": EXACT,
     "loss_ops.hip": FAST,
     "densify_ops.hip": EXACT,

@@ -404,6 +404,10 @@ int depth_order_prepare(void *temp, size_t temp_bytes, size_t P, hipStream_t s)
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }
+uint4 *depth_order_slots(void *temp, size_t P)
+{
+    return Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P)).slot;
+}
 uint32_t *depth_order_words(void *temp, size_t P)
 {
     return &Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P)).ctrl->total;

@@ -188,6 +188,7 @@ __device__ __forceinline__ void depth_register_end(const DepthReg &r, uint32_t i
 // depth order's temp storage (zeroed by depth_order_prepare):
 enum { DW_TOTAL = 0, DW_OVERFLOW, DW_USER, DW_PMAX, DW_PNMAX, DW_NMAX, DW_NNMAX, DW_NVIS, DW_COUNT };
 uint32_t *depth_order_words(void *temp, size_t P);
+uint4 *depth_order_slots(void *temp, size_t P);   // [P] 16-byte records of the hinted path; also the small-grid survivor list
 // which = 0 rasterizer, 1 voxelizer: separate hint histories.  Returns false when there is no usable hint for P keys (first
 // call, P changed, hints switched off): the caller then runs the un-hinted path.
 bool depth_hint_lookup(int which, size_t P, DepthHint *out);
@@ -252,6 +253,8 @@ struct WorkListOut {
     uint32_t *tile_done;
     // optional (voxelizer): tiles with fewer than min_len instances get NO work item (a light kernel renders them)
     uint32_t min_len;
+    // optional: capacity of `work` in items (0 = as many as needed); items beyond it are dropped (the caller checks the total)
+    uint32_t work_cap;
 };
 template <int NT>
 __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict__ counts, const WorkListOut wo)
@@ -280,7 +283,8 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
             wo.ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
             wo.chunk_base[t] = wstart;
             for (uint32_t j = 0; j < nw; ++j)
-                wo.work[wstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
+                if (!wo.work_cap || wstart + j < wo.work_cap)
+                    wo.work[wstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
         }
         __syncthreads();
         if (tid == NT - 1) { rw_carry = start + c; rw_carry2 = wstart + nw; }

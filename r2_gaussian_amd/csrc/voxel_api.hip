@@ -52,6 +52,16 @@ extern "C" int r2_voxel_forward(
     }
     const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
 
+    // small grids (the 32^3 TV patch of the training loop): survivors only, 4 launches (voxel_small.hip)
+    if (!debug) {
+        const int small = voxel_forward_small(binningBuffer, binning_user, imageBuffer, image_user, geom, v, P, means3D, opacities,
+                                              scales, scale_modifier, rotations, cov3D_precomp, out_volume, radii_x, radii_y, radii_z, s);
+        if (small != VOX_SMALL_NOT_TAKEN) {
+            host_mark_forward_end();
+            return small;
+        }
+    }
+
     // binning, first half (see raster_api.hip): order of the Gaussians by the bits of world z (the reference's low sort
     // word, Q10) + instance offsets in that order; hinted / un-hinted bucket sort, radix fallback
     int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)P, s);
@@ -162,6 +172,7 @@ extern "C" int r2_voxel_forward(
     { StageScope t(ST_VOX_RENDER_FWD, s);
     launch_voxel_render_forward(geom, bin, img, v, out_volume, debug != 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
+    if (R > 0 && voxel_forward_fills_tiles(T)) fill_tiles_from_ranges(img.ranges, T, bin.tiles, s);   // see voxel_state.hpp
     host_mark_forward_end();
     return (int)num_rendered;
 }
@@ -187,7 +198,7 @@ extern "C" int r2_voxel_backward(
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
     const size_t T = (size_t)v.gx * v.gy * v.gz;
-    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1)))) {
+    if (R > 0 && sort_is_single_pass((int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1))) && !voxel_forward_fills_tiles(T)) {
         if (!img_buffer) {
             set_error("r2_voxel_backward: image state required");
             return R2_ERR_INVALID;

@@ -30,6 +30,10 @@ __device__ __forceinline__ void voxel_cov(const float *cov3D, float dvx, float d
 }
 
 // n_out = the Gaussian's number of tiles (0: it emits nothing)
+// EARLY_CULL (small grids, where ~98 % of the Gaussians miss the volume): the volume / tile-cube tests come first, so a culled
+// Gaussian costs two loads and never computes or stores its covariance.  Same outcome: the reference returns with radii = 0 on
+// whichever test fails first (VOX/forward.cu:120-160) and nothing of a culled Gaussian's state is read again.
+template <bool EARLY_CULL = false>
 __device__ __forceinline__ void voxel_preprocess_one(
     int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
@@ -48,6 +52,17 @@ __device__ __forceinline__ void voxel_preprocess_one(
     // unsigned ints, negative z sorts after positive -- quirk Q10).  Culled Gaussians emit nothing, so their
     // position in the depth order is irrelevant.
     depth_key[idx] = __float_as_uint(p.z);
+    if (EARLY_CULL) {
+        const float ms = fmaxf(fmaxf(scales[3 * idx], scales[3 * idx + 1]), scales[3 * idx + 2]);
+        const float3 rd = make_float3(ceilf((3.f * ms) / dvx), ceilf((3.f * ms) / dvy), ceilf((3.f * ms) / dvz));
+        const float3 q = make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy, (p.z - v.cz + v.sz / 2) / dvz);
+        if (q.x + rd.x < 0 || q.y + rd.y < 0 || q.z + rd.z < 0 || q.x - rd.x > (float)v.nx || q.y - rd.y > (float)v.ny ||
+            q.z - rd.z > (float)v.nz)
+            return;
+        int3 l0, h0;
+        tile_cube(q, rd, v.gx, v.gy, v.gz, l0, h0);
+        if ((h0.x - l0.x) * (h0.y - l0.y) * (h0.z - l0.z) == 0) return;
+    }
 
     float cov3D[6];
     if (cov3D_precomp != nullptr) {
@@ -136,6 +151,90 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     depth_register_end(reg, (uint32_t)idx, key, bt);
 }
 
+// ---- small grids (the training loop's 32^3 TV patch: 64 tiles; train.py:128-142).  Only ~2 % of the Gaussians reach such a
+// patch, and the general pipeline spends its time on per-Gaussian bookkeeping over ALL of them (bucket counters, dual scan,
+// place, rank, emission, tile sort: nine latency-bound launches).  Here the preprocess itself hands every
+// SURVIVOR (a) its run of rows in the backward's moment scratch and (b) a slot in a compact survivor list -- one 64-bit atomic
+// per 1024-thread workgroup {workgroups done : 12 | survivors : 20 | rows : 32} (same-address atomics retire at ~90 per
+// microsecond device-wide: one per wave would cost as much as the whole kernel) -- and the LAST workgroup posts the totals to
+// the host mailbox.  voxel_small.hip then builds every tile's depth-sorted list straight from the survivor list.  Nothing of
+// the reference's contract changes: radii, tiles_touched, num_rendered, point_list and ranges are bit-identical; the order in
+// which Gaussians get their scratch rows is ours (any disjoint assignment serves the backward).
+__global__ void __launch_bounds__(1024) voxel_preprocess_small_kernel(
+    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, float *__restrict__ cov3Ds,
+    uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, uint32_t *__restrict__ first, uint4 *__restrict__ cube,
+    uint4 *__restrict__ surv, unsigned long long *counter /* persistent, zero between calls */, uint32_t *__restrict__ words,
+    uint32_t *__restrict__ mailbox, uint32_t seq)
+{
+    const int idx = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t key = DEPTH_CULLED_KEY;
+    uint2 bt = make_uint2(0u, 0u);
+    const DepthReg noreg{};
+    if (idx < P)
+        voxel_preprocess_one<true>(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y,
+                                   radii_z, rec, depth_key, cov3Ds, tiles_touched, ext, noreg, key, bt);
+    const bool vis = key != DEPTH_CULLED_KEY;
+    const uint32_t n = vis ? tiles_touched[idx] : 0u;
+    // exclusive prefix of (rows, survivors) inside the workgroup
+    uint32_t in = n, iv = vis ? 1u : 0u;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t un = __shfl_up(in, d), uv = __shfl_up(iv, d);
+        if (lane >= d) { in += un; iv += uv; }
+    }
+    __shared__ uint32_t wn[16], wv[16];
+    __shared__ unsigned long long s_old;
+    if (lane == 63) { wn[wave] = in; wv[wave] = iv; }
+    __syncthreads();
+    uint32_t bn = 0, bv = 0, tn = 0, tv = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { bn += wn[w]; bv += wv[w]; }
+        tn += wn[w]; tv += wv[w];
+    }
+    if (threadIdx.x == 0) s_old = atomicAdd(counter, (1ull << 52) | ((unsigned long long)tv << 32) | (unsigned long long)tn);
+    __syncthreads();
+    const unsigned long long old = s_old;
+    const uint32_t row0 = (uint32_t)old, sv0 = (uint32_t)(old >> 32) & 0xFFFFFu, done = (uint32_t)(old >> 52);
+    if (vis) {
+        const float4 r0 = rec[3 * idx];
+        int3 lo, hi;
+        tile_cube(make_float3(r0.x, r0.y, r0.z), make_float3((float)radii_x[idx], (float)radii_y[idx], (float)radii_z[idx]),
+                  v.gx, v.gy, v.gz, lo, hi);
+        const uint32_t f = row0 + bn + in - n;
+        first[idx] = f;
+        cube[idx] = make_uint4(f, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
+                               (uint32_t)(hi.y - lo.y));
+        surv[sv0 + bv + iv - 1u] = make_uint4((uint32_t)idx, key,
+                                               (uint32_t)lo.x | ((uint32_t)lo.y << 4) | ((uint32_t)lo.z << 8) | ((uint32_t)hi.x << 12) |
+                                                   ((uint32_t)hi.y << 16) | ((uint32_t)hi.z << 20), f);
+    }
+    if (done == gridDim.x - 1u && threadIdx.x == 0) {   // the last workgroup to arrive: totals -> state + host, counter back to 0
+        const uint32_t R = row0 + tn, nsurv = sv0 + tv;
+        *counter = 0ull;
+        words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = VOX_SMALL_MARK; words[DW_NVIS] = nsurv;
+        words[DW_PMAX] = 0u; words[DW_PNMAX] = 0u; words[DW_NMAX] = 0u; words[DW_NNMAX] = 0u;
+        mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = VOX_SMALL_MARK; mailbox[DW_NVIS] = nsurv;
+        mailbox[DW_PMAX] = 0u; mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = 0u; mailbox[DW_NNMAX] = 0u;
+        __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+int launch_voxel_preprocess_small(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
+                                  float scale_modifier, const float *rotations, const float *opacities,
+                                  const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, uint4 *surv,
+                                  unsigned long long *counter, uint32_t *mailbox, uint32_t seq, hipStream_t s)
+{
+    voxel_preprocess_small_kernel<<<dim3((P + 1023) / 1024), dim3(1024), 0, s>>>(
+        P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z, g.rec, g.depth_key,
+        g.cov3D, g.tiles_touched, g.ext, g.first, g.cube, surv, counter, g.host_words, mailbox, seq);
+    return 0;
+}
+
 // Instance emission (duplicateWithKeys, VOX/voxelizer_impl.cu:54-101) in DEPTH order: sorted position j ->
 // Gaussian order[j] -> its tiles z-major / y / x-minor.  Only the tile id is the sort key (see binning.hip).
 // One wave serves 64 consecutive sorted positions and walks their contiguous output span with coalesced
@@ -203,6 +302,18 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     }
 }
 
+// zero the K-float rows of a wave's 64 Gaussians whose bit is set in `rows`, with unit-stride stores over the wave's span
+template <int K>
+__device__ __forceinline__ void zero_culled_rows(float *__restrict__ a, size_t row0, int lane, unsigned long long rows)
+{
+    if (a == nullptr) return;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int e = j * 64 + lane;
+        if ((rows >> (e / K)) & 1ull) a[row0 * (size_t)K + (size_t)e] = 0.f;
+    }
+}
+
 // Fused geometry backward, one pass per Gaussian:
 //   1. reduce the per-instance moment rows of the render backward (contiguous run in the emission list),
 //      fixed order -> deterministic, atomic-free (reference: 10 float atomicAdd per pair, VOX/backward.cu:359-370);
@@ -218,18 +329,25 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P) return;
-    if (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) {
-        // culled Gaussian: all-zero gradient rows (the reference relies on zero-filled tensors, SUB/voxelize_points.cu:130-136)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { dL_dmean3D_norm[3 * idx + k] = 0.f; dL_dmeans[3 * idx + k] = 0.f; }
-#pragma unroll
-        for (int k = 0; k < 6; ++k) { dL_dconic3D[6 * idx + k] = 0.f; dL_dcov[6 * idx + k] = 0.f; }
-        dL_dopacity[idx] = 0.f;
-        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
-        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        return;
+    // culled Gaussians: all-zero gradient rows (the reference relies on zero-filled tensors, SUB/voxelize_points.cu:130-136).
+    // The WAVE writes them: its 64 rows are one contiguous span of every output array, walked with unit-stride stores, each
+    // element zeroed iff its row's lane is culled (on the TV patch 98 % of the rows are: the per-lane version -- 26 strided
+    // 4-byte stores -- was the whole cost of this kernel there)
+    const bool in_range = idx < P;
+    const bool culled = in_range && (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0));
+    const unsigned long long cmask = __ballot(culled);
+    if (cmask) {   // wave-uniform
+        const int lane = threadIdx.x & 63;
+        const size_t row0 = (size_t)(idx - lane);
+        zero_culled_rows<3>(dL_dmean3D_norm, row0, lane, cmask);
+        zero_culled_rows<3>(dL_dmeans, row0, lane, cmask);
+        zero_culled_rows<6>(dL_dconic3D, row0, lane, cmask);
+        zero_culled_rows<6>(dL_dcov, row0, lane, cmask);
+        zero_culled_rows<1>(dL_dopacity, row0, lane, cmask);
+        zero_culled_rows<3>(dL_dscale, row0, lane, cmask);
+        zero_culled_rows<4>(dL_drot, row0, lane, cmask);
     }
+    if (!in_range || culled) return;
     const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
 
     // ---- 1. moments: S0, (Sx,Sy,Sz), (Sxx,Sxy,Sxz,Syy,Syz,Szz)

@@ -195,9 +195,13 @@ __global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
         // a tail too short to fill a lane-per-entry step, and the exact entries, are evaluated voxel-parallel instead (lane =
         // voxel y*8+z of the slab, entries broadcast from LDS, exact exp): ~20 instructions per entry instead of a
         // ~500-instruction step
-        const int ntail = (cnt - head) + cntx;
+        // (head may have stepped past cnt: the last lane-per-entry step was a partial one.  Round 2 computed the tail length as
+        // (cnt - head) + cntx without the clamp: a negative remainder swallowed that many of the EXACT entries -- found in round 3
+        // by a 32^3 grid whose voxels are larger than most Gaussians, where thin entries are the rule, not the exception)
+        const int rem = max(cnt - head, 0);
+        const int ntail = rem + cntx;
         for (int t = 0; t < ntail; ++t) {
-            const int j = t < cnt - head ? head + t : VFWD_BATCH - 1 - (t - (cnt - head));
+            const int j = t < rem ? head + t : VFWD_BATCH - 1 - (t - rem);
             const int e = sQ[wave][j];
             const float4 p = s0[e], q = s1[e], r = s2[e];
             const float dx = p.x - xc, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);

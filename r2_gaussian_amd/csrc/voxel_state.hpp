@@ -9,7 +9,7 @@ constexpr uint32_t VOX_CHUNK = 1024;  // most instances of one tile list evaluat
 // Small problems (the training loop's 32^3 TV patch: 64 tiles, ~5e4 instances) are cut finer, so that the forward still
 // launches a few workgroups per CU instead of ~one long-running workgroup per tile.  A pure function of R: the backward and
 // the state introspection re-derive the same layout.
-inline uint32_t vox_chunk_for(size_t R) { return R >= (size_t)1 << 20 ? VOX_CHUNK : (R >= (size_t)1 << 19 ? 512u : (R >= (size_t)1 << 17 ? 256u : 128u)); }
+__host__ __device__ inline uint32_t vox_chunk_for(size_t R) { return R >= (size_t)1 << 20 ? VOX_CHUNK : (R >= (size_t)1 << 19 ? 512u : (R >= (size_t)1 << 17 ? 256u : 128u)); }
 constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
 constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
 constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)
@@ -147,6 +147,24 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
                             bool store_cov3D, hipStream_t s);
+// small grids (<= 64 tiles): preprocess + survivor list (voxel_geom.hip), per-tile lists from it (voxel_small.hip)
+int launch_voxel_preprocess_small(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
+                                  float scale_modifier, const float *rotations, const float *opacities,
+                                  const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, uint4 *surv,
+                                  unsigned long long *counter, uint32_t *mailbox, uint32_t seq, hipStream_t s);
+constexpr size_t VOX_SMALL_MAX_TILES = 64;         // 4 x 4 x 4 tiles: the 32^3 TV patch
+// For such grids the FORWARD leaves the per-instance tile ids (binning state `tiles`) behind, whichever path it took and
+// whatever its debug flag; the backward of larger single-pass grids fills them from the ranges itself.  A static rule of the
+// grid alone: the backward cannot ask which forward path ran, nor with which flags.
+inline bool voxel_forward_fills_tiles(size_t T) { return T <= VOX_SMALL_MAX_TILES; }
+constexpr uint32_t VOX_SMALL_MAX_SURVIVORS = 8192;  // a tile's list (<= all survivors) is sorted in LDS: 2 x 8 bytes per entry
+// -> num_rendered (>= 0), a negative R2_ERR_* code, or VOX_SMALL_NOT_TAKEN: the caller runs the general pipeline
+constexpr int VOX_SMALL_NOT_TAKEN = -1000;
+constexpr uint32_t VOX_SMALL_MARK = 0x5A11u;      // DW_USER word of a state produced by the small-grid path (introspection / tests)
+int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
+                        const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
+                        const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                        float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,

@@ -130,3 +130,94 @@ def test_x_slab_sharding_reassembles_the_full_volume(gpu):
         tol = 1e-4 * full.abs() + 2e-6
         assert float((err > tol).float().mean()) < 1e-4, float((err > tol).float().mean())
         assert float(full.max()) > 0.01
+
+
+# ---- the small-grid path (csrc/voxel_small.hip: <= 64 tiles, the training loop's TV patch) -----------------------------------
+def _small_path_taken(h):
+    return int(h["host_words"][2]) == 0x5A11
+
+
+def test_small_grid_path_is_taken_and_matches_the_general_path(oracle, gpu, monkeypatch):
+    """300 k-style sparse patch: the survivor path runs (marker in the state), its point_list / ranges / volume equal the
+    general pipeline's (debug mode forces that one) bit for bit, and the oracle's."""
+    c = S.make_cloud(60000, seed=13)
+    n, s, ctr = (32, 32, 32), (0.25, 0.25, 0.25), (-0.2, 0.1, 0.0)
+    fast = Hh.hip_voxel(c, n, s, ctr, gpu)
+    general = Hh.hip_voxel(c, n, s, ctr, gpu, debug=True)
+    assert _small_path_taken(fast) and not _small_path_taken(general)
+    assert fast["num_rendered"] == general["num_rendered"] > 0
+    for k in ("radii_x", "radii_y", "radii_z", "tiles_touched", "point_list", "ranges"):
+        assert np.array_equal(fast[k], general[k]), k
+    # (the debug forward renders voxel-parallel, the production one lane-per-entry: same lists, another association of the sums)
+    np.testing.assert_allclose(fast["vol"], general["vol"], rtol=2e-5, atol=1e-9)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
+    Hh.check_binning(fast, o)
+    # ragged small grid with empty tiles: 20 x 12 x 28 voxels = 3 x 2 x 4 tiles, most of them outside the cloud
+    n2, s2, ctr2 = (20, 12, 28), (0.2, 0.12, 0.28), (1.08, 1.02, 0.9)
+    f2 = Hh.hip_voxel(c, n2, s2, ctr2, gpu)
+    o2 = Hh.oracle_voxel(oracle, c, n2, s2, ctr2, render=False)
+    assert _small_path_taken(f2)
+    Hh.check_binning(f2, o2)
+    assert f2["num_rendered"] > 0
+
+
+def test_small_grid_equal_depth_keys_keep_id_order(oracle, gpu):
+    """All Gaussians on one z plane: every sort key is equal, the reference's stable sort leaves ascending ids; the in-LDS bucket
+    sort then has ONE long bucket and must still rank by (key, id)."""
+    c = S.make_cloud(20000, seed=5, scale_mult=0.3)
+    xyz = torch.cat([c.xyz[:, :2] * 0.1, torch.full((20000, 1), 0.0123)], 1)
+    xyz[3000:, 0] += 50.0                       # only the first 3000 reach the patch (the state's temp is sized by P)
+    c = S.Cloud(xyz.contiguous(), c.scales, c.rotations, c.density)
+    n, s, ctr = (32, 32, 32), (0.3, 0.3, 0.3), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert _small_path_taken(h) and h["num_rendered"] > 5000
+    Hh.check_binning(h, o)
+    for a, b in h["ranges"]:
+        assert (np.diff(h["point_list"][a:b].astype(np.int64)) > 0).all()   # equal keys: ids ascend inside every tile
+
+
+def test_small_grid_falls_back_when_the_patch_holds_too_many(oracle, gpu):
+    """More survivors than the LDS sort holds (8192): the call silently takes the general pipeline; same results."""
+    c = S.make_cloud(40000, seed=3)
+    n, s, ctr = (32, 32, 32), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)      # the patch is the whole volume: everybody survives
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert not _small_path_taken(h) and h["num_rendered"] == o["num_rendered"]
+    Hh.check_binning(h, o)
+    Hh.parity_volume(oracle, o, h["vol"], "small-grid fallback 40k/32^3")
+    g = torch.Generator().manual_seed(2)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    gh = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+    st = Hh.parity_voxel_grads(oracle, o, gh, c, dL, "small-grid fallback 40k/32^3")
+    for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        assert st[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, st[k])
+
+
+def test_small_grid_from_two_threads(gpu):
+    """The path keeps a per-host-thread device counter: two threads hammering different patches on their own streams."""
+    import threading
+    from r2_gaussian_amd import GaussianVoxelizationSettings, GaussianVoxelizer
+    c = S.make_cloud(50000, seed=8)
+    args = dict(means3D=c.xyz.to(gpu), opacities=c.density.to(gpu), scales=c.scales.to(gpu), rotations=c.rotations.to(gpu))
+    centres = [(-0.3 + 0.1 * i, 0.05 * i - 0.1, 0.02 * i) for i in range(6)]
+    mk = lambda ctr: GaussianVoxelizer(GaussianVoxelizationSettings(1.0, 32, 32, 32, 0.25, 0.25, 0.25, ctr[0], ctr[1], ctr[2], False, False))
+    ref = [mk(ctr)(**args)[0].clone() for ctr in centres]
+    torch.cuda.synchronize()
+    bad = []
+
+    def worker(t):
+        st = torch.cuda.Stream(device=gpu)
+        with torch.cuda.stream(st):
+            for rep in range(30):
+                i = (rep * 2 + t) % len(centres)
+                vol, _ = mk(centres[i])(**args)
+                st.synchronize()
+                if not torch.equal(vol, ref[i]):
+                    bad.append((t, rep, i))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not bad, bad[:5]
