@@ -134,6 +134,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uin
 }
 
 // ------------------------------------------------------------------------------------------------------------- scan
+// (Measured and left out, round 3: 8 digits per workgroup for narrow radices -- 32 workgroups instead of 8 for the voxelizer's
+// 8-bit passes, a quarter of the dependent row loads per thread: 12 us SLOWER per pass; a wave then touches eight 32-byte
+// sectors per load instead of two 128-byte lines.)
 // H[t][d] <- sum of H[t'][d] over t' < t (exclusive, per digit); totals[d] = column sum.  One workgroup owns 32
 // consecutive digits; its 8 thread rows split the tile range, so every access is a full 128-byte row segment.
 __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__restrict__ H, uint32_t ntiles, int bits, uint32_t n,

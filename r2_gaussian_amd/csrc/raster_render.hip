@@ -382,7 +382,10 @@ constexpr int MAX_WAVE_TILES = 3;
 // frees its slot and its 8 KB of LDS at once instead of waiting for its three siblings (-3 % kernel time).  Walking the
 // chunks with a grid-stride loop from a few resident workgroups per CU was measured too: no gain.
 constexpr int BWD_WAVES = 1, BWD_THREADS = 64 * BWD_WAVES;
-constexpr int BWD_OCC = 4;   // waves per SIMD the kernel is compiled for (121 VGPRs with the pipeline registers)
+#ifndef R2_EXP_BWD_OCC
+#define R2_EXP_BWD_OCC 4
+#endif
+constexpr int BWD_OCC = R2_EXP_BWD_OCC;   // waves per SIMD the kernel is compiled for (121 VGPRs with the pipeline registers)
 
 __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, float bdy, float cdy2, float g, float &r0,
                                               float &r1, float &r3)
@@ -445,6 +448,11 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             // its sums: the same as adding 0), s_mov restores EXEC on the scalar unit -- 5 VALU instead of the 6 of compare +
             // select + multiply + 3 updates (this kernel is VALU-issue-bound).  (c - mid)^k enter as literal operands.
             static_assert(N == 8, "the pixel macro below is written for 8-pixel rows");
+            // the EXEC save / restore below is written for wave64 on gfx9-family ISA (64-bit exec, v_cmpx writing EXEC); the
+            // plain-C++ body under R2_EXP_NO_CMPX is the portable statement of the same arithmetic (tests build and compare it)
+#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "the inline asm below assumes a 64-lane EXEC mask (wave64)"
+#endif
             const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
 #define R2_BWD_K(x) "n"(__builtin_bit_cast(int, (float)(x)))   /* literals: SGPR operands measured 1 us slower */
 #define R2_BWD_PX(c)                                                                                                      \
@@ -569,7 +577,11 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     uint32_t first_row;
     R2_TS_AT(render, 2);
     load1(blockIdx.x, tile, id, live);
+#ifndef R2_EXP_BWD_NOPIPE
     load1(blockIdx.x + G, tile1, id1, live1);
+#else
+    tile1 = 0; id1 = 0; live1 = false;
+#endif
     load2(id, a, b, rad, first_row);
 
     for (uint32_t v = blockIdx.x; v < nslots; v += G) {
@@ -596,11 +608,15 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     // (b) round (1) of the chunk after next, (c) round (2) of the next chunk
     uint32_t tile2, id2;
     bool live2;
-    load1(v + 2u * G, tile2, id2, live2);
     float4 a1, b1;
     int rad1;
     uint32_t first_row1;
+#ifndef R2_EXP_BWD_NOPIPE
+    load1(v + 2u * G, tile2, id2, live2);
     load2(id1, a1, b1, rad1, first_row1);
+#else   // experiment: no software pipeline (one chunk per wave), occupancy instead
+    tile2 = 0; id2 = 0; live2 = false; a1 = a; b1 = b; rad1 = 0; first_row1 = 0;
+#endif
 
     float S[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     // The chunk's tiles are handled MAX_WAVE_TILES at a time (nearly always one pass: 97 % of the waves sit inside a
@@ -717,6 +733,9 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         part[2 * u] = make_float4(S[0], S[1], S[2], S[3]);
         part[2 * u + 1] = make_float4(S[4], S[5], 0.f, 0.f);
     }
+#ifdef R2_EXP_BWD_NOPIPE
+    break;
+#endif
     // rotate the pipeline registers
     tile = tile1; id = id1; live = live1;
     tile1 = tile2; id1 = id2; live1 = live2;
@@ -785,7 +804,12 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     const int cus = device_cu_count();
     const uint32_t slots = (uint32_t)cus * 4u * (uint32_t)BWD_OCC;   // a multiple of 8 (XCD-aware chunk order)
     const uint32_t nslots = ((nchunks + 7u) >> 3) << 3;
+#ifdef R2_EXP_BWD_NOPIPE
+    const uint32_t grid = nslots;
+    (void)slots;
+#else
     const uint32_t grid = (nslots <= slots || (slots & 7u)) ? nslots : (nslots / slots) * slots;
+#endif
     const int gy = (H + TILE2D - 1) / TILE2D;
     if (V > 1)   // the view of an instance follows from its tile id
         raster_render_backward_kernel<true><<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(

@@ -49,7 +49,11 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
     const float dz0 = p.z - (z0 + 0.5f);
     const float kf1 = r.y * (1.0f - 2.0f * dz0);
     const float rr = __builtin_amdgcn_exp2f(2.0f * r.y);
+#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "the inline asm below assumes a 64-lane EXEC mask (wave64)"
+#endif
     const unsigned long long full_exec = __builtin_amdgcn_read_exec();
+    (void)full_exec;
 #pragma unroll
     for (int iy = 0; iy < TILE3D; ++iy) {
         const float dy = p.y - (y0 + (float)iy + 0.5f);
@@ -66,12 +70,16 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
                 // alpha >= 1e-6: VOX/forward.cu:293
                 // acc += (g >= 1e-6) ? g : 0 as an EXEC mask: compare + masked add instead of compare + select + add (487 ->
                 // 467 us at 256^3 once the kernel runs 4 waves/SIMD; it changed nothing at 3)
+#ifndef R2_EXP_NO_CMPX
                 asm volatile("v_cmpx_le_f32_e32 %[thr], %[g]\n\t"
                              "v_add_f32_e32 %[a], %[a], %[g]\n\t"
                              "s_mov_b64 exec, %[ex]"
                              : [a] "+v"(acc[iy * TILE3D + seg + c])
                              : [thr] "n"(0x358637bd), [g] "v"(g), [ex] "s"(full_exec)
                              : "vcc");
+#else   // the portable statement of the same arithmetic (built as libr2hip_nocmpx.so and compared in tests/test_variants_gpu.py)
+                acc[iy * TILE3D + seg + c] += (g >= ALPHA_MIN_3D) ? g : 0.f;
+#endif
                 g *= rt;
                 rt *= rr;
             }

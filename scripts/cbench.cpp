@@ -427,8 +427,11 @@ int main(int argc, char **argv)
             if (cnt[i] && !strncmp(prof_name(i), "voxel.", 6)) printf("  tv %-17s %8.2f us\n", prof_name(i), 1e3 * ms[i] / cnt[i]);
         prof_enable(0);
     }
+    // (one call at a time: a stage's begin event is stamped when the command processor reaches it, which with calls queued back to
+    // back is while the PREVIOUS call's render kernel still runs -- round 2's "voxel.preprocess 348 us" was that tail, not the
+    // 24 us kernel rocprofv3 shows)
     prof_enable(~0ull);
-    for (int k = 0; k < 5; ++k) vox();
+    for (int k = 0; k < 5; ++k) { vox(); CHECK(hipStreamSynchronize(s)); }
     CHECK(hipStreamSynchronize(s));
     prof_read(ms.data(), cnt.data(), 1);
     for (int i = 0; i < ns; ++i)

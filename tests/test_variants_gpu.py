@@ -1,0 +1,53 @@
+"""The render kernels' hand-written EXEC-mask inline asm (v_cmpx + masked accumulation, csrc/raster_render.hip block_moments_lds,
+csrc/voxel_render.hip vfwd_item) against the same kernels built with the plain C++ statement of that arithmetic
+(-DR2_EXP_NO_CMPX -> r2_gaussian_amd/libr2hip_nocmpx.so, built by __graft_entry__.build()): identical results.  The variant
+library is loaded in a subprocess (R2HIP_LIB), the product in this one."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "r2_gaussian_amd", "libr2hip_nocmpx.so")
+
+_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+dev = torch.device("cuda:0")
+c = S.make_cloud(30000, seed=21)
+v = S.make_views(8, (160, 144))[3]
+h = Hh.hip_raster(c, v, dev)
+dL = S.make_pixel_grad(160, 144).numpy()
+g = Hh.hip_raster_backward(h, c, v, dL, dev)
+n, s, ctr = (48, 40, 56), (1.5, 1.25, 1.75), (0.0, 0.05, -0.05)
+hv = Hh.hip_voxel(c, n, s, ctr, dev)
+np.savez(sys.argv[1], color=h["color"], vol=hv["vol"], **g)
+"""
+
+
+def _run(tmp_path, name, lib):
+    out = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ)
+    env.pop("R2HIP_LIB", None)
+    if lib:
+        env["R2HIP_LIB"] = lib
+    r = subprocess.run([sys.executable, "-c", _SCRIPT % ROOT, out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+def test_exec_mask_asm_equals_the_plain_cxx_build(tmp_path):
+    if not os.path.exists(VARIANT):
+        pytest.skip("libr2hip_nocmpx.so not built (run __graft_entry__.build())")
+    a = _run(tmp_path, "product", None)
+    b = _run(tmp_path, "nocmpx", VARIANT)
+    for k in a.files:
+        assert a[k].shape == b[k].shape, k
+        scale = np.abs(a[k]).max()
+        assert np.abs(a[k].astype(np.float64) - b[k]).max() <= 1e-6 * scale, (k, np.abs(a[k] - b[k]).max(), scale)
