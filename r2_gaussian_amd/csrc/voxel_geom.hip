@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(1024) voxel_preprocess_small_kernel(
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key, float *__restrict__ cov3Ds,
     uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, uint32_t *__restrict__ first, uint4 *__restrict__ cube,
-    uint4 *__restrict__ surv, unsigned long long *counter /* persistent, zero between calls */, uint32_t *__restrict__ words,
+    uint32_t *__restrict__ order, uint4 *__restrict__ surv, unsigned long long *counter /* persistent, zero between calls */, uint32_t *__restrict__ words,
     uint32_t *__restrict__ mailbox, uint32_t seq)
 {
     const int idx = blockIdx.x * 1024 + threadIdx.x;
@@ -209,6 +209,7 @@ __global__ void __launch_bounds__(1024) voxel_preprocess_small_kernel(
         first[idx] = f;
         cube[idx] = make_uint4(f, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
                                (uint32_t)(hi.y - lo.y));
+        order[sv0 + bv + iv - 1u] = (uint32_t)idx;   // the compact list of visible ids (the geometry backward walks it)
         surv[sv0 + bv + iv - 1u] = make_uint4((uint32_t)idx, key,
                                                (uint32_t)lo.x | ((uint32_t)lo.y << 4) | ((uint32_t)lo.z << 8) | ((uint32_t)hi.x << 12) |
                                                    ((uint32_t)hi.y << 16) | ((uint32_t)hi.z << 20), f);
@@ -231,7 +232,7 @@ int launch_voxel_preprocess_small(const VoxelGeom &g, const VoxelGrid &v, int P,
 {
     voxel_preprocess_small_kernel<<<dim3((P + 1023) / 1024), dim3(1024), 0, s>>>(
         P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z, g.rec, g.depth_key,
-        g.cov3D, g.tiles_touched, g.ext, g.first, g.cube, surv, counter, g.host_words, mailbox, seq);
+        g.cov3D, g.tiles_touched, g.ext, g.first, g.cube, g.order, surv, counter, g.host_words, mailbox, seq);
     return 0;
 }
 
@@ -319,8 +320,68 @@ __device__ __forceinline__ void zero_culled_rows(float *__restrict__ a, size_t r
 //      fixed order -> deterministic, atomic-free (reference: 10 float atomicAdd per pair, VOX/backward.cu:359-370);
 //   2. moments -> dL/dmean3D_norm (x dVoxel, quirk Q4), dL/dconic3D, dL/dopacity;
 //   3. computeCov3DCUDA (VOX/backward.cu:86-177) + preprocessCUDA backward (VOX/backward.cu:180-213).
-__global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
+// Two launches: the zero rows of the culled Gaussians (every lane, unit-stride stores), then the real work over the COMPACT list
+// of visible ids -- `order[0 .. nvis)`, which every forward path leaves behind (depth order: hinted prefix / full permutation with
+// the culled ids last / the small-grid survivor list).  On the training loop's TV patch 2 % of the Gaussians are visible, spread
+// thinly over the waves: with one lane per Gaussian nearly every wave ran the whole chain below for one or two lanes.
+__global__ void __launch_bounds__(256) voxel_geom_backward_zero_kernel(
     int P, const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
+    float *__restrict__ dL_dconic3D, float *__restrict__ dL_dmean3D_norm, float *__restrict__ dL_dopacity,
+    float *__restrict__ dL_dmeans, float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot,
+    int visible_get_zero_scale_rot)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    // culled Gaussians: all-zero gradient rows (the reference relies on zero-filled tensors, SUB/voxelize_points.cu:130-136).
+    // The WAVE writes them: its 64 rows are one contiguous span of every output array, walked with unit-stride stores, each
+    // element zeroed iff its row's lane is culled
+    const bool in_range = idx < P;
+    const bool culled = in_range && (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0));
+    const unsigned long long cmask = __ballot(culled);
+    const unsigned long long all = __ballot(in_range);
+    const int lane = threadIdx.x & 63;
+    const size_t row0 = (size_t)(idx - lane);
+    if (cmask) {   // wave-uniform
+        zero_culled_rows<3>(dL_dmean3D_norm, row0, lane, cmask);
+        zero_culled_rows<3>(dL_dmeans, row0, lane, cmask);
+        zero_culled_rows<6>(dL_dconic3D, row0, lane, cmask);
+        zero_culled_rows<6>(dL_dcov, row0, lane, cmask);
+        zero_culled_rows<1>(dL_dopacity, row0, lane, cmask);
+    }
+    // scale / rotation gradients: zero for the culled rows, and for ALL rows when the covariance was given (cov3D_precomp)
+    const unsigned long long zmask = visible_get_zero_scale_rot ? all : cmask;
+    if (zmask) {
+        zero_culled_rows<3>(dL_dscale, row0, lane, zmask);
+        zero_culled_rows<4>(dL_drot, row0, lane, zmask);
+    }
+}
+
+// Small grids (nearly everything is culled): ALL rows are zeroed with plain wide stores -- the compact kernel that follows
+// overwrites the visible ones (ordered by the kernel boundary).  The predicated 4-byte version above moves 31 MB at ~2 TB/s.
+struct ZeroArrays {
+    float *p[7];
+    size_t n[7];   // floats
+};
+__global__ void __launch_bounds__(256) voxel_zero_all_rows_kernel(ZeroArrays z)
+{
+    const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, nt = (size_t)gridDim.x * 256u;
+#pragma unroll
+    for (int a = 0; a < 7; ++a) {
+        float *__restrict__ p = z.p[a];
+        if (p == nullptr) continue;
+        const size_t n = z.n[a];
+        const size_t head = min(n, (size_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u);   // floats before the first 16-byte boundary
+        float4 *__restrict__ p4 = reinterpret_cast<float4 *>(p + head);
+        const size_t n4 = (n - head) / 4;
+        for (size_t i = t; i < n4; i += nt) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < head) p[t] = 0.f;
+        const size_t tail0 = head + 4 * n4;
+        if (t < n - tail0) p[tail0 + t] = 0.f;
+    }
+}
+
+__global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
+    int P, const uint32_t *__restrict__ order, const uint32_t *__restrict__ words,
+    const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z,
     const float *__restrict__ cov3Ds, const float *__restrict__ scales, const float *__restrict__ rotations,
     float scale_modifier, VoxelGrid v, const float4 *__restrict__ rec, const uint32_t *__restrict__ first_inst,
     const uint32_t *__restrict__ tiles_touched, const float4 *__restrict__ part,
@@ -328,26 +389,15 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     float *__restrict__ dL_dmean3D_norm, float *__restrict__ dL_dopacity, float *__restrict__ dL_dmeans,
     float *__restrict__ dL_dcov, float *__restrict__ dL_dscale, float *__restrict__ dL_drot)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    // culled Gaussians: all-zero gradient rows (the reference relies on zero-filled tensors, SUB/voxelize_points.cu:130-136).
-    // The WAVE writes them: its 64 rows are one contiguous span of every output array, walked with unit-stride stores, each
-    // element zeroed iff its row's lane is culled (on the TV patch 98 % of the rows are: the per-lane version -- 26 strided
-    // 4-byte stores -- was the whole cost of this kernel there)
-    const bool in_range = idx < P;
-    const bool culled = in_range && (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0));
-    const unsigned long long cmask = __ballot(culled);
-    if (cmask) {   // wave-uniform
-        const int lane = threadIdx.x & 63;
-        const size_t row0 = (size_t)(idx - lane);
-        zero_culled_rows<3>(dL_dmean3D_norm, row0, lane, cmask);
-        zero_culled_rows<3>(dL_dmeans, row0, lane, cmask);
-        zero_culled_rows<6>(dL_dconic3D, row0, lane, cmask);
-        zero_culled_rows<6>(dL_dcov, row0, lane, cmask);
-        zero_culled_rows<1>(dL_dopacity, row0, lane, cmask);
-        zero_culled_rows<3>(dL_dscale, row0, lane, cmask);
-        zero_culled_rows<4>(dL_drot, row0, lane, cmask);
-    }
-    if (!in_range || culled) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    // number of list entries that can be visible: the hinted depth order / the small-grid path record it (DW_NVIS); the
+    // un-hinted orders are full permutations with the culled ids at the tail (DW_NVIS == 0: walk all of it)
+    const uint32_t nvis = words[DW_NVIS];
+    const int count = nvis ? (int)min(nvis, (uint32_t)P) : P;
+    if (j >= count) return;
+    const int idx = (int)order[j];
+    if ((uint32_t)idx >= (uint32_t)P) return;   // nothing visible at all: the list was never written (every row is a zero row)
+    if (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) return;
     const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
 
     // ---- 1. moments: S0, (Sx,Sy,Sz), (Sxx,Sxy,Sxz,Syy,Syz,Szz)
@@ -435,10 +485,7 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
         dL_dscale[3 * idx + 1] = ds[1];
         dL_dscale[3 * idx + 2] = ds[2];
         reinterpret_cast<float4 *>(dL_drot)[idx] = dq;
-    } else {
-        if (dL_dscale) { dL_dscale[3 * idx + 0] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f; }
-        if (dL_drot) reinterpret_cast<float4 *>(dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    }   // else (cov3D_precomp): the zero kernel has written the scale / rotation rows
 }
 
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
@@ -469,9 +516,19 @@ int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, co
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
                                hipStream_t s)
 {
+    if ((size_t)v.gx * v.gy * v.gz <= VOX_SMALL_MAX_TILES) {   // a patch: nearly every row is a zero row
+        const size_t Pz = (size_t)P;
+        const ZeroArrays z{{dL_dmean3D_norm, dL_dmean3D, dL_dconic3D, dL_dcov3D, dL_dopacity, dL_dscale, dL_drot},
+                           {3 * Pz, 3 * Pz, 6 * Pz, 6 * Pz, Pz, 3 * Pz, 4 * Pz}};
+        voxel_zero_all_rows_kernel<<<dim3(1024), dim3(256), 0, s>>>(z);
+    } else {
+        voxel_geom_backward_zero_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
+            P, radii_x, radii_y, radii_z, dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot,
+            (scales == nullptr || rotations == nullptr) ? 1 : 0);
+    }
     voxel_geom_backward_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(
-        P, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first, g.tiles_touched,
-        reinterpret_cast<const float4 *>(part), dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D,
+        P, g.order, g.host_words, radii_x, radii_y, radii_z, cov3D, scales, rotations, scale_modifier, v, g.rec, g.first,
+        g.tiles_touched, reinterpret_cast<const float4 *>(part), dL_dconic3D, dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D,
         dL_dscale, dL_drot);
     return 0;
 }

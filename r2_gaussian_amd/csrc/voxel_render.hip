@@ -369,9 +369,16 @@ template <bool NCONTRIB>
 __global__ void __launch_bounds__(512) voxel_combine_kernel(
     const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial,
     const uint32_t *__restrict__ partial_last, VoxelGrid v, float *__restrict__ out, uint32_t *__restrict__ n_contrib,
-    const uint2 *__restrict__ ranges, uint32_t short_min)
+    const uint2 *__restrict__ ranges, uint32_t short_min, VoxelPublish pub)
 {
     const uint32_t tile = blockIdx.x;
+    // side job (small-grid path): the lists move into the binning / image state for the backward; every workgroup takes a share
+    for (uint32_t i = blockIdx.x * 512u + threadIdx.x; i < pub.n; i += gridDim.x * 512u) {
+        if (i < pub.R) { pub.dst_plist[i] = pub.src_plist[i]; pub.dst_tiles[i] = pub.src_tiles[i]; }
+        if (i < pub.T) pub.dst_ranges[i] = pub.src_ranges[i];
+        if (i < pub.T + 1u) pub.dst_chunk_base[i] = pub.src_chunk_base[i];
+        if (i < pub.NW) pub.dst_work[i] = pub.src_work[i];
+    }
     if (!NCONTRIB && short_min) {   // tiles with a short list were rendered by voxel_render_short_kernel
         const uint2 rg = ranges[tile];
         if (rg.y != rg.x && rg.y - rg.x < short_min) return;
@@ -601,15 +608,27 @@ __global__ void __launch_bounds__(64) voxel_render_backward_kernel(
 }
 
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,
-                                float *out_volume, bool write_ncontrib, hipStream_t s)
+                                float *out_volume, bool write_ncontrib, hipStream_t s, bool no_short_kernel,
+                                const VoxelPublish *publish)
 {
     const uint32_t T = (uint32_t)v.gx * v.gy * v.gz;
+    const VoxelPublish pub = publish ? *publish : VoxelPublish{};
+    if (no_short_kernel) {
+        // small grids (voxel_small.hip): the work list covers every non-empty tile (no short-list exemption), so the item kernel
+        // and the combine pass do it all; the combine launch also publishes the lists
+        if (im.NW > 0)
+            voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+        voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
+                                                                  im.n_contrib, im.ranges, 0u, pub);
+        return 0;
+    }
     if (write_ncontrib) {
         if (im.NW > 0)
             voxel_render_forward_debug_kernel<<<dim3((unsigned)im.NW), dim3(512), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, v, im.partial, im.partial_last);
         voxel_combine_kernel<true><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
-                                                                 im.n_contrib, im.ranges, 0u);
+                                                                 im.n_contrib, im.ranges, 0u, pub);
         return 0;
     }
     if (im.NW > 0) {
@@ -620,7 +639,7 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
             im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
     }
     voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
-                                                              im.n_contrib, im.ranges, im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u);
+                                                              im.n_contrib, im.ranges, im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u, pub);
     return 0;
 }
 

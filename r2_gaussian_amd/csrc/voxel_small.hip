@@ -223,25 +223,12 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
         s_counts[tid] = (uint32_t)tid < T ? __hip_atomic_load(&tmp.counts[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
     __syncthreads();
     // tile ranges (empty tiles stay (0, 0) like the reference's zero-filled array, VOX/voxelizer_impl.cu:289) + work list
-    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_chunk_for(R), nullptr, min_len,
+    // no short-list exemption: the item kernel's own short-list branch serves the few short tiles of a patch, which spares the
+    // short-list kernel's launch.  (ONE item per tile -- no partial sums at all -- was measured: the 128 long-running workgroups
+    // took 38 us instead of 23.)
+    (void)min_len;
+    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_chunk_for(R), nullptr, 0u,
                                                             tmp.cap_work});
-}
-
-// the lists move from the geometry state's temp into the binning / image state, where the backward and the introspection find
-// them (behind the forward's render kernels: off its critical path)
-__global__ void __launch_bounds__(256) voxel_small_publish_kernel(SmallTmp tmp, uint32_t R, uint32_t T, uint32_t NW,
-                                                                  uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles,
-                                                                  uint2 *__restrict__ ranges, uint32_t *__restrict__ chunk_base,
-                                                                  uint4 *__restrict__ work)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < R) {
-        point_list[i] = tmp.plist[i];
-        tiles[i] = tmp.tiles[i];
-    }
-    if (i < T) ranges[i] = tmp.ranges[i];
-    if (i < T + 1u) chunk_base[i] = tmp.chunk_base[i];
-    if (i < NW && i < tmp.cap_work) work[i] = tmp.work[i];
 }
 
 // one 64-byte device word per host thread: the survivor / row counter of the small-grid preprocess, zero between calls
@@ -320,18 +307,17 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false);
     { StageScope t(ST_VOX_RENDER_FWD, s);
-    VoxelBinning b2 = bin;          // the render kernels read the lists where they were built
+    VoxelBinning b2 = bin;          // the render kernels read the lists where they were built ...
     VoxelImage i2 = img;
     b2.point_list = tmp.plist;
     i2.ranges = tmp.ranges;
     i2.chunk_base = tmp.chunk_base;
     i2.work_tile = tmp.work;
-    launch_voxel_render_forward(geom, b2, i2, v, out_volume, false, s); }
-    { StageScope t(ST_VOX_RANGES, s);
-    const uint32_t n = (uint32_t)std::max<size_t>(std::max<size_t>(R, T + 1), NW);
-    voxel_small_publish_kernel<<<dim3((n + 255u) / 256u), dim3(256), 0, s>>>(tmp, (uint32_t)R, (uint32_t)T, (uint32_t)img.NW,
-                                                                            bin.point_list, bin.tiles, img.ranges, img.chunk_base,
-                                                                            img.work_tile); }
+    // ... and the last of them also moves them into the binning / image state, where the backward and the introspection look
+    VoxelPublish pub{tmp.plist, tmp.tiles, tmp.chunk_base, tmp.ranges, tmp.work, bin.point_list, bin.tiles, img.chunk_base, img.ranges,
+                     img.work_tile, (uint32_t)R, (uint32_t)T, (uint32_t)NW, 0u};
+    pub.n = std::max(std::max(pub.R, pub.T + 1u), pub.NW);
+    launch_voxel_render_forward(geom, b2, i2, v, out_volume, false, s, /*no_short_kernel=*/true, &pub); }
     R2_HIP_TRY(hipGetLastError());
     return (int)num_rendered;
 }

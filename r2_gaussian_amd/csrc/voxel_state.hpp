@@ -174,8 +174,20 @@ int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, co
                                hipStream_t s);
 // tile lists shorter than this get no forward work item (a light kernel renders them); 0 in debug mode
 uint32_t voxel_short_list_min(bool debug);
+// Optional side job of the forward's last kernel (small-grid path): move the lists from where they were built into the binning /
+// image state (n == 0: nothing to do).
+struct VoxelPublish {
+    const uint32_t *src_plist, *src_tiles, *src_chunk_base;
+    const uint2 *src_ranges;
+    const uint4 *src_work;
+    uint32_t *dst_plist, *dst_tiles, *dst_chunk_base;
+    uint2 *dst_ranges;
+    uint4 *dst_work;
+    uint32_t R, T, NW, n;   // n = max(R, T + 1, NW)
+};
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,
-                                float *out_volume, bool write_ncontrib, hipStream_t s);
+                                float *out_volume, bool write_ncontrib, hipStream_t s, bool no_short_kernel = false,
+                                const VoxelPublish *publish = nullptr);
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
                                  const float *dL_dvol, hipStream_t s);
 
