@@ -290,16 +290,17 @@ __global__ void __launch_bounds__(256) zero_kernel(uint4 *__restrict__ p, size_t
     R2_TS_AT(order, 1);
 }
 
-// every visible key takes its slot: bucket base + ticket.  One 16-byte record {key, id, instances, bucket} per slot.
+// every visible key takes its slot: bucket base + ticket.  One 16-byte record {key, id, instances, bucket} per slot
+// (RECT: n_inst = the producer's payload words, tile rectangles that encode the instance count -- depth_rect_count).
 __global__ void __launch_bounds__(256) fast_place_kernel(uint32_t n, const uint32_t *__restrict__ keys, const uint32_t *__restrict__ n_inst,
                                                          const uint2 *__restrict__ bt, const uint32_t *__restrict__ incl_c,
-                                                         uint4 *__restrict__ slot)
+                                                         uint4 *__restrict__ slot, bool rect)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     R2_TS_AT(order, 6);
     if (i >= n) return;
     const uint32_t k = keys[i], m = n_inst[i];
-    if (k == CULLED_KEY || m == 0u) return;
+    if (k == CULLED_KEY || (!rect && m == 0u)) return;   // (a rectangle word may be 0: one tile at the origin)
     const uint2 b = bt[i];
     const uint32_t beg = b.x ? incl_c[b.x - 1u] : 0u;
     slot[beg + b.y] = make_uint4(k, i, m, b.x);
@@ -311,9 +312,11 @@ __global__ void __launch_bounds__(256) fast_place_kernel(uint32_t n, const uint3
 // staged in LDS, two dependent round trips instead of three, 1.4 us for the median workgroup -- but the clamped end buckets of
 // a hinted range routinely hold up to MAX_BUCKET keys, and the lane that owns one ranks n^2 pairs alone: 90-140 us for that
 // workgroup.  A lane per slot spreads exactly those buckets over many lanes.)
+template <bool RECT>
 __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, const uint4 *__restrict__ slot,
                                                         const uint32_t *__restrict__ incl_c, const uint32_t *__restrict__ incl_t,
-                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ offsets)
+                                                        uint32_t *__restrict__ order, uint32_t *__restrict__ offsets,
+                                                        uint4 *__restrict__ sorted)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     R2_TS_AT(order, 8);
@@ -333,10 +336,12 @@ __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, co
         const uint4 o = slot[q];
         const bool lt = o.x < me.x || (o.x == me.x && o.y < me.y);
         rank += lt ? 1u : 0u;
-        before += lt ? o.z : 0u;
+        before += lt ? (RECT ? depth_rect_count(o.z) : o.z) : 0u;
     }
+    const uint32_t incl = tbeg + before + (RECT ? depth_rect_count(me.z) : me.z);   // inclusive, like the scan of the un-hinted path
     order[beg + rank] = me.y;
-    offsets[beg + rank] = tbeg + before + me.z;   // inclusive, like the scan of the un-hinted path
+    offsets[beg + rank] = incl;
+    if (RECT) sorted[beg + rank] = make_uint4(me.y, incl, me.z, 0u);
     R2_TS_AT(order, 9);
 }
 
@@ -352,6 +357,8 @@ struct Temp {
     uint2 *bt;            // [P]
     uint32_t *wgmm;       // [4 * (P/256 + 1)]
     uint2 *partial2;      // [nb/4096 + 1]
+    uint32_t *payload;    // [P]    hinted path, optional (DepthReg::payload)
+    uint4 *sorted;        // [P]    hinted path, optional: sorted records
     char *scan_temp;
     size_t scan_bytes, zero_bytes, bytes;
     static Temp carve(char *chunk, size_t P, size_t nb)
@@ -370,6 +377,8 @@ struct Temp {
         t.bt = b.take<uint2>(P);
         t.wgmm = b.take<uint32_t>(4 * (P / 256 + 2));
         t.partial2 = b.take<uint2>(nb / S2_TILE + 2);
+        t.payload = b.take<uint32_t>(P);
+        t.sorted = b.take<uint4>(P);
         t.scan_bytes = scan_temp_bytes((int)nb);
         t.scan_temp = b.take<char>(t.scan_bytes);
         t.bytes = b.total();
@@ -440,10 +449,14 @@ int depth_order_buckets(void *temp, size_t temp_bytes, const uint32_t *keys, uin
 }
 
 // ---- hinted path, host side
-DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h)
+DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, bool with_rects)
 {
     const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P));
-    return DepthReg{t.ct, t.bt, t.wgmm, h};
+    return DepthReg{t.ct, t.bt, t.wgmm, h, with_rects ? t.payload : nullptr};
+}
+const uint4 *depth_order_sorted_records(void *temp, size_t P)
+{
+    return Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P)).sorted;
 }
 
 int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s)
@@ -460,12 +473,13 @@ int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, ui
 }
 
 int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
-                            uint32_t *offsets, hipStream_t s)
+                            uint32_t *offsets, hipStream_t s, bool rects)
 {
     const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P));
     const unsigned grid = (unsigned)((P + 255) / 256);
-    fast_place_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)P, keys, n_inst, t.bt, t.incl, t.slot);
-    fast_rank_kernel<<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets);
+    fast_place_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)P, keys, rects ? t.payload : n_inst, t.bt, t.incl, t.slot, rects);
+    if (rects) fast_rank_kernel<true><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, t.sorted);
+    else fast_rank_kernel<false><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, nullptr);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -135,7 +135,15 @@ struct DepthReg {
     uint2 *bt;              // [P]  {bucket, ticket} of every visible key
     uint32_t *wgmm;         // [4 * producer workgroups] key extrema {pmax, ~pmin, nmax, ~nmin} per workgroup
     DepthHint h;
+    uint32_t *payload;      // [P] optional: one word per visible key that travels with it into the sorted records (rasterizer: its
+                            //     tile rectangle, depth_rect_pack), which then also gives its instance count.  nullptr = off
 };
+// tile rectangle of a Gaussian in one word: x0 | y0 << 8 | (w - 1) << 16 | (h - 1) << 24 (grids up to 256 x 256 tiles, w, h >= 1)
+__host__ __device__ __forceinline__ uint32_t depth_rect_pack(int x0, int y0, int w, int h)
+{
+    return (uint32_t)x0 | (uint32_t)y0 << 8 | (uint32_t)(w - 1) << 16 | (uint32_t)(h - 1) << 24;
+}
+__host__ __device__ __forceinline__ uint32_t depth_rect_count(uint32_t r) { return (((r >> 16) & 0xFFu) + 1u) * ((r >> 24) + 1u); }
 __device__ __forceinline__ uint32_t hinted_bucket(uint32_t key, const DepthHint &h)
 {
     const bool neg = (key >> 31) != 0u;
@@ -158,12 +166,14 @@ __device__ __forceinline__ uint2 depth_register_key(const DepthReg &r, uint32_t 
     const unsigned long long old = atomicAdd(&r.ct[b], (1ull << 32) | (unsigned long long)n_inst);
     return make_uint2(b, (uint32_t)(old >> 32));
 }
-__device__ __forceinline__ void depth_register_end(const DepthReg &r, uint32_t idx, uint32_t key, uint2 bucket_ticket)
+__device__ __forceinline__ void depth_register_end(const DepthReg &r, uint32_t idx, uint32_t key, uint2 bucket_ticket,
+                                                   uint32_t payload = 0u)
 {
     if (r.ct == nullptr) return;   // kernel-uniform
     uint32_t m0 = 0u, m1 = 0u, m2 = 0u, m3 = 0u;
     if (key != DEPTH_CULLED_KEY) {
         r.bt[idx] = bucket_ticket;
+        if (r.payload != nullptr) r.payload[idx] = payload;
         if (key >> 31) { m2 = key; m3 = ~key; }
         else { m0 = key; m1 = ~key; }
     }
@@ -193,13 +203,16 @@ uint4 *depth_order_slots(void *temp, size_t P);   // [P] 16-byte records of the 
 // call, P changed, hints switched off): the caller then runs the un-hinted path.
 bool depth_hint_lookup(int which, size_t P, DepthHint *out);
 void depth_hint_update(int which, size_t P, const uint32_t words[DW_COUNT], bool overflowed);
-DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h);
+DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, bool with_rects = false);
+// with_rects: 16-byte records in (key, id) order, {id, inclusive instance offset, rectangle, 0} for j < nvis, left by
+// depth_order_fast_finish(..., rects = true) -- everything the emission kernel needs in one coalesced load
+const uint4 *depth_order_sorted_records(void *temp, size_t P);
 // after the producer kernel: dual prefix sum (-> DW_TOTAL, DW_NVIS, DW_OVERFLOW, key extrema are final after this launch
 // pair: its last workgroup posts all DW_COUNT words + seq to the host mailbox, see host_mailbox_arm) ...
 int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s);
 // ... then placement + ranking: order[j] (j < nvis) = ids in (key, id) order, offsets[j] = inclusive instance offsets
 int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
-                            uint32_t *offsets, hipStream_t s);
+                            uint32_t *offsets, hipStream_t s, bool rects = false);
 struct WorkListOut;
 bool sort_is_single_pass(int end_bit);
 // single-pass (<= 12 key bits) stable sort of instances by tile: ids_out[pos] = ids[index], inv_out[index] = pos,

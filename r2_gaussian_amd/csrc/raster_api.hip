@@ -59,7 +59,10 @@ static int raster_forward_impl(
     const bool hinted = depth_hint_lookup(0, (size_t)PV, &hint);
     const uint32_t pre_wgs = (uint32_t)((PV + 255) / 256);
     DepthReg reg{};
-    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)PV, hint);
+    // sorted records for the emission kernel: the preprocess hands each key's tile rectangle (one word) to the depth order
+    static const bool rects_on = [] { const char *e = getenv("R2_SORTED_RECORDS"); return !(e && e[0] == '0'); }();
+    const bool rects = hinted && rects_on && gx <= 256 && gy <= 256;
+    if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)PV, hint, rects);
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess(geom, P, V, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrices,
                              projmatrices, width, height, tan_fovx, tan_fovy, mode, radii, host_words + DW_USER, reg, true, s); }
@@ -73,7 +76,7 @@ static int raster_forward_impl(
         rc = depth_order_fast_scan(geom.dorder_temp, (size_t)PV, pre_wgs, mailbox, mailbox_seq, s); }
         if (rc) return rc;
         { StageScope t(ST_RAS_DEPTHSORT, s);
-        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)PV, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s); }
+        rc = depth_order_fast_finish(geom.dorder_temp, (size_t)PV, geom.depth_key, geom.tiles_touched, geom.order, geom.offsets, s, rects); }
         if (rc) return rc;
         rc = host_mailbox_wait(mailbox_seq, hw, DW_COUNT, s);   // the GPU places + ranks while the host waits for the words
         if (rc) return rc;
@@ -130,7 +133,8 @@ static int raster_forward_impl(
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
         { StageScope t(ST_RAS_DUPLICATE, s);
-        launch_raster_duplicate(geom, bin, P, V, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
+        if (rects && !full_order) launch_raster_duplicate_sorted(geom, bin, P, V, width, height, host_words + DW_NVIS, s);
+        else launch_raster_duplicate(geom, bin, P, V, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)

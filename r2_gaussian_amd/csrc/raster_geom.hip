@@ -72,7 +72,7 @@ __device__ __forceinline__ void raster_preprocess_one(
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
-    uint32_t *__restrict__ thin_flag, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
+    uint32_t *__restrict__ thin_flag, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out, uint32_t &rect_out)
 {
     key_out = DEPTH_CULLED_KEY;
     radii[idx] = 0;
@@ -127,6 +127,7 @@ __device__ __forceinline__ void raster_preprocess_one(
     key_out = __float_as_uint(p_view.z);
     // hinted depth order: the key goes straight into its bucket; the ticket comes back while the record is computed
     bt_out = depth_register_key(reg, key_out, (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0));
+    rect_out = depth_rect_pack(x0, y0, x1 - x0, y1 - y0);   // (meaningful for grids up to 256 x 256 tiles: the caller checks)
     // 32-byte render record: centre, conic pre-scaled so that the render kernels evaluate
     // alpha = opacity*mu*exp(power) as exp2(A2 dx^2 + B2 dx dy + C2 dy^2 + L), L = log2(opacity*mu), and the
     // half-extents (hx, hy) of the bounding box of the set where alpha can reach the reference's 1e-5 cut-off
@@ -170,14 +171,15 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     R2_TS_AT(geom, 0);
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
+    uint32_t rect = 0u;
     if (idx < P * V) {
         const int v = V == 1 ? 0 : idx / P;
         raster_preprocess_one(idx, idx - v * P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, views + 16 * v,
                               projs + 16 * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds,
-                              tiles_touched, op_mu, thin_flag, reg, key, bt);
+                              tiles_touched, op_mu, thin_flag, reg, key, bt, rect);
     }
     R2_TS_AT(geom, 1);
-    depth_register_end(reg, (uint32_t)idx, key, bt);
+    depth_register_end(reg, (uint32_t)idx, key, bt, rect);
     R2_TS_AT(geom, 2);
 }
 
@@ -256,6 +258,51 @@ __global__ void __launch_bounds__(256) raster_duplicate_kernel(
             const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
             const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
             // the views' tile grids are stacked: view v = o_id / Pview owns tile rows [v * gy, (v + 1) * gy)
+            const int vrow = multi_view ? (int)(o_id / (uint32_t)Pview) * gy : 0;
+            tiles[k] = (uint32_t)((vrow + ty) * gx + tx);
+            vals[k] = o_id;
+        }
+    }
+    R2_TS_AT(geom, 5);
+}
+
+// Same emission from the sorted records of the hinted depth order ({id, inclusive offset, tile rectangle} per sorted position,
+// depth_order.hip): ONE coalesced load per lane instead of the order -> radii / record gathers (13.6 -> 8.8 us at 300k / 512^2).
+__global__ void __launch_bounds__(256) raster_duplicate_sorted_kernel(
+    int Pview, const uint4 *__restrict__ sorted, int gy, uint32_t *__restrict__ first, uint32_t *__restrict__ tiles,
+    uint32_t *__restrict__ vals, const uint32_t *__restrict__ nvis, int gx, bool multi_view)
+{
+    R2_TS_AT(geom, 4);
+    const int P = (int)*nvis;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave_first = j - lane;
+    if (wave_first >= P) return;
+    const uint4 r = sorted[min(j, P - 1)];
+    const uint32_t id = r.x;
+    const int rw = (int)((r.z >> 16) & 0xFFu) + 1;
+    const uint32_t incl = r.y, excl = j < P ? r.y - depth_rect_count(r.z) : r.y;
+    const int x0 = (int)(r.z & 0xFFu), y0 = (int)((r.z >> 8) & 0xFFu);
+    if (j < P) first[id] = excl;   // where this Gaussian's instance run starts: the backward's scratch rows
+    const uint32_t wbeg = __shfl(excl, 0);
+    const int last_lane = min(63, P - 1 - wave_first);
+    const uint32_t wend = __shfl(incl, last_lane);
+    for (uint32_t base = wbeg; base < wend; base += 64) {
+        const uint32_t k = base + lane;
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int probe = lo + step;
+            const uint32_t e = __shfl(excl, probe & 63);
+            if (probe <= last_lane && e <= k) lo = probe;
+        }
+        const uint32_t o_excl = __shfl(excl, lo);
+        const int o_x0 = __shfl(x0, lo), o_y0 = __shfl(y0, lo), o_rw = __shfl(rw, lo);
+        const uint32_t o_id = __shfl(id, lo);
+        if (k < wend) {
+            const uint32_t local = k - o_excl;
+            const int ty = o_y0 + (int)(local / (uint32_t)o_rw);
+            const int tx = o_x0 + (int)(local % (uint32_t)o_rw);
             const int vrow = multi_view ? (int)(o_id / (uint32_t)Pview) * gy : 0;
             tiles[k] = (uint32_t)((vrow + ty) * gx + tx);
             vals[k] = o_id;
@@ -532,6 +579,16 @@ int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P, 
     const int PV = P * V;
     raster_duplicate_kernel<<<dim3((PV + 255) / 256), dim3(256), 0, s>>>(PV, P, g.rec, g.order, g.offsets, radii, gx, gy,
                                                                          g.first, b.tiles_unsorted, b.vals_unsorted, nvis);
+    return 0;
+}
+
+int launch_raster_duplicate_sorted(const RasterGeom &g, const RasterBinning &b, int P, int V, int W, int H, const uint32_t *nvis,
+                                   hipStream_t s)
+{
+    const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
+    const int PV = P * V;
+    raster_duplicate_sorted_kernel<<<dim3((PV + 255) / 256), dim3(256), 0, s>>>(P, depth_order_sorted_records(g.dorder_temp, (size_t)PV), gy,
+                                                                                g.first, b.tiles_unsorted, b.vals_unsorted, nvis, gx, V > 1);
     return 0;
 }
 

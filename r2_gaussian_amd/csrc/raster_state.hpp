@@ -190,6 +190,9 @@ int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, c
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P /* per view */, int V, const int *radii, int W, int H,
                             const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);
+// emission from the slab depth order's sorted records (hinted path; nvis = device word with the number of visible instances)
+int launch_raster_duplicate_sorted(const RasterGeom &g, const RasterBinning &b, int P, int V, int W, int H, const uint32_t *nvis,
+                                   hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 int launch_raster_geom_backward(int P /* per view */, int V, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
