@@ -561,9 +561,21 @@ def main():
         tc = time.perf_counter() - tc
         nthr = int(O.lib().r2o_num_threads())
         cpu = {"value": round(1.0 / tc, 4), "unit": "views/s", "cores": nthr, "kind": "port",
-               "what": "C/OpenMP port of the reference algorithm (oracle/r2_oracle.c), %d threads; NOT the pure-PyTorch "
-                       "evaluation north_star mentions -- a stronger CPU baseline" % nthr,
+               "what": "C/OpenMP port of the reference algorithm (oracle/r2_oracle.c), %d threads: a stronger CPU baseline than "
+                       "the pure-PyTorch evaluation north_star mentions, which is reported beside it (pure_pytorch_config_a)" % nthr,
                "sample": "1 view fwd+bwd of the same workload (%dk Gaussians, %d^2, R=%d)" % (P // 1000, HW, st["num_rendered"])}
+        # the pure-PyTorch CPU evaluation north_star names: BASELINE configs[0] (5k Gaussians, 64^2, 10 views + a 64^3 query),
+        # forward + autograd backward, run fully (oracle/torch_baseline.py, checked against the oracle in tests/)
+        try:
+            from oracle import torch_baseline as TB
+            TB.config_a(n_gaussians=500, detector=32, n_views=1, n_voxel=16)   # warm torch's thread pool
+            ta, na, _imgs, _vol = TB.config_a()
+            cpu["pure_pytorch_config_a"] = {
+                "seconds": round(ta, 3), "views_per_s": round(na / ta, 3), "threads": torch.get_num_threads(),
+                "what": "oracle/torch_baseline.py: 5k Gaussians, 64^2 detector, 10 views forward + autograd backward, "
+                        "plus one 64^3 volume query forward + backward; float32, tile-exact lists"}
+        except Exception as ex:   # a reported extra: never fails the bench line
+            cpu["pure_pytorch_config_a"] = {"error": str(ex)[:200]}
         s0 = settings[0]
         with torch.no_grad():
             Rg, color, radii, gb, bb, ib = _C.rasterize_gaussians(xyz, dens, scal, rot, 1.0, e, s0.viewmatrix, s0.projmatrix,
