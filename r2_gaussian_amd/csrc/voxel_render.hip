@@ -91,7 +91,8 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
 #ifndef R2_VFWD_WGS
 #define R2_VFWD_WGS 4
 #endif
-__global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
+__device__ __forceinline__ void vfwd_item_body(
+    const uint32_t bid /* workgroup index among the item workgroups */,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
     VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
@@ -103,8 +104,8 @@ __global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
     // neighbours that share most of their Gaussians) go to one XCD, so their record gathers hit that XCD's L2; the
     // runs are dealt round-robin over the 8 XCDs, which keeps the dense middle of the volume spread over all of them.
     const uint32_t nhalf = 2u * chunk_base[T];
-    const uint32_t seq = blockIdx.x >> 3;
-    const uint32_t hb = ((seq >> 7) * 8u + (blockIdx.x & 7u)) * 128u + (seq & 127u);
+    const uint32_t seq = bid >> 3;
+    const uint32_t hb = ((seq >> 7) * 8u + (bid & 7u)) * 128u + (seq & 127u);
     if (hb >= nhalf) return;
     const uint32_t w = hb >> 1;
     const int half = (int)(hb & 1u);
@@ -255,6 +256,14 @@ __global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
     }
 }
 
+__global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
+    VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
+{
+    vfwd_item_body(blockIdx.x, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
+}
+
 // Short tile lists (fewer than VFWD_MIN_STEP entries: 71 % of the non-empty tiles of a 256^3 query, 3 % of the instances).
 // They get no work item of the kernel above (launch_build_work(min_len)); here ONE WAVE renders a whole tile with no
 // accumulators and no LDS: lane j gathers entry j's record, the wave then takes the entries in list order, pulls an
@@ -265,11 +274,12 @@ __device__ __forceinline__ float lane_bcast(float x, int j)
 {
     return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(x), j));
 }
-__global__ void __launch_bounds__(256) voxel_render_short_kernel(
+__device__ __forceinline__ void vfwd_short_body(
+    const uint32_t bid,
     const uint2 *__restrict__ ranges, uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
     const float4 *__restrict__ ext, VoxelGrid v, float *__restrict__ out)
 {
-    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t tile = bid * 4u + (threadIdx.x >> 6);
     if (tile >= T) return;
     const uint2 rg = ranges[tile];
     const int n = (int)(rg.y - rg.x);
@@ -311,6 +321,26 @@ __global__ void __launch_bounds__(256) voxel_render_short_kernel(
         const int ox = tx * TILE3D + sl;
         if (ox < v.nx && oy < v.ny && oz < v.nz) out[((size_t)ox * v.ny + oy) * v.nz + oz] = sum[sl];
     }
+}
+
+__global__ void __launch_bounds__(256) voxel_render_short_kernel(
+    const uint2 *__restrict__ ranges, uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+    const float4 *__restrict__ ext, VoxelGrid v, float *__restrict__ out)
+{
+    vfwd_short_body(blockIdx.x, ranges, T, point_list, rec, ext, v, out);
+}
+
+// Both in ONE launch: the item workgroups first (the long ones), the short-list workgroups behind them start while the
+// item tail drains (0.668 -> 0.660 ms at 256^3).  (Measured and left out: short groups interleaved evenly among the item
+// groups, so that latency-bound and arithmetic waves mix for the whole kernel: 0.685 ms -- the item workgroups lose the
+// neighbourhood of their list order in time.)
+__global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_both_kernel(
+    const uint32_t item_blocks, const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base,
+    const uint4 *__restrict__ work_tile, uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+    const float4 *__restrict__ ext, VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
+{
+    if (blockIdx.x < item_blocks) vfwd_item_body(blockIdx.x, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
+    else vfwd_short_body(blockIdx.x - item_blocks, ranges, T, point_list, rec, ext, v, out);
 }
 
 // Debug-mode kernel (voxel-parallel): also tracks n_contrib, which only `debug` callers read back.
@@ -633,10 +663,17 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
     }
     if (im.NW > 0) {
         // short lists: one wave per tile (the work list holds no item for them, see voxel_short_list_min())
-        voxel_render_short_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(im.ranges, T, b.point_list, g.rec, g.ext, v, out_volume);
         // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
-        voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
-            im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+        const unsigned item_blocks = (unsigned)(((2 * im.NW + 1023) / 1024) * 1024);
+        static const bool split = [] { const char *e = getenv("R2_VOXEL_SPLIT_SHORT"); return e && e[0] == '1'; }();
+        if (split) {
+            voxel_render_short_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(im.ranges, T, b.point_list, g.rec, g.ext, v, out_volume);
+            voxel_render_forward_kernel<<<dim3(item_blocks), dim3(256), 0, s>>>(
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+        } else {
+            voxel_render_forward_both_kernel<<<dim3(item_blocks + (T + 3) / 4), dim3(256), 0, s>>>(
+                item_blocks, im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
+        }
     }
     voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
                                                               im.n_contrib, im.ranges, im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u, pub);
