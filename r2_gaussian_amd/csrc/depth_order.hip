@@ -316,7 +316,7 @@ template <bool RECT>
 __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, const uint4 *__restrict__ slot,
                                                         const uint32_t *__restrict__ incl_c, const uint32_t *__restrict__ incl_t,
                                                         uint32_t *__restrict__ order, uint32_t *__restrict__ offsets,
-                                                        uint4 *__restrict__ sorted)
+                                                        uint4 *__restrict__ sorted, uint32_t *__restrict__ owners, uint32_t owners_cap)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     R2_TS_AT(order, 8);
@@ -341,7 +341,13 @@ __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, co
     const uint32_t incl = tbeg + before + (RECT ? depth_rect_count(me.z) : me.z);   // inclusive, like the scan of the un-hinted path
     order[beg + rank] = me.y;
     offsets[beg + rank] = incl;
-    if (RECT) sorted[beg + rank] = make_uint4(me.y, incl, me.z, 0u);
+    if (RECT) {
+        sorted[beg + rank] = make_uint4(me.y, incl, me.z, 0u);
+        // owner of every TILE_SORT_GRANULE-th instance (a Gaussian emits ~4 instances: one lane in a hundred writes one entry)
+        const uint32_t excl = incl - depth_rect_count(me.z);
+        for (uint32_t q = (excl + TILE_SORT_GRANULE - 1u) / TILE_SORT_GRANULE; q * TILE_SORT_GRANULE < incl && q < owners_cap; ++q)
+            owners[q] = beg + rank;
+    }
     R2_TS_AT(order, 9);
 }
 
@@ -359,6 +365,7 @@ struct Temp {
     uint2 *partial2;      // [nb/4096 + 1]
     uint32_t *payload;    // [P]    hinted path, optional (DepthReg::payload)
     uint4 *sorted;        // [P]    hinted path, optional: sorted records
+    uint32_t *owners;     // [P + 4096] ... and the owners of every TILE_SORT_GRANULE-th instance
     char *scan_temp;
     size_t scan_bytes, zero_bytes, bytes;
     static Temp carve(char *chunk, size_t P, size_t nb)
@@ -379,6 +386,7 @@ struct Temp {
         t.partial2 = b.take<uint2>(nb / S2_TILE + 2);
         t.payload = b.take<uint32_t>(P);
         t.sorted = b.take<uint4>(P);
+        t.owners = b.take<uint32_t>(P + 4096);
         t.scan_bytes = scan_temp_bytes((int)nb);
         t.scan_temp = b.take<char>(t.scan_bytes);
         t.bytes = b.total();
@@ -472,14 +480,21 @@ int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, ui
     return 0;
 }
 
+const uint32_t *depth_order_granule_owners(void *temp, size_t P, uint32_t *cap)
+{
+    *cap = (uint32_t)(P + 4096);
+    return Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P)).owners;
+}
+
 int depth_order_fast_finish(void *temp, size_t P, const uint32_t *keys, const uint32_t *n_inst, uint32_t *order,
                             uint32_t *offsets, hipStream_t s, bool rects)
 {
     const Temp t = Temp::carve(reinterpret_cast<char *>(temp), P, (size_t)1 << log_buckets(P));
     const unsigned grid = (unsigned)((P + 255) / 256);
     fast_place_kernel<<<dim3(grid), dim3(256), 0, s>>>((uint32_t)P, keys, rects ? t.payload : n_inst, t.bt, t.incl, t.slot, rects);
-    if (rects) fast_rank_kernel<true><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, t.sorted);
-    else fast_rank_kernel<false><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, nullptr);
+    if (rects) fast_rank_kernel<true><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, t.sorted, t.owners,
+                                                                       (uint32_t)(P + 4096));
+    else fast_rank_kernel<false><<<dim3(grid), dim3(256), 0, s>>>(t.ctrl, t.slot, t.incl, t.incl_t, order, offsets, nullptr, nullptr, 0u);
     R2_HIP_TRY(hipGetLastError());
     return 0;
 }

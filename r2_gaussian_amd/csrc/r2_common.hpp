@@ -207,6 +207,9 @@ DepthReg depth_order_reg(void *temp, size_t P, const DepthHint &h, bool with_rec
 // with_rects: 16-byte records in (key, id) order, {id, inclusive instance offset, rectangle, 0} for j < nvis, left by
 // depth_order_fast_finish(..., rects = true) -- everything the emission kernel needs in one coalesced load
 const uint4 *depth_order_sorted_records(void *temp, size_t P);
+// ... and, per TILE_SORT_GRANULE instances, the sorted position of the Gaussian that owns instance q * TILE_SORT_GRANULE
+// (entries q < *cap only): lets a kernel that works by OUTPUT range find its Gaussians without a search
+const uint32_t *depth_order_granule_owners(void *temp, size_t P, uint32_t *cap);
 // after the producer kernel: dual prefix sum (-> DW_TOTAL, DW_NVIS, DW_OVERFLOW, key extrema are final after this launch
 // pair: its last workgroup posts all DW_COUNT words + seq to the host mailbox, see host_mailbox_arm) ...
 int depth_order_fast_scan(void *temp, size_t P, uint32_t producer_workgroups, uint32_t *mailbox, uint32_t seq, hipStream_t s);
@@ -219,7 +222,18 @@ bool sort_is_single_pass(int end_bit);
 // *counts_out = per-tile instance counts (device pointer into temp)
 int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
                              uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s,
-                             const struct WorkListOut *work_out = nullptr /* also build tile ranges + work list */);
+                             const struct WorkListOut *work_out = nullptr /* also build tile ranges + work list */,
+                             bool hist_ready = false /* the per-tile histograms are in place (tile_sort_plan) */);
+// layout of the single-pass tile sort's per-tile digit histograms, for a key producer that builds them itself
+struct TileSortPlan {
+    uint32_t tile_keys;   // keys per sort tile (a multiple of TILE_SORT_GRANULE)
+    uint32_t ntiles;
+    int bits;             // radix = 1 << bits digit values (the whole key)
+    uint32_t *H;          // [ntiles][1 << bits]
+    uint32_t *skip;       // skip[0] must be set to 0
+};
+constexpr uint32_t TILE_SORT_GRANULE = 512;
+bool tile_sort_plan(void *temp, size_t temp_bytes, size_t n, int end_bit, TileSortPlan *out);
 // tiles[k] = t for k in ranges[t] (the backward's per-instance tile id when the sort did not scatter the keys);
 int fill_tiles_from_ranges(const uint2 *ranges, size_t T, uint32_t *tiles, hipStream_t s);
 size_t scan_gather_temp_bytes(int P);

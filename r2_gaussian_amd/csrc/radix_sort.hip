@@ -478,11 +478,45 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
 
 bool sort_is_single_pass(int end_bit) { return make_plan(end_bit).npass == 1; }
 
+// keys per workgroup of the single-pass tile sort: its two big kernels run one workgroup per key tile and a CU hosts them one after
+// the other in practice, so the kernel lasts ceil(tiles / CUs) rounds of a workgroup's life (~ its keys); pick the tile size with
+// the least rounds x keys (1.16 M instances: 284 tiles of 4096 = two rounds, 252 tiles of 4608 = one)
+static int pick_ipt(size_t n)
+{
+    const int cus = device_cu_count();
+    int ipt = RS_IPT;
+    static const int cand[] = { 8, 9, 10, 12 };
+    size_t best = ~(size_t)0;
+    for (int c : cand) {
+        const size_t tiles = (n + (size_t)c * RS_THREADS - 1) / ((size_t)c * RS_THREADS);
+        const size_t cost = ((tiles + (size_t)cus - 1) / (size_t)cus) * (size_t)c;
+        if (cost < best) { best = cost; ipt = c; }
+    }
+    return ipt;
+}
+
+// Where a producer that already holds the keys can leave the per-tile digit histograms itself (rs_upsweep's output): row t of
+// H = counts of the `radix` digit values among keys [t * tile_keys, (t + 1) * tile_keys); skip[0] must be cleared.
+bool tile_sort_plan(void *temp, size_t temp_bytes, size_t n, int end_bit, TileSortPlan *out)
+{
+    const Plan plan = make_plan(end_bit);
+    if (n == 0 || plan.npass != 1 || n >= (size_t)1 << 31) return false;
+    const SortTemp t = SortTemp::carve(reinterpret_cast<char *>(temp), n);
+    if (t.bytes > temp_bytes) return false;
+    const int ipt = pick_ipt(n);
+    out->tile_keys = (uint32_t)(ipt * RS_THREADS);
+    out->ntiles = (uint32_t)((n + out->tile_keys - 1) / out->tile_keys);
+    out->bits = plan.bits[0];
+    out->H = t.H;
+    out->skip = t.skip;
+    return true;
+}
+
 // Single-pass stable sort of n instances by tile id (end_bit <= 12 bits): ids_out[pos] = ids[index] (scattered),
 // inv_out[index] = pos (coalesced), *counts_out = device pointer to the per-tile instance counts.
 int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tiles, const uint32_t *ids, uint32_t *ids_out,
                              uint32_t *inv_out, size_t n, int end_bit, const uint32_t **counts_out, hipStream_t s,
-                             const WorkListOut *work_out)
+                             const WorkListOut *work_out, bool hist_ready)
 {
     if (counts_out) *counts_out = nullptr;
     if (n == 0) return 0;
@@ -496,24 +530,12 @@ int sort_by_tile_single_pass(void *temp, size_t temp_bytes, const uint32_t *tile
         set_error("sort_by_tile_single_pass: temp storage too small (%zu < %zu)", temp_bytes, t.bytes);
         return R2_ERR_INVALID;
     }
-    // keys per workgroup: the sort's two big kernels run one workgroup per key tile and a CU hosts them one after the other in
-    // practice, so the kernel lasts ceil(tiles / CUs) rounds of a workgroup's life (~ its keys); pick the tile size with the
-    // least rounds x keys (1.16 M instances: 284 tiles of 4096 = two rounds, 252 tiles of 4608 = one)
-    const int cus = device_cu_count();
-    int ipt = RS_IPT;
-    {
-        static const int cand[] = { 8, 9, 10, 12 };
-        size_t best = ~(size_t)0;
-        for (int c : cand) {
-            const size_t tiles = (n + (size_t)c * RS_THREADS - 1) / ((size_t)c * RS_THREADS);
-            const size_t cost = ((tiles + (size_t)cus - 1) / (size_t)cus) * (size_t)c;
-            if (cost < best) { best = cost; ipt = c; }
-        }
-    }
+    const int ipt = pick_ipt(n);
     const uint32_t ntiles = (uint32_t)((n + (size_t)ipt * RS_THREADS - 1) / ((size_t)ipt * RS_THREADS));
     const int bits = plan.bits[0], radix = 1 << bits, phase = 1;
     Buffers buf{tiles, nullptr, ids, nullptr, nullptr, nullptr, nullptr, nullptr, ids_out};
-    rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.skip, ipt);
+    if (!hist_ready)   // (else the producer of the keys built the histograms: tile_sort_plan)
+        rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, 0, bits, 0, phase, t.skip, t.H, t.skip, ipt);
     rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
         t.H, ntiles, bits, (uint32_t)n, 0, 0, t.skip, t.totals);
     const size_t lds = (size_t)(RS_WAVES + 1) * pidx((uint32_t)radix) * sizeof(uint32_t);

@@ -132,12 +132,20 @@ static int raster_forward_impl(
     const uint32_t *tile_counts = nullptr;
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     if (R > 0) {
-        { StageScope t(ST_RAS_DUPLICATE, s);
-        if (rects && !full_order) launch_raster_duplicate_sorted(geom, bin, P, V, width, height, host_words + DW_NVIS, s);
-        else launch_raster_duplicate(geom, bin, P, V, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s); }
-        R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)
+        bool hist_ready = false;   // the emission kernel built the tile sort's histograms as well
+        { StageScope t(ST_RAS_DUPLICATE, s);
+        if (rects && !full_order) {
+            static const bool fuse_on = [] { const char *e = getenv("R2_EMIT_HIST"); return !(e && e[0] == '0'); }();
+            TileSortPlan plan;
+            if (fuse_on && !debug && tile_sort_plan(bin.sort_temp, bin.sort_bytes, R, bit, &plan))
+                hist_ready = launch_raster_emit_hist(geom, bin, P, V, width, height, host_words + DW_NVIS, R, plan, s);
+            if (!hist_ready) launch_raster_duplicate_sorted(geom, bin, P, V, width, height, host_words + DW_NVIS, s);
+        } else {
+            launch_raster_duplicate(geom, bin, P, V, radii, width, height, full_order ? nullptr : host_words + DW_NVIS, s);
+        } }
+        R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         // stable sort by tile id; payloads: the emission index (-> perm, the backward's scratch row) and the Gaussian
         // id (-> point_list)
         { StageScope t(ST_RAS_SORT, s);
@@ -145,7 +153,7 @@ static int raster_forward_impl(
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK,
                                  debug ? nullptr : img.tile_done, 0u};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
-                                          debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo);   // inv: introspection only
+                                          debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo, hist_ready);   // inv: introspection only
             work_built = true;
         } else {   // > 4096 tiles: general multi-pass sort, then invert its permutation (the scratch is free until backward)
             uint32_t *perm = reinterpret_cast<uint32_t *>(bin.part);   // scratch for the intermediate pass (free until backward)

@@ -311,6 +311,109 @@ __global__ void __launch_bounds__(256) raster_duplicate_sorted_kernel(
     R2_TS_AT(geom, 5);
 }
 
+// Emission BY OUTPUT RANGE, fused with the tile sort's histogram pass (its rs_upsweep): workgroup t produces exactly the
+// keys of sort tile t -- instances [t * tile_keys, (t + 1) * tile_keys) -- and therefore also that tile's digit histogram, so
+// the sort starts at its scan: no second pass over keys that were just written, one launch less.  The Gaussians of a range are
+// the sorted records between the owners of its first instance and of the next range's first (depth_order_granule_owners, left by
+// the ranking kernel: no search); their records are staged in LDS, every instance slot finds its owner by a mark + running-max
+// scan over the range (owners start at increasing slots), then tile = rectangle origin + (row, column) of the slot inside
+// the Gaussian's run.  Keys and ids are written coalesced, the histogram counts them on the way (LDS atomics).
+constexpr int EMIT_THREADS = 512;
+__global__ void __launch_bounds__(EMIT_THREADS) raster_emit_hist_kernel(
+    const uint4 *__restrict__ sorted, const uint32_t *__restrict__ owners, const uint32_t *__restrict__ nvis_p, uint32_t R,
+    uint32_t tile_keys, int bits, int Pview, int gx, int gy, bool multi_view, uint32_t *__restrict__ first,
+    uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals, uint32_t *__restrict__ H, uint32_t *__restrict__ clear_skip)
+{
+    extern __shared__ uint32_t emit_lds[];
+    const uint32_t radix = 1u << bits;
+    uint32_t *hist = emit_lds;                       // [radix]
+    uint32_t *s_excl = hist + radix;                 // [tile_keys + 1]
+    uint32_t *s_id = s_excl + tile_keys + 1;         // [tile_keys + 1]
+    uint32_t *s_rect = s_id + tile_keys + 1;         // [tile_keys + 1]
+    uint32_t *s_owner = s_rect + tile_keys + 1;      // [tile_keys] slot -> index into the staged records
+    __shared__ uint32_t s_wmax[EMIT_THREADS / 64];
+    R2_TS_AT(geom, 4);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t k0 = blockIdx.x * tile_keys, k1 = min(k0 + tile_keys, R), nk = k1 - k0;
+    const uint32_t ja = owners[k0 / TILE_SORT_GRANULE];
+    const uint32_t jb = k1 < R ? owners[k1 / TILE_SORT_GRANULE] : *nvis_p - 1u;   // owner of the NEXT range's first instance (at most one
+    const uint32_t nj = jb - ja + 1u;                                              // Gaussian too many: it marks no slot here)
+    // the first rounds of records are requested before the LDS is cleared (a range holds ~tile_keys / 4 Gaussians)
+    constexpr int PRE = 3;
+    uint4 pre_r[PRE];
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const uint32_t jj = (uint32_t)(q * EMIT_THREADS + tid);
+        pre_r[q] = sorted[ja + min(jj, nj - 1u)];
+    }
+    if (clear_skip && blockIdx.x == 0 && tid == 0) clear_skip[0] = 0u;
+    for (uint32_t d = tid; d < radix; d += EMIT_THREADS) hist[d] = 0u;
+    for (uint32_t i = tid; i < nk; i += EMIT_THREADS) s_owner[i] = 0u;
+    __syncthreads();
+    auto stage = [&](uint32_t jj, const uint4 r) {
+        const uint32_t excl = r.y - depth_rect_count(r.z);
+        s_excl[jj] = excl;
+        s_id[jj] = r.x;
+        s_rect[jj] = r.z;
+        if (excl >= k0 && excl < k1) {
+            s_owner[excl - k0] = jj;
+            first[r.x] = excl;   // where this Gaussian's instance run starts: the backward's scratch rows (written by the range
+        }                        // its run STARTS in; the very first Gaussian starts in range 0)
+    };
+#pragma unroll
+    for (int q = 0; q < PRE; ++q) {
+        const uint32_t jj = (uint32_t)(q * EMIT_THREADS + tid);
+        if (jj < nj) stage(jj, pre_r[q]);
+    }
+    for (uint32_t jj = (uint32_t)(PRE * EMIT_THREADS + tid); jj < nj; jj += EMIT_THREADS) stage(jj, sorted[ja + jj]);
+    __syncthreads();
+    // running maximum over the slots: thread t owns slots [t * ipt, (t + 1) * ipt)
+    const uint32_t ipt = tile_keys / EMIT_THREADS;
+    uint32_t run = 0u;
+    for (uint32_t i = 0; i < ipt; ++i) {
+        const uint32_t sidx = (uint32_t)tid * ipt + i;
+        if (sidx < nk) run = max(run, s_owner[sidx]);
+    }
+    uint32_t incl = run;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl = max(incl, up);
+    }
+    if (lane == 63) s_wmax[wave] = incl;
+    __syncthreads();
+    uint32_t pre = __shfl_up(incl, 1);
+    if (lane == 0) pre = 0u;
+    for (int w = 0; w < wave; ++w) pre = max(pre, s_wmax[w]);
+    run = pre;
+    for (uint32_t i = 0; i < ipt; ++i) {
+        const uint32_t sidx = (uint32_t)tid * ipt + i;
+        if (sidx < nk) {
+            run = max(run, s_owner[sidx]);
+            s_owner[sidx] = run;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < nk; i += EMIT_THREADS) {
+        const uint32_t o = s_owner[i];
+        const uint32_t rect = s_rect[o], id = s_id[o];
+        const uint32_t local = k0 + i - s_excl[o];
+        const uint32_t rw = ((rect >> 16) & 0xFFu) + 1u;
+        // local / rw without the integer division: local < 65536 and rw <= 256, so (local + 0.5) / rw stays 0.5 / rw away from
+        // the integers -- far more than float rounding moves it
+        const uint32_t row = (uint32_t)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)rw)), col = local - row * rw;
+        const int vrow = multi_view ? (int)(id / (uint32_t)Pview) * gy : 0;
+        const uint32_t tile = (uint32_t)((vrow + (int)((rect >> 8) & 0xFFu) + (int)row) * gx + (int)(rect & 0xFFu) + (int)col);
+        tiles[k0 + i] = tile;
+        vals[k0 + i] = id;
+        atomicAdd(&hist[tile & (radix - 1u)], 1u);
+    }
+    __syncthreads();
+    uint32_t *__restrict__ hrow = H + (size_t)blockIdx.x * radix;
+    for (uint32_t d = tid; d < radix; d += EMIT_THREADS) hrow[d] = hist[d];
+    R2_TS_AT(geom, 5);
+}
+
 // ------------------------------------------------------------------ backward: fused geometry gradient
 // One pass per Gaussian:
 //   1. reduce the per-instance moment rows written by the render backward (this Gaussian's instances are
@@ -590,6 +693,26 @@ int launch_raster_duplicate_sorted(const RasterGeom &g, const RasterBinning &b, 
     raster_duplicate_sorted_kernel<<<dim3((PV + 255) / 256), dim3(256), 0, s>>>(P, depth_order_sorted_records(g.dorder_temp, (size_t)PV), gy,
                                                                                 g.first, b.tiles_unsorted, b.vals_unsorted, nvis, gx, V > 1);
     return 0;
+}
+
+bool launch_raster_emit_hist(const RasterGeom &g, const RasterBinning &b, int P, int V, int W, int H, const uint32_t *nvis, size_t R,
+                             const TileSortPlan &plan, hipStream_t s)
+{
+    const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
+    const int PV = P * V;
+    uint32_t cap = 0;
+    const uint32_t *owners = depth_order_granule_owners(g.dorder_temp, (size_t)PV, &cap);
+    if (R / TILE_SORT_GRANULE + 1 > cap || plan.tile_keys % EMIT_THREADS != 0) return false;   // (a cloud of huge Gaussians)
+    const size_t lds = ((size_t)(1u << plan.bits) + 3 * ((size_t)plan.tile_keys + 1) + plan.tile_keys) * sizeof(uint32_t);
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void *>(raster_emit_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   150 * 1024) == hipSuccess;
+    }();
+    if (!attr_ok || lds > 150 * 1024) return false;
+    raster_emit_hist_kernel<<<dim3(plan.ntiles), dim3(EMIT_THREADS), lds, s>>>(
+        depth_order_sorted_records(g.dorder_temp, (size_t)PV), owners, nvis, (uint32_t)R, plan.tile_keys, plan.bits, P, gx, gy, V > 1,
+        g.first, b.tiles_unsorted, b.vals_unsorted, plan.H, plan.skip);
+    return true;
 }
 
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s)

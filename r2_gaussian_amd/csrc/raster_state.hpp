@@ -193,6 +193,10 @@ int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P /
 // emission from the slab depth order's sorted records (hinted path; nvis = device word with the number of visible instances)
 int launch_raster_duplicate_sorted(const RasterGeom &g, const RasterBinning &b, int P, int V, int W, int H, const uint32_t *nvis,
                                    hipStream_t s);
+// the same by output range, one workgroup per sort tile, which also leaves the tile sort's histograms (plan from tile_sort_plan);
+// false = not applicable here (nothing launched: use launch_raster_duplicate_sorted and the sort's own histogram pass)
+bool launch_raster_emit_hist(const RasterGeom &g, const RasterBinning &b, int P, int V, int W, int H, const uint32_t *nvis, size_t R,
+                             const TileSortPlan &plan, hipStream_t s);
 int launch_mark_visible(int P, const float *means3D, const float *view, uint8_t *present, hipStream_t s);
 int launch_raster_geom_backward(int P /* per view */, int V, const float *means3D, const int *radii, const float *cov3D, const float *scales,
                                 const float *rotations, float scale_modifier, int W, int H, float tan_fovx,
