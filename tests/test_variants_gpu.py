@@ -51,3 +51,44 @@ def test_exec_mask_asm_equals_the_plain_cxx_build(tmp_path):
         assert a[k].shape == b[k].shape, k
         scale = np.abs(a[k]).max()
         assert np.abs(a[k].astype(np.float64) - b[k]).max() <= 1e-6 * scale, (k, np.abs(a[k] - b[k]).max(), scale)
+
+
+# ---- the three emission paths of the hinted forward (csrc/raster_api.hip): order -> record gathers (R2_SORTED_RECORDS=0), sorted
+# records (R2_EMIT_HIST=0), and emission by output range fused with the tile sort's histograms (default) -- identical lists
+_BIN_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+dev = torch.device("cuda:0")
+out = {}
+for tag, P, det, seed in (("a", 30000, (160, 144), 21), ("b", 120000, (512, 512), 5), ("c", 7, (48, 48), 3)):
+    c = S.make_cloud(P, seed=seed)
+    views = S.make_views(8, det)
+    Hh.hip_raster(c, views[2], dev)          # un-hinted first call for this size
+    h = Hh.hip_raster(c, views[3], dev)      # hinted
+    assert h["host_words"][7] > 0            # DW_NVIS: the hinted path ran
+    for k in ("point_list", "ranges", "first", "tiles_unsorted", "vals_unsorted", "offsets", "order", "color"):
+        out[tag + "_" + k] = h[k] if k != "order" and k != "offsets" else h[k][:h["host_words"][7]]
+    out[tag + "_first"] = h["first"] * (h["radii"] > 0)   # (rows of culled Gaussians are never written)
+    out[tag + "_R"] = np.array([h["num_rendered"]])
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _run_env(tmp_path, name, extra_env):
+    out = str(tmp_path / (name + ".npz"))
+    env = dict(os.environ)
+    env.pop("R2HIP_LIB", None)
+    env.update(extra_env)
+    r = subprocess.run([sys.executable, "-c", _BIN_SCRIPT % ROOT, out], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return np.load(out)
+
+
+def test_emission_paths_produce_identical_lists(tmp_path):
+    ref = _run_env(tmp_path, "gathers", {"R2_SORTED_RECORDS": "0"})
+    for name, env in (("sorted_records", {"R2_EMIT_HIST": "0"}), ("fused", {})):
+        got = _run_env(tmp_path, name, env)
+        for k in ref.files:
+            assert np.array_equal(ref[k], got[k]), (name, k)
