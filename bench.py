@@ -55,7 +55,7 @@ STAGE_KERNEL = {
     "raster.render_fwd": "r2::raster_render_forward_kernel<false, true, false>",
     "raster.geom_bwd": "r2::raster_geom_backward_kernel<false>",
     "raster.preprocess": "r2::raster_preprocess_kernel",
-    "raster.duplicate": "r2::raster_duplicate_kernel",
+    "raster.duplicate": "r2::raster_emit_hist_kernel",
 }
 
 

@@ -131,6 +131,16 @@ def main():
     for name, kw in (("serial", {}), ("tv_stream", {"tv_stream": sB}), ("sync_each", {"sync_each": True}), ("serial_again", {})):
         loop(50, **kw)
         loops[name] = round(max(loop(300, **kw) for _ in range(3)), 1)
+    # the same loop with torch's own fused Adam (one multi-tensor kernel per group instead of ~15 element-wise launches): a
+    # one-line change in GaussianModel.training_setup (gaussian_model.py:192-215); densification's optimizer surgery is unaffected
+    # (same state keys)
+    try:
+        groups = [{"params": g["params"], "lr": g["lr"], "name": g["name"]} for g in model.optimizer.param_groups]
+        model.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15, fused=True)
+        loop(50)
+        loops["serial_fused_adam"] = round(max(loop(300) for _ in range(3)), 1)
+    except Exception as ex:   # older torch builds: no fused Adam on this device
+        loops["serial_fused_adam"] = "unavailable: %s" % str(ex)[:80]
     out = {"P": n_init, "detector": detector, "phases": phases,
            "device_us_per_iteration": round(sum(v["device_us"] for v in phases.values()), 1),
            "host_issue_us_per_iteration": round(sum(v["host_issue_us"] for v in phases.values()), 1),
