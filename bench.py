@@ -565,17 +565,24 @@ def main():
                        "the pure-PyTorch evaluation north_star mentions, which is reported beside it (pure_pytorch_config_a)" % nthr,
                "sample": "1 view fwd+bwd of the same workload (%dk Gaussians, %d^2, R=%d)" % (P // 1000, HW, st["num_rendered"])}
         # the pure-PyTorch CPU evaluation north_star names: BASELINE configs[0] (5k Gaussians, 64^2, 10 views + a 64^3 query),
-        # forward + autograd backward, run fully (oracle/torch_baseline.py, checked against the oracle in tests/)
+        # forward + autograd backward, run fully (oracle/torch_baseline.py, checked against the oracle in tests/).  In a FRESH
+        # process with a bounded wait: this one's OpenMP workers were created while it was pinned to a slice of the GPU's socket
+        # and keep that affinity -- torch CPU kernels with one thread per host core would crawl on them (minutes, not seconds)
         try:
-            from oracle import torch_baseline as TB
-            TB.config_a(n_gaussians=500, detector=32, n_views=1, n_voxel=16)   # warm torch's thread pool
-            ta, na, _imgs, _vol = TB.config_a()
+            nthr = max(1, min(32, len(all_cpus)))
+            code = ("import sys, json, torch; sys.path.insert(0, %r); torch.set_num_threads(%d); "
+                    "from oracle import torch_baseline as TB; TB.config_a(n_gaussians=500, detector=32, n_views=1, n_voxel=16); "
+                    "t, n, _i, _v = TB.config_a(); print(json.dumps({'seconds': t, 'views': n, 'threads': torch.get_num_threads()}))"
+                    % (ROOT, nthr))
+            env = dict(os.environ, OMP_NUM_THREADS=str(nthr), HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+            r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=150, env=env, cwd=ROOT)
+            ja = json.loads(r.stdout.strip().splitlines()[-1])
             cpu["pure_pytorch_config_a"] = {
-                "seconds": round(ta, 3), "views_per_s": round(na / ta, 3), "threads": torch.get_num_threads(),
-                "what": "oracle/torch_baseline.py: 5k Gaussians, 64^2 detector, 10 views forward + autograd backward, "
-                        "plus one 64^3 volume query forward + backward; float32, tile-exact lists"}
-        except Exception as ex:   # a reported extra: never fails the bench line
-            cpu["pure_pytorch_config_a"] = {"error": str(ex)[:200]}
+                "seconds": round(ja["seconds"], 3), "views_per_s": round(ja["views"] / ja["seconds"], 3), "threads": ja["threads"],
+                "what": "oracle/torch_baseline.py in a fresh process: 5k Gaussians, 64^2 detector, 10 views forward + autograd "
+                        "backward, plus one 64^3 volume query forward + backward; float32, tile-exact lists"}
+        except Exception as ex:   # a reported extra: never fails (or stalls) the bench line
+            cpu["pure_pytorch_config_a"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         s0 = settings[0]
         with torch.no_grad():
             Rg, color, radii, gb, bb, ib = _C.rasterize_gaussians(xyz, dens, scal, rot, 1.0, e, s0.viewmatrix, s0.projmatrix,
