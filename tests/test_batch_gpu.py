@@ -121,3 +121,28 @@ def test_autograd_module_sums_the_views(gpu):
     for a, t in zip(got[:4], p):
         assert torch.allclose(a, t.grad, rtol=1e-5, atol=1e-6 * float(t.grad.abs().max()))
     assert torch.equal(got[4], torch.stack(want2))
+
+
+def test_hinted_batched_call(gpu):
+    """The SECOND batched call of a size runs the hinted depth order (sorted records, emission by output range with the stacked
+    tile grids of the views): images, radii and per-view screen-space gradients stay bit-identical to single-view calls."""
+    from r2_gaussian_amd import _C
+    P, hw, V = 20000, (256, 256), 4
+    c = S.make_cloud(P, seed=7)
+    _batch(c, [S.make_view(0.1 + 0.7 * k, hw) for k in range(V)], gpu)          # first call of this size: un-hinted
+    views = [S.make_view(0.4 + 0.8 * k, hw) for k in range(V)]
+    args, (R, color, radii, gb, bb, ib) = _batch(c, views, gpu)                  # hinted
+    torch.cuda.synchronize()
+    singles = [Hh.hip_raster(c, v, gpu) for v in views]
+    assert R == sum(h["num_rendered"] for h in singles)
+    g = torch.Generator().manual_seed(5)
+    dL = ((torch.rand((V,) + hw, generator=g) * 2 - 1) / float(hw[0] * hw[1])).to(gpu)
+    res = _C.rasterize_gaussians_backward_batch(args[0], radii, args[2], args[3], 1.0, args[5], args[6], args[7], args[8],
+                                                args[9], dL, gb, R, bb, ib, args[12], False)
+    torch.cuda.synchronize()
+    d2 = res[0].cpu().numpy()
+    for k, (v, h) in enumerate(zip(views, singles)):
+        assert np.array_equal(radii[k].cpu().numpy(), h["radii"])
+        assert np.array_equal(color[k].cpu().numpy().view(np.uint32), h["color"][0].view(np.uint32)), "image of view %d" % k
+        gs = Hh.hip_raster_backward(h, c, v, dL[k:k + 1].cpu().numpy(), gpu)
+        assert np.array_equal(d2[k].view(np.uint32), gs["dL_dmeans2D"].view(np.uint32)), "dL_dmeans2D of view %d" % k
