@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 mkdir -p gpurun_out/tl
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o tl -- scripts/cbench ${1:-60} > gpurun_out/tl/cbench.txt 2>&1
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o tl -- scripts/cbench ${1:-60} r2_gaussian_amd/libr2hip.so ${2:-single} > gpurun_out/tl/cbench.txt 2>&1
 python3 - <<'PY'
 import csv, glob, re, collections
 f = glob.glob("gpurun_out/tl/**/*kernel_trace.csv", recursive=True)[0]
