@@ -79,7 +79,7 @@ void host_mark_forward_end()
 static thread_local uint32_t *g_pinned = nullptr;
 // one event per device: an event can only be recorded on a stream of the device it was created on, and one host thread may
 // drive several GPUs (the caller makes the stream's device current, like every HIP API that takes a stream)
-constexpr int MAX_DEVICES = 64;
+constexpr int MAX_DEVICES = R2_MAX_DEVICES;
 static thread_local hipEvent_t g_read_evs[MAX_DEVICES] = {};
 static thread_local hipEvent_t g_read_ev = nullptr;   // the event of the read in flight
 
@@ -88,6 +88,18 @@ int current_device_slot()
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
     return dev % MAX_DEVICES;
+}
+
+// A kernel that needs more than the default 64 KB of dynamic LDS has to be told so once PER DEVICE (a host thread may drive several
+// GPUs): state[] is the call site's table (0 = not asked yet, 1 = granted, -1 = refused), indexed by current_device_slot().
+bool allow_dynamic_lds(const void *kernel, int bytes, signed char *state)
+{
+    signed char &st = state[current_device_slot()];   // written with the same value by whoever gets here first: a benign race
+    if (st == 0) {
+        if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess) st = 1;
+        else { (void)hipGetLastError(); st = -1; }
+    }
+    return st > 0;
 }
 
 int device_cu_count()

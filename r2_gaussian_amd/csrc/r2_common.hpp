@@ -243,6 +243,10 @@ int inclusive_scan_gather_u32(void *temp, size_t temp_bytes, const uint32_t *in,
 // stream, wait spins until it has landed: work enqueued between the two keeps the GPU busy while the host waits.
 int current_device_slot();   // index of the current HIP device into small per-device host tables (binning.hip)
 int device_cu_count();       // compute units of the current device (cached per device)
+constexpr int R2_MAX_DEVICES = 64;
+// > 64 KB of dynamic LDS for `kernel` on the current device, asked for once per device; state = the call site's
+// static signed char [R2_MAX_DEVICES] table (zero-initialised)
+bool allow_dynamic_lds(const void *kernel, int bytes, signed char *state);
 int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
 int read_host_words_wait(uint32_t *out, int n);
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);

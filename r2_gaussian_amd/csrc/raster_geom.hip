@@ -704,10 +704,8 @@ bool launch_raster_emit_hist(const RasterGeom &g, const RasterBinning &b, int P,
     const uint32_t *owners = depth_order_granule_owners(g.dorder_temp, (size_t)PV, &cap);
     if (R / TILE_SORT_GRANULE + 1 > cap || plan.tile_keys % EMIT_THREADS != 0) return false;   // (a cloud of huge Gaussians)
     const size_t lds = ((size_t)(1u << plan.bits) + 3 * ((size_t)plan.tile_keys + 1) + plan.tile_keys) * sizeof(uint32_t);
-    static const bool attr_ok = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void *>(raster_emit_hist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   150 * 1024) == hipSuccess;
-    }();
+    static signed char lds_state[R2_MAX_DEVICES] = {};
+    const bool attr_ok = allow_dynamic_lds(reinterpret_cast<const void *>(raster_emit_hist_kernel), 150 * 1024, lds_state);
     if (!attr_ok || lds > 150 * 1024) return false;
     raster_emit_hist_kernel<<<dim3(plan.ntiles), dim3(EMIT_THREADS), lds, s>>>(
         depth_order_sorted_records(g.dorder_temp, (size_t)PV), owners, nvis, (uint32_t)R, plan.tile_keys, plan.bits, P, gx, gy, V > 1,

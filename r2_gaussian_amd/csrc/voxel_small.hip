@@ -240,15 +240,10 @@ bool small_enabled()
     // R2_VOXEL_SMALL=0 switches the path off; more than 64 KB of LDS per workgroup (gfx950: 160 KB per CU) has to be asked for
     static const bool on = [] {
         const char *e = getenv("R2_VOXEL_SMALL");
-        if (e && e[0] == '0') return false;
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(voxel_small_lists_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)SL_LDS_BYTES) != hipSuccess) {
-            (void)hipGetLastError();
-            return false;
-        }
-        return true;
+        return !(e && e[0] == '0');
     }();
-    return on;
+    static signed char lds_state[R2_MAX_DEVICES] = {};
+    return on && allow_dynamic_lds(reinterpret_cast<const void *>(voxel_small_lists_kernel), (int)SL_LDS_BYTES, lds_state);
 }
 
 }  // namespace

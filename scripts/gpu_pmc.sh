@@ -7,10 +7,10 @@ TAG=${1:-r01}
 mkdir -p gpurun_out/pmc
 CMD=${CMD:-"python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-voxel"}
 for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc/${TAG}_$C -o $C -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_$C.err
+  timeout 150 rocprofv3 --kernel-trace --pmc $C --output-format csv -d gpurun_out/pmc/${TAG}_$C -o $C -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_$C.err
   tail -1 gpurun_out/pmc/${TAG}_$C.err
 done
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d gpurun_out/pmc/${TAG}_SQ -o SQ -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_SQ.err
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --output-format csv -d gpurun_out/pmc/${TAG}_SQ -o SQ -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_SQ.err
 python - <<PY
 import csv, glob, collections, json, re
 def short(n):

@@ -5,7 +5,7 @@ export TMPDIR=/tmp
 TAG=${1:-x}
 mkdir -p gpurun_out/pmc
 CMD=${CMD:-"python bench.py --steps 3 --warmup 2 --no-cpu-baseline"}
-timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc/${TAG}_SQ2 -o SQ2 -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_SQ2.err
+timeout 150 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS --output-format csv -d gpurun_out/pmc/${TAG}_SQ2 -o SQ2 -- $CMD > /dev/null 2> gpurun_out/pmc/${TAG}_SQ2.err
 tail -2 gpurun_out/pmc/${TAG}_SQ2.err
 python - <<PY
 import csv, glob, collections, re
