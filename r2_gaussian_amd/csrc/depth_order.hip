@@ -311,7 +311,11 @@ __global__ void __launch_bounds__(256) fast_place_kernel(uint32_t n, const uint3
 // (Measured and left out, round 2: a lane per BUCKET instead of per slot -- bucket bounds first, the wave's slot range
 // staged in LDS, two dependent round trips instead of three, 1.4 us for the median workgroup -- but the clamped end buckets of
 // a hinted range routinely hold up to MAX_BUCKET keys, and the lane that owns one ranks n^2 pairs alone: 90-140 us for that
-// workgroup.  A lane per slot spreads exactly those buckets over many lanes.)
+// workgroup.  A lane per slot spreads exactly those buckets over many lanes.
+// Round 3: the members of a bucket are neighbouring LANES (consecutive slots), so the placement kernel stored the bucket's first
+// slot and its instance base in the record and this kernel read the other members out of the wave's registers (ds_bpermute; only
+// buckets that cross a wave walked memory) -- one memory round trip instead of three, indices identical: place + rank 19.5 -> 24.1 us.
+// The per-member shuffles (three per member, serial) cost more than the L1-resident loads they replace.)
 template <bool RECT>
 __global__ void __launch_bounds__(256) fast_rank_kernel(Ctrl *__restrict__ c, const uint4 *__restrict__ slot,
                                                         const uint32_t *__restrict__ incl_c, const uint32_t *__restrict__ incl_t,
