@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--no-batched", action="store_true", help="skip the batched-views section")
     ap.add_argument("--no-streams", action="store_true", help="skip the concurrent-streams section")
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only section")
+    ap.add_argument("--cloud", default=None,
+                    help="render a TRAINED, densified cloud instead of the synthetic one: a point_cloud.pickle in the reference's "
+                         "layout (r2_gaussian_amd.model_io), or a recipe name of scripts/train_cloud.py (small | large: looked up / "
+                         "trained through tests/trained_cloud.py).  --gaussians is then the cloud's own size")
     ap.add_argument("--headline-only", action="store_true",
                     help="the single-view step and nothing else (profiler passes: every kernel row is the headline step)")
     args = ap.parse_args()
@@ -220,7 +224,23 @@ def main():
     else:
         from r2_gaussian_amd import GaussianRasterizationSettings, GaussianRasterizer, _lib
         _lib.lib()
-        cloud = S.make_cloud(P, seed=0)
+        cloud_info = None
+        if args.cloud:
+            from r2_gaussian_amd import model_io
+            cpath = args.cloud
+            if not os.path.isfile(cpath):
+                from tests import trained_cloud as TCl      # input data only: looks the recipe up, trains it when absent
+                cpath = TCl.path(args.cloud)
+            with torch.no_grad():
+                cx, cd, cs, cr = (t.float().contiguous() for t in model_io.activate(model_io.load_point_cloud(cpath, device="cpu")))
+            cloud = S.Cloud(cx, cs, cr, cd.reshape(-1, 1))
+            P = int(cx.shape[0])
+            flats = [torch.empty((P, r2dist.GRAD_WIDTH), dtype=torch.float32, device=dev) for _ in range(2)]
+            cloud_info = {"source": os.path.relpath(cpath, ROOT) if cpath.startswith(ROOT) else cpath, "P": P,
+                          "scale_median": round(float(cs.median()), 5), "scale_min": round(float(cs.min()), 5),
+                          "scale_max": round(float(cs.max()), 5)}
+        else:
+            cloud = S.make_cloud(P, seed=0)
         xyz = cloud.xyz.to(dev).requires_grad_(True)
         dens = cloud.density.to(dev).requires_grad_(True)
         scal = cloud.scales.to(dev).requires_grad_(True)
@@ -478,6 +498,34 @@ def main():
                                              s.tanfovy, HW, HW, s.campos, False, s.mode, False)[0])
     R = int(sum(Rl) / len(Rl))
     N, T = HW * HW, ((HW + 15) // 16) ** 2
+    # what the cloud looks like to the binning chain: tile-list lengths, and how often the hinted depth order overflowed its
+    # buckets (whole-call fallback) / the thin-Gaussian render variant was compiled in, over the measured views
+    import ctypes as _ct
+    import numpy as _np
+    Lc = _lib.lib()
+    lens, n_over, n_thin, n_hinted = [], 0, 0, 0
+    with torch.no_grad():
+        for vi in range(0, len(views), max(1, len(views) // 10)):
+            s = settings[vi]
+            r_ = _C.rasterize_gaussians(xyz, dens, scal, rot, 1.0, e, s.viewmatrix, s.projmatrix, s.tanfovx, s.tanfovy, HW, HW,
+                                        s.campos, False, s.mode, False)
+            torch.cuda.synchronize()
+            bid = _ct.c_int(-1)
+            off = Lc.r2_raster_state_offset(15, P, r_[0], HW, HW, _ct.byref(bid))
+            hwd = r_[3 + bid.value][off:off + 32].cpu().numpy().view(_np.uint32)
+            n_over += int(hwd[1] != 0)
+            n_thin += int(hwd[2] != 0)
+            n_hinted += int(hwd[7] != 0)
+            off = Lc.r2_raster_state_offset(6, P, r_[0], HW, HW, _ct.byref(bid))
+            rg_ = r_[3 + bid.value][off:off + 8 * T].cpu().numpy().view(_np.uint32).reshape(T, 2).astype(_np.int64)
+            lens.append(rg_[:, 1] - rg_[:, 0])
+    lens = _np.concatenate(lens)
+    cloud_stats = {"views_sampled": len(Rl), "instances_per_gaussian": round(R / max(P, 1), 2),
+                   "tile_list_len": {"p50": float(_np.percentile(lens, 50)), "p90": float(_np.percentile(lens, 90)),
+                                     "p99": float(_np.percentile(lens, 99)), "max": int(lens.max())},
+                   "depth_hint_used": n_hinted, "depth_hint_overflow": n_over, "thin_variant_ANY4": n_thin}
+    if cloud_info:
+        cloud_stats.update(cloud_info)
     kernels = {}
     for name, (ms, cnt) in sorted(prof.items()):
         us = 1e3 * ms / cnt
@@ -619,7 +667,7 @@ def main():
             pmc = json.load(open(pmc_path))
             have, want = pmc.get("_meta", {}).get("source_sha"), r2build.source_hash()
             kq = pmc.get(STAGE_KERNEL.get(DOMINANT, ""), {})
-            if (P, HW, args.views) != (300000, 512, 50):
+            if (P, HW, args.views) != (300000, 512, 50) or args.cloud:
                 traffic_note = "profiles/pmc_latest.json holds the counters of the headline workload (300k Gaussians, 512^2): " \
                                "not applicable to this one"
             elif have != want:
@@ -640,13 +688,16 @@ def main():
         else:
             par = "single GPU"
         out = {
-            "metric": "rasterized X-ray views/sec (fwd+bwd) at 300k Gaussians, 512^2 cone-beam detector",
+            "metric": "rasterized X-ray views/sec (fwd+bwd) at %dk Gaussians, %d^2 cone-beam detector" % (round(P / 1000), HW),
             "value": main_t["value"], "unit": "views/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": main_t["ms_per_step"], "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "synthetic 0_chest_cone-like cone-beam set: %d Gaussians (seed 0), %dx%d detector, "
-                                   "%d views, DSD 7 / DSO 5" % (P, HW, HW, args.views),
+            "config": {"workload": ("synthetic 0_chest_cone-like cone-beam set: %d Gaussians (seed 0), %dx%d detector, "
+                                    "%d views, DSD 7 / DSO 5" % (P, HW, HW, args.views)) if not args.cloud else
+                                   ("TRAINED densified cloud (%s): %d Gaussians, %dx%d detector, %d views of the synthetic "
+                                    "cone-beam set it was trained on, DSD 7 / DSO 5" % (cloud_info["source"], P, HW, HW, args.views)),
                        "num_rendered": R, "parallelism": par},
+            "cloud_stats": cloud_stats,
             "timing": dict(main_t, note="median of %d regions of exactly %d steps, each between barrier + synchronize, "
                                         "max over ranks" % (repeats, args.steps)),
             "overlapped": overlapped,

@@ -190,18 +190,33 @@ def raster_forward_audit(st):
 RASTER_RAW = ("mean2D_x", "mean2D_y", "conic_x", "conic_y", "conic_w", "opacity", "mu")
 
 
-def raster_backward_audit(st, dL_dcolor):
+PAIR_CAP = 1 << 20   # borderline pairs listed per call (a case with more is reported as truncated, never silently cut)
+
+
+def _pair_buffers(width, pairs):
+    cap = PAIR_CAP if pairs else 0
+    return cap, np.zeros(max(cap, 1), np.uint32), np.zeros((max(cap, 1), width), np.float64), C.c_int64(0)
+
+
+def _pair_result(cap, ids, vals, count):
+    n = int(count.value)
+    return {"ids": ids[:min(n, cap)], "vals": vals[:min(n, cap)], "truncated": n > cap, "count": n}
+
+
+def raster_backward_audit(st, dL_dcolor, pairs=False):
     """The 7 raw sums of the render backward per Gaussian, accumulated in double: (sum, abssum, flip), each [P,7] in the order
     RASTER_RAW.  abssum = sum of |terms| (the scale a float sum with cancellation is accurate to), flip = |terms| of pairs on a
-    cut-off."""
+    cut-off.  pairs=True: a fourth result, the list of the borderline pairs themselves -- dict(ids [n] Gaussian, vals [n,7] what
+    the pair would ADD to that Gaussian's sums if the cut-off were decided the other way)."""
     P, H, W = st["P"], st["H"], st["W"]
     out = [np.zeros((P, 7), np.float64) for _ in range(3)]
+    cap, ids, vals, count = _pair_buffers(7, pairs)
     if P:
         lib().r2o_raster_render_bwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(W), C.c_int(H), C.c_int(P),
                                           C.c_int64(st["num_rendered"]), _p(st["means2D"]), _p(st["conic_opacity"]),
                                           _p(st["mus"]), _p(st["n_contrib"]), _p(_c32(dL_dcolor).reshape(-1)),
-                                          _p(out[0]), _p(out[1]), _p(out[2]))
-    return out
+                                          _p(out[0]), _p(out[1]), _p(out[2]), C.c_int64(cap), _p(ids), _p(vals), C.byref(count))
+    return out + [_pair_result(cap, ids, vals, count)] if pairs else out
 
 
 def raster_geom_chain(st, raw, means3D, scales, rotations, scale_modifier, cov3D_precomp, viewmatrix, projmatrix, tanfovx,
@@ -328,18 +343,21 @@ def voxel_forward_audit(st):
 VOXEL_RAW = ("mean_x", "mean_y", "mean_z", "conic_0", "conic_1", "conic_2", "conic_3", "conic_4", "conic_5", "opacity")
 
 
-def voxel_backward_audit(st, dL_dvol):
-    """(sum, abssum, flip), each [P,10] float64 in VOXEL_RAW order -- see raster_backward_audit."""
+def voxel_backward_audit(st, dL_dvol, pairs=False):
+    """(sum, abssum, flip), each [P,10] float64 in VOXEL_RAW order (+ the pair list with pairs=True) -- see
+    raster_backward_audit."""
     P = st["P"]
     nx, ny, nz = st["nVoxel"]
     sx, sy, sz = st["sVoxel"]
     out = [np.zeros((P, 10), np.float64) for _ in range(3)]
+    cap, ids, vals, count = _pair_buffers(10, pairs)
     if P:
         lib().r2o_voxel_render_bwd_audit(_p(st["ranges"]), _p(st["point_list"]), C.c_int(nx), C.c_int(ny), C.c_int(nz),
                                          C.c_float(sx), C.c_float(sy), C.c_float(sz), C.c_int(P),
                                          C.c_int64(st["num_rendered"]), _p(st["means3D_norm"]), _p(st["conic_opacity"]),
-                                         _p(st["n_contrib"]), _p(_c32(dL_dvol).reshape(-1)), _p(out[0]), _p(out[1]), _p(out[2]))
-    return out
+                                         _p(st["n_contrib"]), _p(_c32(dL_dvol).reshape(-1)), _p(out[0]), _p(out[1]), _p(out[2]),
+                                         C.c_int64(cap), _p(ids), _p(vals), C.byref(count))
+    return out + [_pair_result(cap, ids, vals, count)] if pairs else out
 
 
 def voxel_geom_chain(st, raw, scales, rotations, scale_modifier, cov3D_precomp):

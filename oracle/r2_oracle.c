@@ -990,11 +990,16 @@ R2O_API void r2o_raster_render_fwd_audit(const uint32_t *ranges, const uint32_t 
 R2O_API void r2o_raster_render_bwd_audit(const uint32_t *ranges, const uint32_t *point_list, int W, int H, int P, int64_t R,
                                          const float *means2D, const float *conic_opacity, const float *mus,
                                          const uint32_t *n_contrib, const float *dL_dpixels,
-                                         double *sum, double *abssum, double *flip)
+                                         double *sum, double *abssum, double *flip,
+                                         int64_t pair_cap, uint32_t *pair_id, double *pair_val, int64_t *pair_count)
 {
+    /* pair list (optional, pair_cap > 0): every borderline pair as (Gaussian id, the 7 terms it would ADD to that Gaussian's
+     * sums if an implementation decided the cut-off the other way: +v when the reference left it out, -v when it took it).
+     * pair_count = how many exist (may exceed pair_cap: the caller then knows the list is truncated). */
     const int gx = (W + 15) / 16, gy = (H + 15) / 16;
     const double ln_cut = log((double)0.00001f);
     const float ddelx_dx = (float)(0.5 * W), ddely_dy = (float)(0.5 * H);
+    int64_t npairs = 0;
     double *inst = (double *)calloc((size_t)R * 21 + 1, sizeof(double));   /* per list instance: 7 sums, 7 abs, 7 flip */
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy; tile++) {
@@ -1029,8 +1034,18 @@ R2O_API void r2o_raster_render_bwd_audit(const uint32_t *ranges, const uint32_t 
                         const double ddx = dx, ddy = dy;
                         const double t0 = 0.5 * co[0] * ddx * ddx, t1 = 0.5 * co[2] * ddy * ddy, t2 = (double)co[1] * ddx * ddy;
                         double a;
-                        if (r2o_borderline(-t0 - t1 - t2, fabs(t0) + fabs(t1) + fabs(t2), log(w), ln_cut, &a))
+                        if (r2o_borderline(-t0 - t1 - t2, fabs(t0) + fabs(t1) + fabs(t2), log(w), ln_cut, &a)) {
                             for (int q = 0; q < 7; q++) acc[14 + q] += fabs((double)v[q]) * 1.0001;
+                            if (pair_cap > 0) {
+                                int64_t slot;
+#pragma omp atomic capture
+                                slot = npairs++;
+                                if (slot < pair_cap) {
+                                    pair_id[slot] = id;
+                                    for (int q = 0; q < 7; q++) pair_val[7 * slot + q] = passes ? -(double)v[q] : (double)v[q];
+                                }
+                            }
+                        }
                     }
                 }
         }
@@ -1047,6 +1062,7 @@ R2O_API void r2o_raster_render_bwd_audit(const uint32_t *ranges, const uint32_t 
         }
     }
     free(inst);
+    if (pair_count) *pair_count = npairs;
 }
 
 static void vox_terms(const float *co, double dx, double dy, double dz, double *power, double *mag)
@@ -1095,11 +1111,13 @@ R2O_API void r2o_voxel_render_fwd_audit(const uint32_t *ranges, const uint32_t *
 R2O_API void r2o_voxel_render_bwd_audit(const uint32_t *ranges, const uint32_t *point_list, int nx, int ny, int nz,
                                         float sx, float sy, float sz, int P, int64_t R,
                                         const float *points_vol, const float *conic_opacity, const uint32_t *n_contrib,
-                                        const float *dL_dpixels, double *sum, double *abssum, double *flip)
+                                        const float *dL_dpixels, double *sum, double *abssum, double *flip,
+                                        int64_t pair_cap, uint32_t *pair_id, double *pair_val, int64_t *pair_count)
 {
     const int gx = (nx + 7) / 8, gy = (ny + 7) / 8, gz = (nz + 7) / 8;
     const float dvx = sx / (float)nx, dvy = sy / (float)ny, dvz = sz / (float)nz;
     const double ln_cut = log((double)0.000001f);
+    int64_t npairs = 0;   /* pair list: see r2o_raster_render_bwd_audit */
     double *inst = (double *)calloc((size_t)R * 30 + 1, sizeof(double));
 #pragma omp parallel for schedule(dynamic, 1)
     for (int tile = 0; tile < gx * gy * gz; tile++) {
@@ -1140,8 +1158,18 @@ R2O_API void r2o_voxel_render_bwd_audit(const uint32_t *ranges, const uint32_t *
                         if (opa > 0.0f) {
                             double pw, mag, a;
                             vox_terms(co, dx, dy, dz, &pw, &mag);
-                            if (r2o_borderline(pw, mag, log((double)opa), ln_cut, &a))
+                            if (r2o_borderline(pw, mag, log((double)opa), ln_cut, &a)) {
                                 for (int q = 0; q < 10; q++) acc[20 + q] += fabs((double)v[q]) * 1.0001;
+                                if (pair_cap > 0) {
+                                    int64_t slot;
+#pragma omp atomic capture
+                                    slot = npairs++;
+                                    if (slot < pair_cap) {
+                                        pair_id[slot] = id;
+                                        for (int q = 0; q < 10; q++) pair_val[10 * slot + q] = passes ? -(double)v[q] : (double)v[q];
+                                    }
+                                }
+                            }
                         }
                     }
         }
@@ -1158,8 +1186,9 @@ R2O_API void r2o_voxel_render_bwd_audit(const uint32_t *ranges, const uint32_t *
         }
     }
     free(inst);
+    if (pair_count) *pair_count = npairs;
 }
 
-R2O_API int r2o_abi_version(void) { return 1; }
+R2O_API int r2o_abi_version(void) { return 2; }
 R2O_API int r2o_num_threads(void) { return omp_get_max_threads(); }
 R2O_API void r2o_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }

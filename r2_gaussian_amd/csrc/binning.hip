@@ -102,6 +102,22 @@ bool allow_dynamic_lds(const void *kernel, int bytes, signed char *state)
     return st > 0;
 }
 
+size_t device_lds_optin_bytes()
+{
+    static size_t lim[MAX_DEVICES] = {};   // written once per device with the same value
+    const int slot = current_device_slot();
+    if (lim[slot] == 0) {
+        int dev = 0, a = 0, b = 0;
+        if (hipGetDevice(&dev) != hipSuccess) (void)hipGetLastError();
+        // runtimes differ in which of the two attributes carries the opt-in limit (gfx950: 160 KB): take the larger
+        if (hipDeviceGetAttribute(&a, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) { (void)hipGetLastError(); a = 0; }
+        if (hipDeviceGetAttribute(&b, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); b = 0; }
+        const int n = std::max(std::max(a, b), 64 * 1024);   // 64 KB: what every device grants without asking
+        lim[slot] = (size_t)n;
+    }
+    return lim[slot];
+}
+
 int device_cu_count()
 {
     static int cus[MAX_DEVICES] = {};   // written once per device with the same value: a benign race at worst

@@ -247,6 +247,7 @@ constexpr int R2_MAX_DEVICES = 64;
 // > 64 KB of dynamic LDS for `kernel` on the current device, asked for once per device; state = the call site's
 // static signed char [R2_MAX_DEVICES] table (zero-initialised)
 bool allow_dynamic_lds(const void *kernel, int bytes, signed char *state);
+size_t device_lds_optin_bytes();   // the device's real per-workgroup LDS limit (sharedMemPerBlockOptin)
 int read_host_words_begin(const uint32_t *dev_words, int n, hipStream_t s);
 int read_host_words_wait(uint32_t *out, int n);
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s);

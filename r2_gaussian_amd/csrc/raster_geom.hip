@@ -706,10 +706,13 @@ bool launch_raster_emit_hist(const RasterGeom &g, const RasterBinning &b, int P,
     const size_t lds = ((size_t)(1u << plan.bits) + 3 * ((size_t)plan.tile_keys + 1) + plan.tile_keys) * sizeof(uint32_t);
     static signed char lds_state[R2_MAX_DEVICES] = {};
     const bool attr_ok = allow_dynamic_lds(reinterpret_cast<const void *>(raster_emit_hist_kernel), 150 * 1024, lds_state);
-    if (!attr_ok || lds > 150 * 1024) return false;
+    if (!attr_ok || lds > 150 * 1024 || lds > device_lds_optin_bytes()) return false;
     raster_emit_hist_kernel<<<dim3(plan.ntiles), dim3(EMIT_THREADS), lds, s>>>(
         depth_order_sorted_records(g.dorder_temp, (size_t)PV), owners, nvis, (uint32_t)R, plan.tile_keys, plan.bits, P, gx, gy, V > 1,
         g.first, b.tiles_unsorted, b.vals_unsorted, plan.H, plan.skip);
+    // a refused launch (the attribute was accepted but the configuration is not) must not count as "histograms ready": the
+    // caller then emits with the plain kernel and runs the sort's own upsweep
+    if (hipGetLastError() != hipSuccess) return false;
     return true;
 }
 

@@ -117,6 +117,10 @@ extern "C" int r2_voxel_forward(
         if (rc) return rc;
         num_rendered = total;
         full_order = true;
+        // `order` is now a permutation of ALL P ids (culled ones interleaved: their depth_key is bits(z), not a sentinel),
+        // but the dual scan left its visible count in the device word: the geometry backward would walk only that prefix
+        // and skip visible Gaussians sorted behind it.  0 = "walk all of it" (voxel_geom_backward_kernel).
+        R2_HIP_TRY(hipMemsetAsync(host_words + DW_NVIS, 0, sizeof(uint32_t), s));
     }
     depth_hint_update(1, (size_t)P, hw, overflow);
     if (num_rendered > 0x7FFFFFFFu) {   // the API returns it as a non-negative int (like the reference's int num_rendered)

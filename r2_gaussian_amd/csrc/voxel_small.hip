@@ -20,6 +20,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <vector>
 
 namespace r2 {
 
@@ -43,13 +44,18 @@ struct SmallTmp {
     static SmallTmp carve(char *base, size_t bytes)
     {
         SmallTmp t;
+        // header: ranges [0, 512), chunk_base [512, 776), counts [1024, 1280) -- disjoint (chunk_base[T] is written too)
+        constexpr size_t OFF_CHUNK = 512, OFF_COUNTS = 1024, HEADER = 1280;
+        static_assert(VOX_SMALL_MAX_TILES * sizeof(uint2) <= OFF_CHUNK, "ranges overlap chunk_base");
+        static_assert(OFF_CHUNK + (VOX_SMALL_MAX_TILES + 2) * sizeof(uint32_t) <= OFF_COUNTS, "chunk_base overlaps counts");
+        static_assert(OFF_COUNTS + VOX_SMALL_MAX_TILES * sizeof(uint32_t) <= HEADER, "counts overlap the work list");
         t.ranges = reinterpret_cast<uint2 *>(base);
-        t.chunk_base = reinterpret_cast<uint32_t *>(base + 512);
-        t.counts = reinterpret_cast<uint32_t *>(base + 768);
-        const size_t avail = bytes > 1024 ? bytes - 1024 : 0;
+        t.chunk_base = reinterpret_cast<uint32_t *>(base + OFF_CHUNK);
+        t.counts = reinterpret_cast<uint32_t *>(base + OFF_COUNTS);
+        const size_t avail = bytes > HEADER ? bytes - HEADER : 0;
         t.cap_work = (uint32_t)std::min<size_t>(8192, avail / 128);   // 1/8 of the space: an item stands for >= 128 instances
-        t.work = reinterpret_cast<uint4 *>(base + 1024);
-        t.plist = reinterpret_cast<uint32_t *>(base + 1024 + (size_t)t.cap_work * 16);
+        t.work = reinterpret_cast<uint4 *>(base + HEADER);
+        t.plist = reinterpret_cast<uint32_t *>(base + HEADER + (size_t)t.cap_work * 16);
         t.cap_R = (uint32_t)std::min<size_t>((avail - (size_t)t.cap_work * 16) / 8, 0x7FFFFFFFu);
         t.tiles = t.plist + t.cap_R;
         return t;
@@ -232,8 +238,30 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
 }
 
 // one 64-byte device word per host thread: the survivor / row counter of the small-grid preprocess, zero between calls
-thread_local unsigned long long *g_small_counter = nullptr;
-thread_local int g_small_counter_dev = -1;
+// The two persistent counters of the path ({done | survivors | rows} of the preprocess, `arrivals` of the lists kernel) are
+// self-resetting, so they must not be shared by two calls in flight: one 64-byte block per (host thread, device, stream), kept
+// for the life of the thread (a thread that alternates devices or streams finds its block again instead of allocating).
+struct SmallCounter { int dev; hipStream_t stream; unsigned long long *ptr; };
+thread_local std::vector<SmallCounter> g_small_counters;
+
+unsigned long long *small_counter_for(int dev, hipStream_t s)
+{
+    for (const SmallCounter &c : g_small_counters)
+        if (c.dev == dev && c.stream == s) return c.ptr;
+    if (g_small_counters.size() >= 256) return nullptr;   // a thread cycling through ever new streams: general path from here on
+    unsigned long long *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    if (hipMemsetAsync(p, 0, 64, s) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(p);
+        return nullptr;
+    }
+    g_small_counters.push_back(SmallCounter{dev, s, p});
+    return p;
+}
 
 bool small_enabled()
 {
@@ -255,18 +283,13 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
 {
     const size_t T = (size_t)v.gx * v.gy * v.gz;
     const size_t V = (size_t)v.nx * v.ny * v.nz;
-    if (T > VOX_SMALL_MAX_TILES || v.gx > 8 || v.gy > 8 || v.gz > 8 || P > (1 << 22) || !small_enabled()) return VOX_SMALL_NOT_TAKEN;
+    // the preprocess packs {workgroups done : 12 | survivors : 20 | rows : 32} into one 64-bit atomic: P < 2^20 keeps every field
+    // inside its bits whatever the scene (survivors <= P, workgroups = P / 1024 < 2^10, rows <= 64 tiles x P < 2^26)
+    if (T > VOX_SMALL_MAX_TILES || v.gx > 8 || v.gy > 8 || v.gz > 8 || P >= (1 << 20) || !small_enabled()) return VOX_SMALL_NOT_TAKEN;
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
-    if (!g_small_counter || g_small_counter_dev != dev) {
-        if (hipMalloc(reinterpret_cast<void **>(&g_small_counter), 64) != hipSuccess) {
-            (void)hipGetLastError();
-            g_small_counter = nullptr;
-            return VOX_SMALL_NOT_TAKEN;
-        }
-        g_small_counter_dev = dev;
-        R2_HIP_TRY(hipMemsetAsync(g_small_counter, 0, 64, s));
-    }
+    unsigned long long *const g_small_counter = small_counter_for(dev, s);
+    if (!g_small_counter) return VOX_SMALL_NOT_TAKEN;
     uint4 *surv = depth_order_slots(geom.dorder_temp, (size_t)P);
     const SmallTmp tmp = SmallTmp::carve(geom.psort_temp, geom.psort_bytes);
     uint32_t *mailbox = nullptr, seq = 0;

@@ -125,3 +125,86 @@ def test_voxel_audit_budget_is_sparse(oracle):
     assert (budget >= 0).all() and (nb > 0).mean() < 0.01
     st = Pz.image_parity(o["vol"], o["vol"], budget, what="volume")
     assert st["n_flips"] == 0
+
+
+def _raster_case(oracle, P=20000, hw=(128, 128), seed=9, sm=0.7):
+    c, v = _scene(P, hw, seed=seed, sm=sm)
+    o = Hh.oracle_raster(oracle, c, v)
+    dL = S.make_pixel_grad(*hw).numpy()
+    xyz, rho, sc, q = Hh.cloud_np(c)
+    vm, pm = Hh.np_view(v)
+    args = (xyz, sc, q, 1.0, None, vm, pm, v.tanfovx, v.tanfovy)
+    return o, dL, args
+
+
+def _as_boundary(oracle, o, raw, args):
+    """Raw sums [P,7] -> the seven arrays the `_C` boundary returns, through the oracle's own geometry chain."""
+    ch = oracle.raster_geom_chain(o, raw.astype(np.float32), *args)
+    P = raw.shape[0]
+    m2 = np.zeros((P, 3), np.float32)
+    m2[:, :2] = raw[:, :2]
+    return dict(dL_dmeans2D=m2, dL_dopacity=raw[:, 5].astype(np.float32), dL_dmu=raw[:, 6].astype(np.float32),
+                dL_dmeans3D=ch["dL_dmeans3D"], dL_dcov3D=ch["dL_dcov3D"], dL_dscales=ch["dL_dscales"],
+                dL_drotations=ch["dL_drotations"])
+
+
+def test_after_flips_closes_the_flagged_row_loophole(oracle):
+    """a flagged row's tolerance contains its whole flip budget, so a rounding defect smaller than one
+    borderline contribution was invisible there.  With the pair list, (a) a row whose pair REALLY flipped leaves a residual far
+    inside the pure tolerance once the flip is taken out, (b) a defect of 3x the pure tolerance planted on a flagged row -- still
+    inside tolerance + budget -- is rejected."""
+    o, dL, args = _raster_case(oracle)
+    s, a, f, pairs = oracle.raster_backward_audit(o, dL, pairs=True)
+    assert not pairs["truncated"] and pairs["count"] == len(pairs["ids"]) > 0
+    flagged = (f > 0).any(axis=1)
+    assert set(np.unique(pairs["ids"])) == set(np.nonzero(flagged)[0])
+    # the pair list adds up to the budget the audit books (|terms| x 1.0001 per pair)
+    tot = np.zeros_like(f)
+    np.add.at(tot, pairs["ids"], np.abs(pairs["vals"]))
+    np.testing.assert_allclose(tot * 1.0001, f, rtol=1e-9, atol=1e-300)
+    # (0) the exact sums pass with margin 0 after flips
+    st = Pz.raster_grad_parity(oracle, o, dL, _as_boundary(oracle, o, s, args), *args)
+    af = st["after_flips"]
+    assert af["rows_checked"] + af["rows_skipped_many_pairs"] == af["rows_flagged"] > 0
+    assert af["max_err_over_tol_after_flips"] < 0.05 and af["rows_needing_a_flip"] == 0, af
+    # (a) flip the first listed pair of a few Gaussians for real
+    raw = s.copy()
+    seen = set()
+    for j, i in enumerate(pairs["ids"]):
+        if int(i) not in seen and len(seen) < 25:
+            seen.add(int(i))
+            raw[i] += pairs["vals"][j]
+    st = Pz.raster_grad_parity(oracle, o, dL, _as_boundary(oracle, o, raw, args), *args)
+    af = st["after_flips"]
+    assert af["rows_needing_a_flip"] == len(seen) >= 5 and af["max_err_over_tol_after_flips"] < 0.05, af
+    assert st["dL_dopacity"]["max_err_over_tol"] > 0.5        # the old column: near 1.0 by construction
+    # (b) a defect of 3x the pure tolerance on the opacity sum of a flagged Gaussian whose budget hides it
+    cand = np.nonzero(flagged & (f[:, 5] > 4e-4 * a[:, 5]) & (a[:, 5] > 0))[0]
+    assert cand.size
+    i = int(cand[0])
+    raw = s.copy()
+    raw[i, 5] += 3e-4 * a[i, 5]
+    g = _as_boundary(oracle, o, raw, args)
+    assert abs(float(g["dL_dopacity"][i]) - s[i, 5]) <= 1e-4 * a[i, 5] + f[i, 5]   # inside tolerance + budget ...
+    with pytest.raises(Pz.ParityError, match="after taking out"):                   # ... and still caught
+        Pz.raster_grad_parity(oracle, o, dL, g, *args)
+
+
+def test_after_flips_voxel(oracle):
+    c = S.make_cloud(6000, seed=4)
+    n, sv, ctr = (32, 32, 32), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, sv, ctr)
+    rng = np.random.default_rng(2)
+    dL = ((rng.random(n, dtype=np.float32) * 2 - 1) / np.prod(n)).astype(np.float32)
+    xyz, rho, sc, q = Hh.cloud_np(c)
+    s, a, f, pairs = oracle.voxel_backward_audit(o, dL, pairs=True)
+    assert pairs["count"] > 0 and not pairs["truncated"]
+    raw = s.copy()
+    i0 = int(pairs["ids"][0])
+    raw[i0] += pairs["vals"][0]                                   # one real flip
+    ch = oracle.voxel_geom_chain(o, raw.astype(np.float32), sc, q, 1.0, None)
+    g = dict(dL_dopacity=raw[:, 9].astype(np.float32), dL_dmeans3D=ch["dL_dmeans3D"], dL_dcov3D=ch["dL_dcov3D"],
+             dL_dscales=ch["dL_dscales"], dL_drotations=ch["dL_drotations"])
+    st = Pz.voxel_grad_parity(oracle, o, dL, g, sc, q, 1.0, None)
+    af = st["after_flips"]
+    assert af["rows_needing_a_flip"] >= 1 and af["max_err_over_tol_after_flips"] < 0.05, af

@@ -113,3 +113,63 @@ def test_config_C_300k_560(oracle, gpu):
     v = S.make_views(50, (560, 560))[11]
     o, _h = _raster_full(oracle, gpu, c, v, "config C 300k/560^2")
     assert o["ranges"].shape[0] == 1225
+
+
+# ---- TRAINED, DENSIFIED clouds (BASELINE configs[2] "full densification to ~300k Gaussians").  Everything above
+# draws its Gaussians from scene.make_cloud (uniform in an ellipsoid, log-uniform scales).  These clouds went through the
+# training loop's clone / split / prune rounds (train.py:155-168, gaussian_model.py:503-550) on the synthetic cone-beam case at
+# 512^2 / 256^3: 50k -> 92k ("small", round 2/3's run) and 50k -> ~335k ("large", lowered gradient threshold, capped at 300k),
+# saved and re-loaded in the reference's point_cloud.pickle layout (tests/trained_cloud.py trains them on this GPU when no copy
+# is around).  They are a different regime: ~9.3 instances per Gaussian instead of 3.9, tile lists of up to 23k entries,
+# depth keys clustered on the object.
+@pytest.fixture(scope="module", params=["small", "large"])
+def trained(request, gpu):
+    from tests import trained_cloud as TC
+    c, info = TC.load(request.param)
+    assert c is not None
+    return request.param, c, info
+
+
+@pytest.mark.parametrize("view", [0, 17])
+def test_trained_cloud_raster_forward_backward(trained, view, oracle, gpu):
+    name, c, info = trained
+    P = c.xyz.shape[0]
+    v = S.make_views(50, (512, 512))[view]
+    label = "TRAINED %s (P %d) 512^2 view %d" % (name, P, view)
+    Hh.hip_raster(c, v, gpu)                       # first call with this P: un-hinted; the one checked below is the hinted path
+    o, h = _raster_full(oracle, gpu, c, v, label)
+    assert int(h["host_words"][7]) == int((o["tiles_touched"] > 0).sum()), "the hinted depth order did not run"
+    assert int(h["host_words"][1]) == 0, "the hinted depth order overflowed its buckets on a trained cloud"
+    assert o["num_rendered"] > 6 * P               # densified clouds are instance-heavy: the regime the synthetic cloud lacks
+    L = (o["ranges"][:, 1] - o["ranges"][:, 0]).astype(np.int64)
+    Hh.PARITY_LOG.append(dict(kind="cloud_stats", case=label, P=int(P), R=int(o["num_rendered"]),
+                              list_len_p50=float(np.percentile(L, 50)), list_len_p90=float(np.percentile(L, 90)),
+                              list_len_p99=float(np.percentile(L, 99)), list_len_max=int(L.max()),
+                              hint_overflow=int(h["host_words"][1]), thin_flag=int(h["host_words"][2])))
+
+
+def test_trained_cloud_query_256cube_and_tv_patch(trained, oracle, gpu):
+    name, c, info = trained
+    P = c.xyz.shape[0]
+    n, s, ctr = (256, 256, 256), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    Hh.hip_voxel(c, n, s, ctr, gpu)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)            # second call: hinted
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    for k in ("radii_x", "radii_y", "radii_z"):
+        assert np.array_equal(h[k], o[k]), k
+    Hh.check_binning(h, o)
+    Hh.parity_volume(oracle, o, h["vol"], "TRAINED %s query 256^3" % name)
+    # one TV patch inside the object (train.py:128-142), forward + backward
+    n, s, ctr = (32, 32, 32), (0.25, 0.25, 0.25), (-0.1, 0.0, 0.05)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    Hh.check_binning(h, o)
+    Hh.parity_volume(oracle, o, h["vol"], "TRAINED %s TV patch 32^3" % name)
+    g = torch.Generator().manual_seed(1)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    gh = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+    sg = Hh.parity_voxel_grads(oracle, o, gh, c, dL, "TRAINED %s TV patch 32^3" % name)
+    for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+        assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])

@@ -221,3 +221,41 @@ def test_small_grid_from_two_threads(gpu):
     for th in ths:
         th.join()
     assert not bad, bad[:5]
+
+
+def test_backward_after_a_hinted_overflow(oracle, gpu):
+    """when the hinted depth order overflows its buckets the forward falls back to a radix sort of ALL P depth
+    keys -- culled Gaussians interleaved, their key is bits(z), not a sentinel -- while the dual scan had already left its visible
+    count in the state; the geometry backward then walked only that prefix of `order` and visible Gaussians sorted behind it got
+    no gradient rows (uninitialised memory on large grids).  Force exactly that: a hint armed by a wide cloud, then the same P
+    with z squeezed into a handful of buckets and half of the cloud outside the volume; grid > 64 tiles (not the small path)."""
+    from r2_gaussian_amd import _lib
+    L = _lib.lib()
+    P = 20000
+    c = S.make_cloud(P, seed=6)
+    n, s, ctr = (40, 40, 40), (1.0, 1.0, 1.0), (0.5, 0.0, 0.0)     # x < 0 is outside: about half of the cloud is culled
+    try:
+        L.r2_depth_hint_control(2)
+        Hh.hip_voxel(c, n, s, ctr, gpu)                            # un-hinted, arms the hint for this P
+        xyz = c.xyz.clone()
+        xyz[:, 2] = xyz[:, 2] * 1e-5 + 0.01
+        c3 = S.Cloud(xyz, c.scales, c.rotations, c.density)
+        o = Hh.oracle_voxel(oracle, c3, n, s, ctr)
+        nvis = int((o["tiles_touched"] > 0).sum())
+        assert 0.2 * P < nvis < 0.8 * P
+        h = Hh.hip_voxel(c3, n, s, ctr, gpu)
+        assert int(h["host_words"][1]) == 1, "the squeezed cloud was meant to overflow the hinted buckets"
+        assert int(h["host_words"][7]) == 0, "after the fallback `order` holds all P ids: the visible-prefix count must be cleared"
+        Hh.check_binning(h, o)
+        g = torch.Generator().manual_seed(3)
+        dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+        for k in range(2):   # twice: the second backward runs on recycled (dirty) gradient buffers
+            gh = Hh.hip_voxel_backward(h, c3, n, s, ctr, dL, gpu)
+            sg = Hh.parity_voxel_grads(oracle, o, gh, c3, dL, "voxel backward after a hinted overflow (%d)" % k)
+            for kk in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+                assert sg[kk]["max_err_over_scale_unflagged"] <= 2e-4, (kk, sg[kk])
+            # every visible Gaussian got a row
+            assert (np.abs(gh["dL_dopacity"].reshape(-1)[o["tiles_touched"] > 0]) > 0).mean() > 0.9
+    finally:
+        L.r2_depth_hint_control(1)
+        L.r2_depth_hint_control(2)
