@@ -95,15 +95,34 @@ def self_launch(n):
 
 
 class StepRunner:
-    """The step / exchange / drain logic of the data-parallel bench, independent of what renders: `render(k)` runs forward +
+    """The step / exchange / drain logic of the data-parallel bench, independent of what renders: `render(k, i)` runs forward +
     backward of step k on this rank and returns the flat gradient block to exchange.  mode "sync": the all-reduce is waited for
-    (stream-ordered) before the step returns; "overlap": it is waited for two steps later (double-buffered)."""
+    (stream-ordered) before the step returns; "overlap": it is waited for two steps later (double-buffered, gradients one step
+    stale).  Two SYNCHRONOUS modes with two views per rank and optimiser step (no stale gradients; a step = 2 views):
+    "sync2": the all-reduce of view A's block runs behind the render of view B, then B's is waited for -- two exchanges per
+    step, one of them hidden; "accum2": view B's backward accumulates into view A's gradients (render(k, i, True)) and the step
+    costs ONE all-reduce -- half the bytes of sync2, the same exposed time."""
+    VIEWS_PER_STEP = {"sync": 1, "overlap": 1, "sync2": 2, "accum2": 2}
 
     def __init__(self, render, allreduce, use_comm, mode="sync"):
         self.render, self.allreduce, self.use_comm, self.mode = render, allreduce, use_comm, mode
         self.pending = [None, None]
 
     def step(self, k):
+        if self.mode == "sync2":
+            blk_a = self.render(2 * k, 0)
+            h_a = self.allreduce(blk_a) if self.use_comm else None   # async: runs while view B renders
+            blk_b = self.render(2 * k + 1, 1)
+            if self.use_comm:
+                h_a.wait()
+                self.allreduce(blk_b).wait()
+            return
+        if self.mode == "accum2":
+            self.render(2 * k, 0)
+            blk = self.render(2 * k + 1, 0, True)                    # accumulates into view A's gradient block
+            if self.use_comm:
+                self.allreduce(blk).wait()
+            return
         i = k & 1
         if self.use_comm and self.mode == "overlap" and self.pending[i] is not None:
             self.pending[i][0].wait()          # the reduction started two steps ago is done: its buffer may be reused
@@ -217,8 +236,11 @@ def main():
     if stub:
         g = torch.Generator().manual_seed(rank)
 
-        def render(k, i):
-            flats[i].copy_(torch.rand(P, r2dist.GRAD_WIDTH, generator=g))
+        def render(k, i, accumulate=False):
+            if accumulate:
+                flats[i].add_(torch.rand(P, r2dist.GRAD_WIDTH, generator=g))
+            else:
+                flats[i].copy_(torch.rand(P, r2dist.GRAD_WIDTH, generator=g))
             return flats[i]
         _lib = None
     else:
@@ -256,12 +278,13 @@ def main():
         # the parameters, resident before the timed region
         means2D = torch.zeros_like(xyz, requires_grad=True)
 
-        def render(k, i):
+        def render(k, i, accumulate=False):
             vi = r2dist.view_for(k, len(views), rank_=rank, world_=world)
             img, _radii = rasterizers[vi](means3D=xyz, means2D=means2D, opacities=dens, scales=scal, rotations=rot)
             means2D.grad = None
-            for p in params:
-                p.grad = None
+            if not accumulate:   # accumulate: autograd adds this view's gradients into the previous view's .grad block
+                for p in params:
+                    p.grad = None
             img.backward(dL)
             if not use_comm:
                 return None
@@ -343,6 +366,21 @@ def main():
         overlapped = summarize(ov_s, args.steps, world)
         overlapped["note"] = "all-reduce of step k overlaps the render of step k+1: gradients are consumed one step late"
     dt_step = statistics.median(region_s) / args.steps
+    two_view = None
+    if use_comm:   # synchronous data parallelism with two views per rank and step (StepRunner docstring): views/s of each
+        two_view = {}
+        for mode2 in ("sync2", "accum2"):
+            rn = StepRunner(render, allreduce, use_comm, mode2)
+            for _ in range(min(args.warmup, 10)):
+                rn.step(k)
+                k += 1
+            rn.drain()
+            n2 = max(1, args.steps // 2)
+            s2, k = timed_regions(rn, n2, repeats, k, barrier, max_over_ranks)
+            two_view[mode2] = summarize(s2, 2 * n2, world)
+        two_view["note"] = ("two views per rank and optimiser step, parameters updated once, no stale gradients; sync2 = all-reduce "
+                            "of view A behind the render of view B + exposed all-reduce of B; accum2 = local accumulation + ONE "
+                            "all-reduce per step")
 
     if stub:
         if rank == 0:
@@ -351,7 +389,7 @@ def main():
                               "warmup": args.warmup, "ms_per_step": main_t["ms_per_step"], "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "stub",
                               "config": {"workload": "stub", "ranks_in_process_group": dist.get_world_size() if use_comm else 1},
-                              "timing": main_t, "overlapped": overlapped}))
+                              "timing": main_t, "overlapped": overlapped, "two_views_per_step": two_view}))
         if use_comm:
             dist.barrier()
             dist.destroy_process_group()
@@ -591,6 +629,22 @@ def main():
                 "tv_patch_32cube_fwd_bwd_us": round(ttv * 1e6, 1), "tv_patch_us_min": round(min(ttvs) * 1e6, 1),
                 "tv_patch_us_max": round(max(ttvs) * 1e6, 1)}
 
+    # ---- simple-knn (distCUDA2, gaussian_model.py:145-150: called once per run, on the initial points): exact brute force, timed
+    # at the initial-cloud sizes of configs B / headline / E
+    knn_t = None
+    if rank == 0 and not args.no_voxel:
+        from r2_gaussian_amd import distCUDA2
+        knn_t = {}
+        for n_ in (50000, 300000, 1000000):
+            pts = S.make_cloud(n_, seed=1).xyz.to(dev)
+            distCUDA2(pts)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            distCUDA2(pts)
+            torch.cuda.synchronize()
+            knn_t[str(n_)] = round((time.perf_counter() - t3) * 1e3, 3)
+        knn_t["unit"] = "ms per call (exact O(P^2) search, csrc/knn.hip)"
+
     # ---- CPU baseline + parity self-check: the oracle on the host cores, ONE view; the same view's GPU result is checked
     # against it before the line is printed
     cpu, parity = None, None
@@ -631,6 +685,24 @@ def main():
                         "backward, plus one 64^3 volume query forward + backward; float32, tile-exact lists"}
         except Exception as ex:   # a reported extra: never fails (or stalls) the bench line
             cpu["pure_pytorch_config_a"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
+        # ... and on THIS workload ("for B / C / E time one view and extrapolate"): one view forward + autograd
+        # backward through the same pure-PyTorch evaluation, same fresh-process / bounded-wait arrangement
+        if not args.cloud:
+            try:
+                code = ("import sys, json, torch; sys.path.insert(0, %r); torch.set_num_threads(%d); "
+                        "from oracle import torch_baseline as TB; t, nt = TB.one_view(%d, %d, %d); "
+                        "print(json.dumps({'seconds': t, 'tiles': nt, 'threads': torch.get_num_threads()}))"
+                        % (ROOT, nthr, P, HW, args.views))
+                r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=240, env=env, cwd=ROOT)
+                jh = json.loads(r.stdout.strip().splitlines()[-1])
+                cpu["pure_pytorch_this_workload"] = {
+                    "seconds_per_view": round(jh["seconds"], 2), "views_per_s": round(1.0 / jh["seconds"], 4),
+                    "threads": jh["threads"],
+                    "what": "oracle/torch_baseline.py, ONE view (view 0) forward + autograd backward of this workload "
+                            "(%dk Gaussians, %d^2), timed once in a fresh process; views/s is the extrapolation 1 / seconds"
+                            % (round(P / 1000), HW)}
+            except Exception as ex:
+                cpu["pure_pytorch_this_workload"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
         s0 = settings[0]
         with torch.no_grad():
             Rg, color, radii, gb, bb, ib = _C.rasterize_gaussians(xyz, dens, scal, rot, 1.0, e, s0.viewmatrix, s0.projmatrix,
@@ -701,6 +773,7 @@ def main():
             "timing": dict(main_t, note="median of %d regions of exactly %d steps, each between barrier + synchronize, "
                                         "max over ranks" % (repeats, args.steps)),
             "overlapped": overlapped,
+            "two_views_per_step": two_view,
             "forward_only": fwd_only,
             "batched": batched,
             "concurrent_streams": concurrent,
@@ -721,6 +794,7 @@ def main():
             "host_cpus_pinned": len(pinned) if pinned else None,
             "kernels": kernels,
             "voxelizer": gvox,
+            "simple_knn_ms": knn_t,
         }
         print(json.dumps(out))
     if dist.is_initialized():

@@ -187,3 +187,20 @@ def config_a(n_gaussians=5000, detector=64, n_views=10, n_voxel=64, seed=0, back
     if backward:
         vol.sum().backward()
     return time.perf_counter() - t0, n_views, images, vol.detach()
+
+
+def one_view(n_gaussians=300000, detector=512, n_views=50, view=0, seed=0, backward=True):
+    """ONE view (forward + autograd backward) of a large workload -- SURVEY.md 8(d): "for B / C / E time one view and
+    extrapolate".  Default = bench.py's headline workload (300k Gaussians, 512^2, view 0 of 50).  -> (seconds, num tiles)."""
+    import time
+
+    from r2_gaussian_amd import scene as S
+    cloud = S.make_cloud(n_gaussians, seed=seed)
+    v = S.make_views(n_views, (detector, detector))[view]
+    params = [t.clone().requires_grad_(backward) for t in (cloud.xyz, cloud.density, cloud.scales, cloud.rotations)]
+    t0 = time.perf_counter()
+    img, _ = rasterize(*params, 1.0, v.world_view_transform, v.full_proj_transform, v.tanfovx, v.tanfovy, v.image_height,
+                       v.image_width, v.mode)
+    if backward:
+        img.sum().backward()
+    return time.perf_counter() - t0, ((detector + 15) // 16) ** 2

@@ -406,7 +406,7 @@ def psnr3d(case, model):
 
 
 def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losses=False, fused_densify=False, views_per_step=1,
-          data_parallel=False, return_model=False):
+          data_parallel=False, return_model=False, views_per_rank=1, exchange="accum"):
     """-> dict(iters=[...], psnr=[...], P=[...], it_per_s=...).  train.py:97-177.
     fused_losses (hip backend): the loss stack through r2_gaussian_amd.losses (one autograd node each) instead of torch ops.
     fused_densify (hip backend): densification statistics + densify / prune through r2_gaussian_amd.densify.
@@ -414,7 +414,13 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
     with data_parallel (torch.distributed initialised, world size W) ONE per rank with r2_gaussian_amd.dist doing the exchange:
     one all-reduce of the parameter gradients, sum / max reductions of the densification statistics.  Both
     orders of evaluation draw the same random stream (view order, TV centre, split samples), so every rank and the
-    single-process run hold the same model."""
+    single-process run hold the same model.
+    views_per_rank = V > 1: every rank renders V views per optimiser step (W = world x V views per step, ONE
+    parameter update, no stale gradients).  exchange = "accum": the rank sums its V gradient blocks locally and the step costs
+    one all-reduce (1/V exchanges per view, all of it exposed); "sync2": every view's block is all-reduced on its own, the
+    reduction of view j running (async) behind the render of view j+1 -- only the last one is exposed.  Both are synchronous
+    data parallelism; they differ in how the float sums associate, and the single-process run (data_parallel=False) reproduces
+    either association with "virtual ranks", so the comparison can be bit for bit."""
     from r2_gaussian_amd import dist as D
     be = Backend(backend_name)
     gen = torch.Generator().manual_seed(seed)          # TV centres, split samples
@@ -425,8 +431,11 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
     tvN = torch.tensor([opt.tv_vol_size] * 3)
     tvS = case.dVoxel * tvN
     W = int(views_per_step)
+    V = int(views_per_rank)
+    assert W % V == 0 and exchange in ("accum", "sync2")
+    n_ranks = W // V                                   # real ranks (data_parallel) or virtual ones (single process)
     if data_parallel:
-        assert D.world() == W, (D.world(), W)
+        assert D.world() == n_ranks, (D.world(), n_ranks)
     out = {"iters": [0], "psnr": [psnr3d(case, model)], "P": [model.P], "backend": backend_name}
     stack = []
     t_train = 0.0
@@ -438,11 +447,13 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
             if not stack:
                 stack = list(range(len(case.views)))
             step_views.append(stack.pop(pyrng.randint(0, len(stack) - 1)))
-        mine = [step_views[D.rank()]] if data_parallel else step_views
+        # view of (rank r, slot j) = step_views[r * V + j]
+        mine = step_views[D.rank() * V:(D.rank() + 1) * V] if data_parallel else step_views
         c = None
         if opt.lambda_tv > 0:   # one TV patch per optimiser step: the same centre for all of the step's views / ranks
             c = (case.bbox[0] + tvS / 2) + (case.bbox[1] - tvS - case.bbox[0]) * torch.rand(3, generator=gen)
         inc_gn = inc_dn = rad_max = None
+        flats, stats_v = [], []                          # W > 1: one packed [P,11] gradient block + statistics per view
         for vi in mine:
             x, d, s, r = model.activated()
             pkg = be.render(case.views[vi], x, d, s, r)
@@ -472,17 +483,56 @@ def train(case, opt, backend_name, eval_every=100, seed=0, log=None, fused_losse
                 else:   # the step's statistics increments (train.py:151-154 per view), reduced over ranks below
                     vis, radii = pkg["visibility_filter"].to(dev), pkg["radii"].to(dev).float()
                     gn = torch.where(vis, pkg["viewspace_points"].grad[:, :2].norm(dim=-1), torch.zeros((), device=dev))
-                    inc_gn = gn if inc_gn is None else inc_gn + gn
-                    inc_dn = vis.float() if inc_dn is None else inc_dn + vis.float()
-                    rad_max = radii if rad_max is None else torch.max(rad_max, radii)
+                    stats_v.append((gn, vis.float(), radii))
+                    params = [model.p[n] for n in model.NAMES]
+                    flat = D.pack_grads(*(p_.grad for p_ in params))   # this view's gradient block, on its own
+                    for p_ in params:
+                        p_.grad = None
+                    if data_parallel and exchange == "sync2":
+                        # its all-reduce starts NOW and runs behind the next view's render (waited for after the loop)
+                        flats.append((flat, D.allreduce_grads(flat, average=False, async_op=True)))
+                    else:
+                        flats.append((flat, None))
         with torch.no_grad():
             if W > 1:
                 params = [model.p[n] for n in model.NAMES]
+
+                def fold(ts):
+                    acc = ts[0]
+                    for t_ in ts[1:]:
+                        acc = acc + t_
+                    return acc
+
+                def by_rank(items):   # [[rank 0's V items], [rank 1's], ...] (single process: virtual ranks)
+                    return [items[r * V:(r + 1) * V] for r in range(len(items) // V)]
                 if data_parallel:
-                    D.allreduce_param_grads(params, average=False)      # ONE all-reduce of the [P,11] gradient block
+                    if exchange == "sync2":
+                        for _f, h in flats:
+                            if h is not None:
+                                h.wait()
+                        total = fold([f_ for f_, _h in flats])          # slot sums, added in slot order
+                    else:
+                        total = fold([f_ for f_, _h in flats])          # local sum in view order ...
+                        D.allreduce_grads(total, average=False)         # ... ONE all-reduce of the [P,11] gradient block
+                    inc_gn, inc_dn = fold([s_[0] for s_ in stats_v]), fold([s_[1] for s_ in stats_v])
+                    rad_max = stats_v[0][2]
+                    for s_ in stats_v[1:]:
+                        rad_max = torch.max(rad_max, s_[2])
                     inc_gn, inc_dn, rad_max = D.allreduce_densify_stats(inc_gn, inc_dn, rad_max)
-                for p_ in params:
-                    p_.grad.div_(W)
+                else:   # the same sums with the same association, ranks emulated
+                    fr = by_rank([f_ for f_, _h in flats])
+                    if exchange == "sync2":
+                        total = fold([fold([fr[r][j] for r in range(n_ranks)]) for j in range(V)])
+                    else:
+                        total = fold([fold(fr[r]) for r in range(n_ranks)])
+                    sr = by_rank(stats_v)
+                    inc_gn = fold([fold([s_[0] for s_ in sr[r]]) for r in range(n_ranks)])
+                    inc_dn = fold([fold([s_[1] for s_ in sr[r]]) for r in range(n_ranks)])
+                    rad_max = stats_v[0][2]
+                    for s_ in stats_v[1:]:
+                        rad_max = torch.max(rad_max, s_[2])
+                for p_, g_ in zip(params, D.unpack_grads(total)):
+                    p_.grad = (g_.reshape(p_.shape) / W).contiguous()
                 model.max_radii2D = torch.max(model.max_radii2D, rad_max)
                 model.grad_accum += inc_gn[:, None]
                 model.denom += inc_dn[:, None]

@@ -228,6 +228,26 @@ def test_bench_step_runner_sync_and_overlap_order():
     r.step(0)
     r.drain()
     assert log == [("render", 0, 0)]
+    # two views per rank and step, synchronous: sync2 = A's reduction started before B renders and waited for after it, then B's;
+    # accum2 = B accumulates into A's block (render's third argument), ONE reduction
+    del log[:]
+
+    def render3(k, i, accumulate=False):
+        log.append(("render", k, i, accumulate))
+        return k
+
+    r = bench.StepRunner(render3, allreduce, True, "sync2")
+    r.step(0)
+    r.step(1)
+    r.drain()
+    assert log == [("render", 0, 0, False), ("reduce", 0), ("render", 1, 1, False), ("wait", 0), ("reduce", 1), ("wait", 1),
+                   ("render", 2, 0, False), ("reduce", 2), ("render", 3, 1, False), ("wait", 2), ("reduce", 3), ("wait", 3)]
+    del log[:]
+    r = bench.StepRunner(render3, allreduce, True, "accum2")
+    r.step(0)
+    r.drain()
+    assert log == [("render", 0, 0, False), ("render", 1, 0, True), ("reduce", 1), ("wait", 1)]
+    assert bench.StepRunner.VIEWS_PER_STEP["sync2"] == bench.StepRunner.VIEWS_PER_STEP["accum2"] == 2
     s = bench.summarize([0.010, 0.012, 0.011], 10, 2)
     assert s["value"] == round(10 * 2 / 0.011, 2) and s["ms_per_step"] == 1.1 and s["regions"] == 3
 
@@ -257,7 +277,7 @@ def _model_signature(model):
     return model.P, h.hexdigest()
 
 
-def _dp_train_worker(rank, world, port, q):
+def _dp_train_worker(rank, world, port, q, views_per_rank=1, exchange="accum"):
     try:
         os.environ["MASTER_ADDR"] = "127.0.0.1"
         os.environ["MASTER_PORT"] = str(port)
@@ -265,7 +285,8 @@ def _dp_train_worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         from tests import mini_trainer as T
         case, opt = _dp_case_and_opt()
-        out = T.train(case, opt, "oracle", eval_every=60, seed=0, views_per_step=world, data_parallel=True, return_model=True)
+        out = T.train(case, opt, "oracle", eval_every=60, seed=0, views_per_step=world * views_per_rank, data_parallel=True,
+                      return_model=True, views_per_rank=views_per_rank, exchange=exchange)
         sig = _model_signature(out["model"])
         dist.barrier()
         dist.destroy_process_group()
@@ -302,4 +323,38 @@ def test_data_parallel_trainer_world2_equals_single_process():
     assert res[0][2] == res[1][2], "the two ranks hold different models"
     assert len(set(ref["P"])) >= 3, ref["P"]                       # the run went through densification rounds that changed P
     assert res[0][3] == ref["P"] and res[0][2] == ref_sig, (res[0][3], ref["P"])   # bit-identical to the single-process run
+    assert res[0][4] == ref["psnr"]
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("exchange", ["accum", "sync2"])
+def test_data_parallel_two_views_per_rank_world2_equals_single_process(exchange):
+    """synchronous data parallelism that hides (sync2) or halves (accum) its exchange -- every rank renders TWO
+    views per optimiser step, parameters update once per step, no stale gradients.  World 2 over gloo with the oracle backend,
+    three densification rounds: both ranks bit-identical, and equal to ONE process that renders the same four views per step
+    and adds their gradient blocks with the same association (mini_trainer's virtual ranks)."""
+    from tests import mini_trainer as T
+    world, V = 2, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_train_worker, args=(r, world, port, q, V, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    case, opt = _dp_case_and_opt()
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(2)
+    try:
+        ref = T.train(case, opt, "oracle", eval_every=60, seed=0, views_per_step=world * V, return_model=True, views_per_rank=V,
+                      exchange=exchange)
+    finally:
+        torch.set_num_threads(nthreads)
+    ref_sig = _model_signature(ref["model"])
+    res = sorted(q.get(timeout=800) for _ in range(world))
+    for p in procs:
+        p.join(30)
+    assert [r[1] for r in res] == ["ok", "ok"], res
+    assert res[0][2] == res[1][2], "the two ranks hold different models"
+    assert len(set(ref["P"])) >= 2, ref["P"]
+    assert res[0][3] == ref["P"] and res[0][2] == ref_sig, (res[0][3], ref["P"])
     assert res[0][4] == ref["psnr"]

@@ -1,0 +1,240 @@
+"""The REFERENCE's own Python, UNMODIFIED, on top of the drop-in packages.
+
+Everything here imports the reference's files as they are -- /root/reference in the build container, oracle/_ref/refpy.tar.gz
+on the GPU box (oracle/refpy.py; git-ignored, travels with the gpurun snapshot only) -- with `xray_gaussian_rasterization_
+voxelization` and `simple_knn` resolving to this repo's import shims, and stand-ins only for third-party modules that are not
+installed and never called on this path (plyfile, open3d, cv2, skimage).  A synthetic cone-beam case is written to disk in the
+reference's own dataset layout (data_generator/synthetic_dataset/generate_data.py:70-101: meta_data.json, proj_train/*.npy,
+proj_test/*.npy, vol_gt.npy, init_<case>.npy) so that the reference's Scene / dataset readers / Camera build every input.
+
+* test_reference_render_query_against_the_oracle: Scene -> GaussianModel.create_from_pcd (-> distCUDA2) -> training_setup ->
+  the reference's render() and query() (render_query.py:27-160): image, volume, radii, viewspace_points.grad and the leaf
+  gradients of the RAW parameters against the CPU oracle; then add_densification_stats / densify_and_prune / optimizer.step
+  for a few rounds (gaussian_model.py:503-556), re-checked against the oracle afterwards.
+* test_reference_train_py_runs_unmodified: `train.py` itself as __main__ (runpy) for a few hundred iterations incl.
+  densification, evaluation (3D PSNR) and model saving; the saved point_cloud.pickle is read back with r2_gaussian_amd.model_io
+  and rendered on the HIP path against the oracle.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASE = "synth_cone"
+
+
+@pytest.fixture(scope="module")
+def ref_tree():
+    from oracle import refpy
+    if not refpy.available():
+        pytest.skip("the reference's Python is not on this machine (no /root/reference, no oracle/_ref/refpy.tar.gz)")
+    t = refpy.tree()
+    refpy.stub_missing_third_party()
+    if t not in sys.path:
+        sys.path.insert(0, t)
+    return t
+
+
+def write_dataset(root, detector=128, n_vol=64, n_train=20, n_test=4, n_init=4000, p_gt=4000):
+    """The synthetic case in the reference's on-disk layout; projections / volume by the oracle (tests/mini_trainer.Case)."""
+    from tests import mini_trainer as T
+    d = os.path.join(root, CASE)
+    if os.path.exists(os.path.join(d, "meta_data.json")):
+        return d
+    case = T.Case(detector=detector, n_vol=n_vol, n_views=n_train, p_gt=p_gt, n_init=n_init, seed=2)
+    os.makedirs(os.path.join(d, "proj_train"), exist_ok=True)
+    os.makedirs(os.path.join(d, "proj_test"), exist_ok=True)
+    scanner = dict(S.CONE_BEAM, nVoxel=[n_vol] * 3, nDetector=[detector, detector], accuracy=0.5, totalAngle=360.0,
+                   startAngle=0.0, noise=False, filter=None)
+    meta = {"scanner": scanner, "vol": "vol_gt.npy", "bbox": [[-1, -1, -1], [1, 1, 1]], "proj_train": [], "proj_test": []}
+    np.save(os.path.join(d, "vol_gt.npy"), case.vol_gt.numpy())
+    for i, (v, p) in enumerate(zip(case.views, case.projs)):
+        f = os.path.join("proj_train", "proj_train_%04d.npy" % i)
+        np.save(os.path.join(d, f), p[0].numpy())
+        meta["proj_train"].append({"file_path": f, "angle": float(v.angle)})
+    from oracle import oracle as O
+    gt = S.make_cloud(p_gt, seed=2)
+    a = Hh.cloud_np(gt)
+    for i, ang in enumerate(np.linspace(0.1, 2 * np.pi + 0.1, n_test + 1)[:-1]):
+        v = S.make_view(float(ang), (detector, detector))
+        st = O.raster_forward(a[0], a[1], a[2], a[3], 1.0, None, v.world_view_transform.numpy(), v.full_proj_transform.numpy(),
+                              v.tanfovx, v.tanfovy, detector, detector, v.mode)
+        f = os.path.join("proj_test", "proj_test_%04d.npy" % i)
+        np.save(os.path.join(d, f), st["color"][0])
+        meta["proj_test"].append({"file_path": f, "angle": float(ang)})
+    init = np.concatenate([case.init_xyz.numpy(), case.init_density.numpy()[:, None]], 1).astype(np.float32)
+    np.save(os.path.join(d, "init_%s.npy" % CASE), init)
+    with open(os.path.join(d, "meta_data.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+    return d
+
+
+@pytest.fixture(scope="module")
+def dataset(tmp_path_factory):
+    return write_dataset(str(tmp_path_factory.mktemp("refdata")))
+
+
+def _activated_np(pc):
+    with torch.no_grad():
+        return [t.detach().float().cpu().contiguous() for t in (pc.get_xyz, pc.get_density, pc.get_scaling, pc.get_rotation)]
+
+
+def _check_render_query(pc, cam, render, query, pipe, scanner_cfg, oracle, label, check_grads=True):
+    """The reference's render() / query() on its own GaussianModel vs the oracle on the same activated parameters."""
+    x, d, s, r = _activated_np(pc)
+    c = S.Cloud(x, s, r, d.reshape(-1, 1))
+    H, W = int(cam.image_height), int(cam.image_width)
+    import math
+    v = S.View(float(cam.angle), int(cam.mode), H, W, math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5),
+               cam.world_view_transform.cpu(), cam.full_proj_transform.cpu(), cam.camera_center.cpu())
+    for g in pc.optimizer.param_groups:
+        g["params"][0].grad = None
+    pkg = render(cam, pc, pipe)
+    o = Hh.oracle_raster(oracle, c, v)
+    assert np.array_equal(pkg["radii"].cpu().numpy(), o["radii"]), "radii"
+    Hh.parity_image(oracle, o, pkg["render"].detach().cpu().numpy(), label + " render()")
+    vol = query(pc, scanner_cfg["offOrigin"], scanner_cfg["nVoxel"], scanner_cfg["sVoxel"], pipe)["vol"]
+    n = tuple(int(k) for k in scanner_cfg["nVoxel"])
+    ov = Hh.oracle_voxel(oracle, c, n, tuple(float(k) for k in scanner_cfg["sVoxel"]),
+                         tuple(float(k) for k in scanner_cfg["offOrigin"]))
+    Hh.parity_volume(oracle, ov, vol.detach().cpu().numpy(), label + " query()")
+    if not check_grads:
+        return pkg
+    # backward of the rendered image alone with a fixed upstream gradient: viewspace_points.grad are raw sums of the render
+    # backward (pure check); the leaves are the RAW parameters behind the reference's activations, so their reference values
+    # are the oracle's gradients pushed through the same activations on the CPU
+    dL = S.make_pixel_grad(H, W)
+    pkg["render"].backward(dL.to(pkg["render"].device))
+    from oracle import parity as Pz
+    sums, a64, f64 = oracle.raster_backward_audit(o, dL.numpy())
+    g2 = pkg["viewspace_points"].grad.cpu().numpy().astype(np.float64)
+    tol = Pz.RTOL * a64[:, :2] + f64[:, :2]
+    assert (np.abs(g2[:, :2] - sums[:, :2]) <= tol).all(), "viewspace_points.grad differs from the oracle's sums"
+    assert not g2[:, 2].any()
+    vm, pm = Hh.np_view(v)
+    ref = oracle.raster_backward(o, x.numpy(), s.numpy(), r.numpy(), 1.0, None, vm, pm, v.tanfovx, v.tanfovy, dL.numpy(), acc64=True)
+    raw = {n_: getattr(pc, "_" + n_).detach().cpu().clone().requires_grad_(True) for n_ in ("xyz", "density", "scaling", "rotation")}
+    act = [raw["xyz"], pc.density_activation(raw["density"]), pc.scaling_activation(raw["scaling"]),
+           pc.rotation_activation(raw["rotation"])]
+    torch.autograd.backward(act, [torch.from_numpy(ref["dL_dmeans3D"]), torch.from_numpy(ref["dL_dopacity"]).reshape(act[1].shape),
+                                  torch.from_numpy(ref["dL_dscales"]), torch.from_numpy(ref["dL_drotations"])])
+    for n_ in raw:
+        got = getattr(pc, "_" + n_).grad.cpu().numpy()
+        want = raw[n_].grad.numpy()
+        Hh.assert_close_scaled(got, want, 2e-4, label + " d/d_%s" % n_, atol_frac=2e-5)
+    pc.optimizer.zero_grad(set_to_none=True)
+    return pkg
+
+
+def test_reference_render_query_against_the_oracle(ref_tree, dataset, oracle, gpu, tmp_path):
+    from argparse import ArgumentParser
+    from r2_gaussian.arguments import ModelParams, OptimizationParams, PipelineParams
+    from r2_gaussian.dataset import Scene
+    from r2_gaussian.gaussian import GaussianModel, initialize_gaussian, query, render
+    import simple_knn._C as knn
+    import xray_gaussian_rasterization_voxelization as drop_in
+    assert os.path.realpath(drop_in.__file__).startswith(os.path.realpath(ROOT)), "not the drop-in package"
+    assert os.path.realpath(knn.__file__).startswith(os.path.realpath(ROOT))
+    parser = ArgumentParser()
+    lp, op, pp = ModelParams(parser), OptimizationParams(parser), PipelineParams(parser)
+    args = parser.parse_args(["-s", dataset, "-m", str(tmp_path / "out")])
+    ds, opt, pipe = lp.extract(args), op.extract(args), pp.extract(args)
+    scene = Scene(ds, shuffle=False)                          # the reference's readers + Camera objects
+    scanner_cfg = scene.scanner_cfg
+    volume_to_world = max(scanner_cfg["sVoxel"])
+    scale_bound = np.array([ds.scale_min, ds.scale_max]) * volume_to_world
+    pc = GaussianModel(scale_bound)
+    initialize_gaussian(pc, ds, None)                         # create_from_pcd -> distCUDA2 of the drop-in simple_knn
+    scene.gaussians = pc
+    pc.training_setup(opt)
+    P0 = pc.get_xyz.shape[0]
+    # distCUDA2 as create_from_pcd used it: the scales it produced are the clamped sqrt of the oracle's brute-force distances
+    init = np.load(os.path.join(dataset, "init_%s.npy" % CASE))
+    d2 = np.clip(oracle.knn_dist2(init[:, :3].astype(np.float32)), 0.001 ** 2, None)
+    with torch.no_grad():
+        got_s = pc.get_scaling[:, 0].cpu().numpy()
+    want_s = np.clip(np.sqrt(d2), scale_bound[0] + 1e-5, scale_bound[1] - 1e-5)    # EPS of gaussian_model.py:33,152-155
+    np.testing.assert_allclose(got_s, want_s, rtol=1e-4, atol=1e-7)
+    cams = scene.getTrainCameras()
+    _check_render_query(pc, cams[3], render, query, pipe, scanner_cfg, oracle, "REFERENCE python, init")
+    # a few training iterations exactly as train.py:97-177 strings them together, with a densification every 10
+    from r2_gaussian.utils.loss_utils import l1_loss, ssim, tv_3d_loss
+    bbox = scene.bbox
+    tvN = torch.tensor([opt.tv_vol_size] * 3)
+    tvS = torch.tensor(scanner_cfg["dVoxel"]) * tvN
+    torch.manual_seed(0)
+    counts = [P0]
+    for it in range(1, 41):
+        pc.update_learning_rate(it)
+        cam = cams[it % len(cams)]
+        pkg = render(cam, pc, pipe)
+        gt = cam.original_image.cuda()
+        loss = l1_loss(pkg["render"], gt) + opt.lambda_dssim * (1.0 - ssim(pkg["render"], gt))
+        ctr = (bbox[0] + tvS / 2) + (bbox[1] - tvS - bbox[0]) * torch.rand(3)
+        loss = loss + opt.lambda_tv * tv_3d_loss(query(pc, ctr, tvN, tvS, pipe)["vol"], reduction="mean")
+        loss.backward()
+        with torch.no_grad():
+            vis, radii = pkg["visibility_filter"], pkg["radii"]
+            pc.max_radii2D[vis] = torch.max(pc.max_radii2D[vis], radii[vis])
+            pc.add_densification_stats(pkg["viewspace_points"], vis)
+            if it % 10 == 0:
+                pc.densify_and_prune(opt.densify_grad_threshold, opt.density_min_threshold, opt.max_screen_size, None,
+                                     opt.max_num_gaussians, opt.densify_scale_threshold * volume_to_world, bbox)
+                counts.append(pc.get_xyz.shape[0])
+            pc.optimizer.step()
+            pc.optimizer.zero_grad(set_to_none=True)
+    assert counts[-1] > P0, "the reference's densify_and_prune never grew the cloud: %r" % (counts,)
+    _check_render_query(pc, cams[7], render, query, pipe, scanner_cfg, oracle, "REFERENCE python, after 40 iterations / %d -> %d" % (P0, counts[-1]))
+    Hh.PARITY_LOG.append(dict(kind="reference_python", case="render/query/densify in-process", P_history=counts))
+
+
+def test_reference_train_py_runs_unmodified(ref_tree, dataset, oracle, gpu, tmp_path):
+    out = str(tmp_path / "model")
+    n_it = 600
+    code = ("import sys, runpy; sys.path.insert(0, %r); sys.path.insert(0, %r); "
+            "from oracle import refpy; print('stubbed:', refpy.stub_missing_third_party()); "
+            "sys.argv = ['train.py', '-s', %r, '-m', %r, '--iterations', '%d', '--densify_from_iter', '100', "
+            "'--densify_until_iter', '400', '--densification_interval', '50', '--position_lr_max_steps', '%d', "
+            "'--density_lr_max_steps', '%d', '--scaling_lr_max_steps', '%d', '--rotation_lr_max_steps', '%d', "
+            "'--test_iterations', '300']; "
+            "runpy.run_path(%r, run_name='__main__')"
+            % (ROOT, ref_tree, dataset, out, n_it, n_it, n_it, n_it, n_it, os.path.join(ref_tree, "train.py")))
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + ref_tree + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ref_tree, env=env, capture_output=True, text=True, timeout=900)
+    tail = (r.stdout[-3000:] + "\n" + r.stderr[-3000:])
+    assert r.returncode == 0, tail
+    assert "Training complete." in r.stdout, tail
+    import yaml
+    ev = {}
+    for it in (1, 300, n_it):
+        with open(os.path.join(out, "eval", "iter_%06d" % it, "eval3d.yml")) as f:
+            ev[it] = yaml.safe_load(f)
+    assert ev[n_it]["psnr_3d"] > ev[1]["psnr_3d"] + 3.0, ev        # the reference's loop learns on the HIP kernels
+    assert ev[n_it]["psnr_3d"] >= ev[300]["psnr_3d"] - 0.5, ev
+    # the model the reference saved (Scene.save -> GaussianModel.save_ply pickle) through this repo's loader, HIP vs oracle
+    from r2_gaussian_amd import model_io
+    p = os.path.join(out, "point_cloud", "iteration_%d" % n_it, "point_cloud.pickle")
+    m = model_io.load_point_cloud(p, device="cpu")
+    with torch.no_grad():
+        x, d, s, q = (t.float().contiguous() for t in model_io.activate(m))
+    c = S.Cloud(x, s, q, d.reshape(-1, 1))
+    v = S.make_views(20, (128, 128))[5]
+    o = Hh.oracle_raster(oracle, c, v)
+    h = Hh.hip_raster(c, v, gpu)
+    Hh.check_binning(h, o)
+    Hh.parity_image(oracle, o, h["color"], "model saved by the reference's train.py (P %d)" % x.shape[0])
+    vol_pred = np.load(os.path.join(out, "point_cloud", "iteration_%d" % n_it, "vol_pred.npy"))
+    ov = Hh.oracle_voxel(oracle, c, (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0))
+    Hh.parity_volume(oracle, ov, vol_pred, "vol_pred.npy saved by the reference's train.py")
+    Hh.PARITY_LOG.append(dict(kind="reference_python", case="train.py as __main__, %d iterations" % n_it, P=int(x.shape[0]),
+                              psnr_3d={str(k): round(float(e["psnr_3d"]), 3) for k, e in ev.items()},
+                              ssim_3d={str(k): round(float(e["ssim_3d"]), 4) for k, e in ev.items()}))
