@@ -276,6 +276,15 @@ R2_API int r2_fdk_backproject(int V, int H, int W, const float *filtered_t, cons
  * 1: use them (default; the environment variable R2_DEPTH_HINT=0 also switches them off), 2: forget the history. */
 R2_API void r2_depth_hint_control(int mode);
 
+/* Tile-first binning of the rasterizer forward (csrc/raster_tilefirst.hip): single-view calls whose instance count the
+ * calling thread can predict from its recent calls with the same P and detector size skip the global depth order -- instances
+ * are counted and scattered per tile and every tile list is sorted on (depth, id) on its own -- and size the binning / image
+ * state by that prediction (the exact count is still returned; a prediction that falls short only costs a second pass).
+ * point_list, ranges, images and gradients are identical on both chains.  mode 0: never, 1: when applicable (default; the
+ * environment variable R2_TILE_FIRST=0 also switches it off), 2: forget the calling thread's predictions (its next call of any
+ * size takes the general chain). */
+R2_API void r2_tile_first_control(int mode);
+
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
 /* Byte offsets of the private arrays inside the state buffers of a forward call with the given sizes; lets
  * tests read the binning intermediates back without fixing the layout in the ABI.  which:

@@ -52,6 +52,7 @@ _SIGNATURES = {
     "r2_profile_read": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_sync_wait_stats": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_depth_hint_control": (None, [_i]),
+    "r2_tile_first_control": (None, [_i]),
     "r2_profile_host": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong), _i]),
     "r2_raster_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, C.POINTER(C.c_int)]),
     "r2_voxel_state_offset": (C.c_longlong, [_i, _i, C.c_longlong, _i, _i, _i, C.POINTER(C.c_int)]),

@@ -31,6 +31,7 @@ SOURCES = {
     "raster_geom.hip": EXACT,
     "raster_render.hip": FAST,
     "raster_api.hip": FAST,
+    "raster_tilefirst.hip": FAST,
     "voxel_geom.hip": EXACT,
     "voxel_render.hip": FAST,
     "voxel_api.hip": FAST,

@@ -40,6 +40,18 @@ static int raster_forward_impl(
     }
     const int PV = P * V;   // view instances: everything between the preprocess and the render kernels works on these
 
+    // tile-first binning (raster_tilefirst.hip): single views whose instance count this thread can predict from its recent
+    // calls; everything else -- first call of a size, batched views, debug mode, huge grids -- takes the chain below
+    if (V == 1 && !debug) {
+        const int r = raster_forward_tilefirst(what, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user,
+                                               P, width, height, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                               viewmatrices, projmatrices, tan_fovx, tan_fovy, mode, out_color, radii, s);
+        if (r != TF_NOT_TAKEN) {
+            if (r >= 0) host_mark_forward_end();
+            return r;
+        }
+    }
+
     char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, PV).bytes, geometry_user);
     if (!gchunk) {
         set_error("%s: state allocation callback returned NULL", what);
@@ -179,6 +191,7 @@ static int raster_forward_impl(
     launch_raster_render_forward(geom, bin, img, width, height, V, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
                                  /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
+    if (V == 1) raster_tilefirst_note(P, width, height, num_rendered, hw[DW_USER] != 0);   // the next call's prediction
     host_mark_forward_end();
     return (int)num_rendered;
 }

@@ -113,11 +113,14 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx, int gy,
     float *__restrict__ partial, uint32_t *__restrict__ tile_done, float *__restrict__ out_color, int W, int H,
-    uint32_t *__restrict__ tiles)
+    uint32_t *__restrict__ tiles, char *tf_bin_base, const uint32_t *__restrict__ tf_words)
 {
     const uint32_t w = blockIdx.x;
     R2_TS_AT(render, 0);
     if (w >= chunk_base[FUSED ? T + 1 : T]) return;
+    // tile-first forward: the binning buffer was carved with a PREDICTED instance count; the backward will carve it with the true
+    // one, so the per-instance tile ids go where that carve puts them (raster_state.hpp)
+    if (FUSED && tf_bin_base != nullptr) tiles = binning_tiles_ptr(tf_bin_base, (size_t)tf_words[DW_TOTAL]);
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     int tx, ty, tv;   // tile column / row inside its view, view (batched views stack their tile grids)
@@ -752,18 +755,19 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
 // ------------------------------------------------------------------------------------------------ launchers
 template <bool MV>
 static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int gx, int gy, uint32_t T,
-                       float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s)
+                       float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s,
+                       char *tf_bin_base, const uint32_t *tf_words)
 {
     if (fused_combine && !write_ncontrib && im.NW > 0) {
         // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
         if (any_thin)
             raster_render_forward_kernel<true, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles);
+                fill_tiles, tf_bin_base, tf_words);
         else
             raster_render_forward_kernel<false, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles);
+                fill_tiles, tf_bin_base, tf_words);
         return;
     }
     if (im.NW > 0) {
@@ -772,10 +776,10 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.partial_last);
         else if (any_thin)
             raster_render_forward_kernel<true, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr);
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr, nullptr, nullptr);
         else
             raster_render_forward_kernel<false, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr);
+                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr, nullptr, nullptr);
     }
     if (write_ncontrib)
         raster_combine_kernel<true, MV><<<dim3(T), dim3(256), 0, s>>>(im.chunk_base, im.partial, im.partial_last, W, H, gx, gy,
@@ -787,12 +791,12 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
 
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
-                                 hipStream_t s)
+                                 hipStream_t s, char *tf_bin_base, const uint32_t *tf_words)
 {
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy * (uint32_t)V;   // the views' tile grids, stacked
-    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s);
-    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s);
+    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words);
+    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words);
     return 0;
 }
 

@@ -95,8 +95,14 @@ struct RasterGeom {
     size_t dorder_bytes;
     char *psort_temp;
     size_t psort_bytes;
+    // tile-first binning (raster_tilefirst.hip) only, carved BEHIND everything else so that the layout the backward and the
+    // introspection compute from P alone is unchanged: the Gaussian's tile rectangle (depth_rect_pack) and, per producer
+    // workgroup of TF_WG Gaussians and tile, the offset of that workgroup's instances inside the tile's list
+    uint32_t *tf_rect;        // [P]
+    uint32_t *tf_wgoff;       // [ceil(P / TF_WG)][T]
+    uint32_t *tf_wgmm;        // [ceil(P / TF_WG)][2] key range {max, ~min} of every producer workgroup
     size_t bytes;
-    static RasterGeom carve(char *chunk, int P)
+    static RasterGeom carve(char *chunk, int P, size_t tf_T = 0)
     {
         RasterGeom g;
         Bump b(chunk);
@@ -117,6 +123,9 @@ struct RasterGeom {
         g.host_words = chunk ? depth_order_words(g.dorder_temp, (size_t)P) : nullptr;
         g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order (kept apart: the control block at
         g.psort_temp = b.take<char>(g.psort_bytes);   // the start of dorder_temp must survive until the backward)
+        g.tf_rect = b.take<uint32_t>(tf_T ? (size_t)P : 0);
+        g.tf_wgoff = b.take<uint32_t>(tf_T ? ((size_t)P + 1023) / 1024 * tf_T : 0);
+        g.tf_wgmm = b.take<uint32_t>(tf_T ? ((size_t)P + 1023) / 1024 * 2 : 0);
         g.bytes = b.total();
         return g;
     }
@@ -139,17 +148,46 @@ struct RasterBinning {
     {
         RasterBinning s;
         Bump b(chunk);
-        s.tiles_unsorted = b.take<uint32_t>(R);
+        // Order matters (round 4): the tile-first forward sizes this buffer by a PREDICTED instance count and launches its
+        // kernels before the host knows R, while the backward carves it with the true R.  What crosses from forward to backward
+        // must therefore sit where both agree: point_list at offset 0, and tiles right behind it, at align128(4 R) -- an
+        // address the forward's last kernel computes ON THE DEVICE from the R it reads there (binning_tiles_ptr).  Everything
+        // else is scratch of one side only.
+        s.point_list = b.take<uint32_t>(R);
         s.tiles = b.take<uint32_t>(R);
+        s.tiles_unsorted = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
         s.inv = b.take<uint32_t>(R);
-        s.point_list = b.take<uint32_t>(R);
         s.part = b.take<float>(R * PART_STRIDE);
         s.sort_bytes = sort_temp_bytes(R);
         s.sort_temp = b.take<char>(s.sort_bytes);
         s.bytes = b.total();
         return s;
     }
+};
+
+// bin.tiles of a binning buffer carved with R instances, from its base (see RasterBinning::carve; Bump aligns to 128 bytes)
+__host__ __device__ __forceinline__ uint32_t *binning_tiles_ptr(char *base, size_t R)
+{
+    return reinterpret_cast<uint32_t *>(base + (((R * sizeof(uint32_t)) + 127) & ~size_t(127)));
+}
+
+constexpr uint32_t TF_SMALL_CAP = 1536;     // tile-first: tile lists beyond this many entries get a whole sort workgroup (raster_tilefirst.hip)
+constexpr int TF_WG = 1024;                 // tile-first: Gaussians per producer workgroup (preprocess and scatter share the mapping);
+                                            // large, so that few workgroups bump the same tile counter (same-address atomics
+                                            // retire at ~90 per microsecond device-wide) and the scatter's per-workgroup scan amortises
+constexpr uint32_t TF_MAX_TILES = 4096;     // tile-first: per-workgroup LDS histogram over the tiles
+constexpr int TF_NOT_TAKEN = -1000001;      // raster_forward_tilefirst: nothing launched, run the general chain
+constexpr uint32_t TF_MARK = 0x71FEu;       // host word DW_PMAX of a forward that took the tile-first path (introspection)
+// Counters of the tile-first path that several workgroups of one kernel bump with atomics.  They live in a small persistent
+// allocation per (host thread, device, stream) and are SELF-RESETTING: whoever consumes a counter last puts the zero back, so no
+// zero-fill launch precedes the forward (a launch boundary costs 3-4 us).  All zero between calls.
+struct TFCounters {
+    unsigned long long total;   // (visible Gaussians << 40) | instances handed out so far (a workgroup's base = the low bits)
+    uint32_t done;              // producer workgroups that have finished
+    uint32_t thin;              // a Gaussian needs the re-anchored row recurrence (row_tier == 1)
+    uint32_t pad[12];
+    uint32_t tile_count[TF_MAX_TILES];   // instances per tile
 };
 
 struct RasterImage {
@@ -162,9 +200,13 @@ struct RasterImage {
     uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
     uint32_t *n_contrib;   // [N]  last contributing list position per pixel; only written in debug mode
     char *work_temp;       // scratch of the parallel work-list construction (only for > 4096 tiles)
+    uint4 *tf_parts;       // [NP + T] tile-first only (forward scratch): the sort kernel's work lists -- NP "big" parts {tile,
+                           //      part | parts << 16, first instance, instances}, then up to T short lists {tile, 0, first, instances}
+    size_t NP;             // upper bound on big parts: every one stands for > TF_SMALL_CAP instances
     size_t NW;             // upper bound on work items: R/FWD_CHUNK + T
     size_t bytes;
-    static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug)
+    // everything the backward or the introspection reads (ranges, chunk_base) sits at offsets that depend on T only
+    static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug, bool tile_first = false)
     {
         RasterImage s;
         Bump b(chunk);
@@ -177,6 +219,8 @@ struct RasterImage {
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
         s.n_contrib = b.take<uint32_t>(debug ? N : 0);
         s.work_temp = b.take<char>(build_work_temp_bytes(T));
+        s.NP = tile_first ? R / TF_SMALL_CAP + 1 : 0;
+        s.tf_parts = b.take<uint4>(tile_first ? s.NP + T : 0);
         s.bytes = b.total();
         return s;
     }
@@ -187,6 +231,12 @@ int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, c
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
+// tile-first binning, first kernel: the preprocess + per-tile instance counts + every Gaussian's run of scratch rows; its last
+// workgroup posts {num_rendered, thin flag, visible count} to the state's host words and to the mailbox
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
+                                const float *rotations, const float *opacities, const float *cov3D_precomp, const float *view,
+                                const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode, int *radii,
+                                TFCounters *ctr, uint32_t *mailbox, uint32_t seq, hipStream_t s);
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P /* per view */, int V, const int *radii, int W, int H,
                             const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);
@@ -204,9 +254,18 @@ int launch_raster_geom_backward(int P /* per view */, int V, const float *means3
                                 float *dL_dmu, float *dL_dmean2D, float *dL_dopacity, float *dL_dmean3D,
                                 float *dL_dcov3D, float *dL_dscale, float *dL_drot, int mode, const RasterGeom &g,
                                 const float *part, hipStream_t s);
+// tf_bin_base / tf_words (tile-first forward only): fill_tiles is then computed ON THE DEVICE as binning_tiles_ptr(tf_bin_base,
+// tf_words[DW_TOTAL]) -- the binning buffer was carved with a predicted count, the backward will carve it with the true one
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
-                                 hipStream_t s);
+                                 hipStream_t s, char *tf_bin_base = nullptr, const uint32_t *tf_words = nullptr);
+// raster_tilefirst.hip
+int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer,
+                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height,
+                             const float *means3D, const float *opacities, const float *scales, float scale_modifier,
+                             const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                             float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s);
+void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin);   // a finished forward's count: the next prediction
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 

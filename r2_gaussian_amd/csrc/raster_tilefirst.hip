@@ -1,0 +1,559 @@
+// raster_tilefirst.hip -- tile-first binning of the X-ray rasterizer (round 4): the reference's
+// duplicateWithKeys -> SortPairs(tile | depth) -> identifyTileRanges (RAS/rasterizer_impl.cu:70-138,275-316) as
+//     1. raster_preprocess_tf_kernel (raster_geom.hip)   preprocess + per-tile instance counts (LDS histogram per workgroup, one
+//                                                        returning global atomic per (workgroup, tile)) + totals to the host
+//     2. raster_tf_scatter_kernel                        every instance straight into its TILE's segment of the list, as a
+//                                                        (depth key, Gaussian id) pair, in arbitrary order inside the segment;
+//                                                        workgroup 0 also builds tile ranges, the render work list and the
+//                                                        sort parts
+//     3. raster_tf_sort_kernel                           one workgroup per tile (long lists: several, by depth range) sorts its
+//                                                        segment by (depth key, id) in LDS and writes point_list
+// A stable sort by tile followed by a sort of every tile's entries on (depth bits, id) IS the reference's (tile | depth) order
+// with its tie rule: point_list and ranges are bit-identical to the global-depth-order chain (raster_api.hip), which stays as
+// the general path (first call of a size, batched views, debug mode, grids of more than 4096 tiles).
+//
+// Why (profiles/r03e_step_timeline.md): the global depth order costs the forward six launches -- zero-fill,
+// preprocess with one 64-bit bucket atomic per Gaussian, dual scan x 2, place, rank -- before a single instance is emitted, and
+// every launch boundary on this part is 3-5 us.  Here the forward is preprocess -> scatter -> sort -> render: no zero-fill (the
+// counters are self-resetting), no scan kernel (every scatter workgroup scans the <= 4096 tile counts itself), no radix pass.
+//
+// The host round trip.  num_rendered sizes the binning / image state (the reference's D2H, RAS/rasterizer_impl.cu:279).  The old
+// chain hides it behind place + rank; here nothing is left to hide it behind, so the two buffers are sized by a PREDICTION (the
+// largest count of the thread's recent calls with this P, + 25 %) and kernels 2-4 are enqueued at once; they read the true count
+// on the device and do nothing when it exceeds the prediction, in which case the host -- which reads the count from the mailbox
+// as before -- sizes the buffers exactly and enqueues them again.  Results never depend on the prediction.
+// What must survive from forward to backward sits at prediction-independent offsets (RasterBinning::carve).
+#include "raster_state.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <vector>
+
+R2_TS_DEFINE(tilefirst)
+
+namespace r2 {
+
+namespace {
+
+constexpr int TFS_THREADS = TF_WG;      // scatter: the producer's mapping (raster_preprocess_tf_kernel)
+// ---- the sort kernel: 1024-thread workgroups of two kinds
+//   "big"    one tile list of > TFK_SMALL_CAP entries (or one depth range of a list beyond TFK_BIG_CAP) sorted by the whole workgroup;
+//   "quad"   four lists of <= TFK_SMALL_CAP entries, one per 256-thread quarter of the workgroup, in lockstep (same code, common
+//            barriers, own slice of the LDS).
+// (Measured on the way, 300k / 512^2: one workgroup per <= 4096-entry PART of a list, every part histogramming the whole list to
+//  find its depth range, spent 25 us -- the dense tiles hold most of the instances and were read 2-3 x S times; lists up to 12288
+//  entries now take ONE pass in one workgroup; 12288 entries / 116 KB of LDS = one workgroup per CU: 18 us, two rounds.)
+constexpr int TFK_THREADS = 1024;
+constexpr uint32_t TFK_SMALL_CAP = 1536, TFK_SMALL_PER = 6, TFK_SMALL_BINS = 1024;     // per 256-thread quarter
+constexpr uint32_t TFK_BIG_CAP = 8192, TFK_BIG_PER = 8, TFK_BIG_BINS = 2048;           // whole workgroup (76 KB of LDS: two per CU)
+constexpr uint32_t TFK_BIG_TARGET = 5120;   // lists beyond TFK_BIG_CAP: ceil(n / 5120) parts, each a range of the list's depth histogram
+constexpr uint32_t TFK_COARSE = 1024;       // bins of that histogram (one per thread)
+constexpr size_t TFK_LDS = TFK_BIG_CAP * sizeof(unsigned long long) + (TFK_BIG_BINS + 1 + TFK_COARSE + 1) * sizeof(uint32_t);
+static_assert(4 * TFK_SMALL_CAP * sizeof(unsigned long long) + 4 * (TFK_SMALL_BINS + 1) * sizeof(uint32_t) <= TFK_LDS, "quads fit the big layout");
+static_assert(TFK_COARSE == TFK_THREADS && TFK_BIG_CAP >= TFK_BIG_TARGET + TFK_BIG_TARGET / 2, "parts need slack over their target size");
+
+// ---- 2. scatter.  Workgroup 0 does not scatter: it builds the tile ranges, the render kernel's work list and the sort kernel's
+// work lists from the tile counts while the others run (as block 0's epilogue this serial job was the kernel's tail)
+__global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
+    int P, int gx, uint32_t T, const uint32_t *__restrict__ rects, const uint32_t *__restrict__ depth_key,
+    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff, const uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ words, uint32_t cap, uint2 *__restrict__ pairs, WorkListOut wo, uint4 *__restrict__ big_parts,
+    uint32_t big_cap, uint4 *__restrict__ small_tiles, uint32_t *__restrict__ nparts /* [2]: big parts, small tiles */)
+{
+    extern __shared__ uint32_t s_pos[];   // [T] start of the tile's segment + this workgroup's offset in it, bumped per instance
+    __shared__ uint32_t s_wsum[3][TFS_THREADS / 64], s_carry[3];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    R2_TS_AT(tilefirst, 0);
+    const uint32_t R = words[DW_TOTAL];
+    if (R > cap) {   // the buffers were sized by a prediction that fell short: do nothing, the host sizes them exactly and re-runs
+        if (blockIdx.x == 0 && tid == 0) { wo.chunk_base[T] = 0u; wo.chunk_base[T + 1] = 0u; nparts[0] = 0u; nparts[1] = 0u; }
+        return;
+    }
+    if (blockIdx.x == 0) {
+        // ---- tile ranges + the render kernel's work list (arrival counters zeroed, empty tiles appended) ...
+        ranges_and_work_block<TFS_THREADS>(tile_count, wo);
+        // ... + the sort kernel's two lists
+        __syncthreads();
+        if (tid < 3) s_carry[tid] = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < T; base += TFS_THREADS) {
+            const uint32_t t = base + (uint32_t)tid;
+            const uint32_t c = t < T ? tile_count[t] : 0u;
+            const uint32_t nb = c > TFK_SMALL_CAP ? (c > TFK_BIG_CAP ? (c + TFK_BIG_TARGET - 1u) / TFK_BIG_TARGET : 1u) : 0u;
+            const uint32_t ns = (c != 0u && nb == 0u) ? 1u : 0u;
+            uint32_t i0 = c, i1 = nb, i2 = ns;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d);
+                if (lane >= d) { i0 += u0; i1 += u1; i2 += u2; }
+            }
+            if (lane == 63) { s_wsum[0][wave] = i0; s_wsum[1][wave] = i1; s_wsum[2][wave] = i2; }
+            __syncthreads();
+            uint32_t o0 = 0, o1 = 0, o2 = 0;
+            for (int w = 0; w < wave; ++w) { o0 += s_wsum[0][w]; o1 += s_wsum[1][w]; o2 += s_wsum[2][w]; }
+            const uint32_t start = s_carry[0] + o0 + i0 - c, bstart = s_carry[1] + o1 + i1 - nb, sstart = s_carry[2] + o2 + i2 - ns;
+            for (uint32_t q = 0; q < nb; ++q)
+                if (bstart + q < big_cap) big_parts[bstart + q] = make_uint4(t, q | (nb << 16), start, c);
+            if (ns) small_tiles[sstart] = make_uint4(t, 0u, start, c);
+            __syncthreads();
+            if (tid == TFS_THREADS - 1) { s_carry[0] = start + c; s_carry[1] = bstart + nb; s_carry[2] = sstart + ns; }
+            __syncthreads();
+        }
+        if (tid == 0) { nparts[0] = min(s_carry[1], big_cap); nparts[1] = s_carry[2]; }
+        R2_TS_AT(tilefirst, 2);
+        return;
+    }
+    const uint32_t wg = blockIdx.x - 1u;
+    // ---- exclusive scan of the tile counts (every workgroup for itself: <= 16 KB, cheaper than a launch boundary)
+    for (uint32_t t = tid; t < T; t += TFS_THREADS) s_pos[t] = tile_count[t];
+    __syncthreads();
+    const uint32_t ipt = (T + TFS_THREADS - 1) / TFS_THREADS;
+    const uint32_t t0 = (uint32_t)tid * ipt, t1 = min(t0 + ipt, T);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += s_pos[t];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    if (lane == 63) s_wsum[0][wave] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wsum[0][w];
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = s_pos[t];
+        s_pos[t] = run;
+        run += c;
+    }
+    __syncthreads();
+    // ... + where this workgroup's instances start inside each segment (rows of tiles it does not touch hold stale words:
+    // they are added to slots nobody reads)
+    const uint32_t *__restrict__ my_off = wgoff + (size_t)wg * T;
+    for (uint32_t t = tid; t < T; t += TFS_THREADS) s_pos[t] += my_off[t];
+    __syncthreads();
+    // ---- every instance of this workgroup's Gaussians
+    const int idx = (int)wg * TFS_THREADS + tid;
+    if (idx < P && tiles_touched[idx] != 0u) {
+        const uint32_t rect = rects[idx], key = depth_key[idx];
+        const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
+        for (uint32_t r = 0; r < h; ++r) {
+            const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
+            for (uint32_t c = 0; c < w; ++c) {
+                const uint32_t pos = atomicAdd(&s_pos[row + c], 1u);
+                pairs[pos] = make_uint2(key, (uint32_t)idx);
+            }
+        }
+    }
+    R2_TS_AT(tilefirst, 1);
+}
+
+// ---- 3. per-tile sort
+__device__ __forceinline__ unsigned long long tf_pack(const uint2 e) { return ((unsigned long long)e.x << 32) | (unsigned long long)e.y; }
+
+// (kmin, kmax) over the NT threads of a group (waves w0 .. w0 + NT / 64) -> every thread of the group; two workgroup barriers
+template <int NT>
+__device__ __forceinline__ void tf_group_minmax(uint32_t &kmin, uint32_t &kmax, uint32_t (*s_mm)[TFK_THREADS / 64], int lane, int wave, int w0)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, d));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, d));
+    }
+    __syncthreads();
+    if (lane == 0) { s_mm[0][wave] = kmin; s_mm[1][wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { kmin = min(kmin, s_mm[0][w0 + w]); kmax = max(kmax, s_mm[1][w0 + w]); }
+}
+
+// s_a[0, cnt) -> dst[rank by (key, id)] = id.  One-level bucket sort (see voxel_small.hip for the reasoning: a tile's depth keys
+// are float bit patterns in a narrow range, ~1.5 entries per value-linear bucket; position = bucket base + rank inside the bucket
+// by (key, id), exact whatever the distribution).  A group of NT threads (gtid = thread inside it, waves w0 ..); the barriers
+// are the WORKGROUP's: every group of the workgroup calls this together.
+template <int NT, uint32_t PER, uint32_t BINS>
+__device__ __forceinline__ void tf_sort_group(unsigned long long *s_a, uint32_t *s_bin, uint32_t *s_wsum /* workgroup's, per wave */,
+                                              int gtid, int lane, int wave, int w0, uint32_t cnt, uint32_t kmin, uint32_t kmax,
+                                              uint32_t *__restrict__ dst)
+{
+    for (uint32_t i = gtid; i <= BINS; i += NT) s_bin[i] = 0u;
+    __syncthreads();
+    const float scale = kmax > kmin ? (float)(BINS - 1) / (float)(kmax - kmin) : 0.f;
+    unsigned long long mine[PER];
+    uint32_t my_bin[PER], my_ticket[PER];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        mine[u] = 0ull; my_bin[u] = 0u; my_ticket[u] = 0u;
+        if (i < cnt) {
+            mine[u] = s_a[i];
+            my_bin[u] = min((uint32_t)((float)((uint32_t)(mine[u] >> 32) - kmin) * scale), BINS - 1u);
+            my_ticket[u] = atomicAdd(&s_bin[my_bin[u]], 1u);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr uint32_t BPT = BINS / NT;
+        static_assert(BINS % NT == 0, "whole buckets per thread");
+        uint32_t c[BPT], tsum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < BPT; ++q) { c[q] = s_bin[gtid * BPT + q]; tsum += c[q]; }
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - tsum;
+        for (int w = w0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+        for (uint32_t q = 0; q < BPT; ++q) { s_bin[gtid * BPT + q] = run; run += c[q]; }
+        if (gtid == NT - 1) s_bin[BINS] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        if (i < cnt) s_a[s_bin[my_bin[u]] + my_ticket[u]] = mine[u];   // every thread holds its entries in registers by now
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        if (i < cnt) {
+            const uint32_t b0 = s_bin[my_bin[u]], b1 = s_bin[my_bin[u] + 1u];
+            // the first four of the bucket with all reads in flight (most buckets hold fewer), the rest -- rare -- one by one
+            const unsigned long long e0 = s_a[b0], e1 = s_a[min(b0 + 1u, b1 - 1u)], e2 = s_a[min(b0 + 2u, b1 - 1u)],
+                                     e3 = s_a[min(b0 + 3u, b1 - 1u)];
+            uint32_t r = (e0 < mine[u] ? 1u : 0u) + ((b0 + 1u < b1 && e1 < mine[u]) ? 1u : 0u) +
+                         ((b0 + 2u < b1 && e2 < mine[u]) ? 1u : 0u) + ((b0 + 3u < b1 && e3 < mine[u]) ? 1u : 0u);
+            for (uint32_t q = b0 + 4u; q < b1; ++q) r += s_a[q] < mine[u] ? 1u : 0u;
+            dst[b0 + r] = (uint32_t)mine[u];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
+    const uint4 *__restrict__ big_parts, const uint4 *__restrict__ small_tiles, const uint32_t *__restrict__ nparts,
+    const uint2 *__restrict__ pairs, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tile_count,
+    const uint32_t *__restrict__ words)
+{
+    extern __shared__ unsigned long long tfk_lds[];
+    __shared__ uint32_t s_mm[2][TFK_THREADS / 64], s_wsum[TFK_THREADS / 64], s_cnt, s_off;
+    const uint32_t p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    R2_TS_AT(tilefirst, 3);
+    const uint32_t nbig = nparts[0], nsmall = nparts[1];
+    if (p >= nbig) {
+        // ---- quad: four short lists, one per quarter of the workgroup
+        const uint32_t q0 = (p - nbig) * 4u;
+        if (q0 >= nsmall) return;
+        const int g = tid >> 8, gtid = tid & 255, w0 = g * 4;
+        unsigned long long *s_a = tfk_lds + (size_t)g * TFK_SMALL_CAP;
+        uint32_t *s_bin = reinterpret_cast<uint32_t *>(tfk_lds + 4 * TFK_SMALL_CAP) + (size_t)g * (TFK_SMALL_BINS + 1);
+        uint32_t n = 0, start = 0;
+        if (q0 + (uint32_t)g < nsmall) {
+            const uint4 sd = small_tiles[q0 + g];
+            start = sd.z; n = sd.w;
+            if (gtid == 0) tile_count[sd.x] = 0u;   // this call has read it for the last time: ready for the next one
+        }
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+        for (uint32_t i = gtid; i < n; i += 256u) {
+            const uint2 e = pairs[start + i];
+            s_a[i] = tf_pack(e);
+            kmin = min(kmin, e.x);
+            kmax = max(kmax, e.x);
+        }
+        tf_group_minmax<256>(kmin, kmax, s_mm, lane, wave, w0);
+        tf_sort_group<256, TFK_SMALL_PER, TFK_SMALL_BINS>(s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, point_list + start);
+        R2_TS_AT(tilefirst, 4);
+        return;
+    }
+    // ---- big: one list (or one depth range of a very long one) for the whole workgroup
+    unsigned long long *s_a = tfk_lds;                                             // [TFK_BIG_CAP]
+    uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_a + TFK_BIG_CAP);             // [TFK_BIG_BINS + 1]
+    uint32_t *s_coarse = s_bin + TFK_BIG_BINS + 1;                                 // [TFK_COARSE + 1]
+    const uint4 pd = big_parts[p];
+    const uint32_t tile = pd.x, part = pd.y & 0xFFFFu, nparts_tile = pd.y >> 16, start = pd.z, n = pd.w;
+    if (part == 0u && tid == 0) tile_count[tile] = 0u;
+    const uint2 *__restrict__ src = pairs + start;
+    uint32_t *__restrict__ dst = point_list + start;
+    uint32_t cnt = n, out_off = 0u;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    if (nparts_tile == 1u) {
+        for (uint32_t i = tid; i < n; i += TFK_THREADS) {
+            const uint2 e = src[i];
+            s_a[i] = tf_pack(e);
+            kmin = min(kmin, e.x);
+            kmax = max(kmax, e.x);
+        }
+        tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);
+    } else {
+        // ---- this part's share of a very long list: a contiguous range of the bins of a depth histogram of the WHOLE list (bins
+        // laid over the key range of the call, which the preprocess left in the host words), chosen so that the parts are
+        // balanced whatever the distribution -- every part of the tile computes the same split
+        const uint32_t gmax = words[DW_NMAX];
+        uint32_t lo = ~words[DW_NNMAX];
+        float cscale = gmax > lo ? (float)(TFK_COARSE - 1) / (float)(gmax - lo) : 0.f;
+        auto coarse_of = [&](uint32_t kk) { return min((uint32_t)((float)(max(kk, lo) - lo) * cscale), TFK_COARSE - 1u); };
+        for (uint32_t i = tid; i <= TFK_COARSE; i += TFK_THREADS) s_coarse[i] = 0u;
+        if (tid == 0) { s_cnt = 0u; s_off = 0xFFFFFFFFu; }
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += TFK_THREADS) {
+            const uint32_t kk = src[i].x;
+            atomicAdd(&s_coarse[coarse_of(kk)], 1u);
+            kmin = min(kmin, kk);
+            kmax = max(kmax, kk);
+        }
+        tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);   // (also orders the histogram's atomics before its readers)
+        {
+            // a list whose depths crowd into a few of those bins (a thin slab seen face-on) cannot be split there: lay the bins
+            // over the list's own key range instead, at the price of a third pass
+            uint32_t mb = s_coarse[tid];
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor(mb, d));
+            __syncthreads();
+            if (lane == 0) s_wsum[wave] = mb;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < TFK_THREADS / 64; ++w) mb = max(mb, s_wsum[w]);
+            if (mb > TFK_BIG_CAP / 2u && (kmin > lo || kmax < gmax)) {   // workgroup-uniform
+                __syncthreads();
+                for (uint32_t i = tid; i <= TFK_COARSE; i += TFK_THREADS) s_coarse[i] = 0u;
+                lo = kmin;
+                cscale = kmax > kmin ? (float)(TFK_COARSE - 1) / (float)(kmax - kmin) : 0.f;
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += TFK_THREADS) atomicAdd(&s_coarse[coarse_of(src[i].x)], 1u);
+            }
+            __syncthreads();
+        }
+        kmin = 0xFFFFFFFFu; kmax = 0u;   // reused below for this part's own range
+        // exclusive prefix over the bins (one per thread), part of a bin = floor(prefix * parts / n): monotone in the bin
+        const uint32_t c = s_coarse[tid];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t excl = incl - c;
+        for (int w = 0; w < wave; ++w) excl += s_wsum[w];
+        const uint32_t owner = min((uint32_t)(((unsigned long long)excl * nparts_tile) / n), nparts_tile - 1u);
+        const bool mine = owner == part && c != 0u;
+        __syncthreads();
+        s_coarse[tid] = mine ? 1u : 0u;   // from here on: "this bin is mine"
+        if (mine) {
+            atomicAdd(&s_cnt, c);
+            atomicMin(&s_off, excl);
+        }
+        __syncthreads();
+        cnt = s_cnt;
+        out_off = s_off;
+        if (cnt == 0u) return;
+        if (cnt > TFK_BIG_CAP) {
+            // (more entries of one tile inside 1/1024 of its depth range than the LDS holds: equal depths.)  Rank by counting,
+            // straight from memory: O(cnt x n).  Exact like everything else.
+            for (uint32_t i = tid; i < n; i += TFK_THREADS) {
+                const uint2 e = src[i];
+                if (s_coarse[coarse_of(e.x)] == 0u) continue;
+                const unsigned long long me = tf_pack(e);
+                uint32_t r = 0;
+                for (uint32_t j = 0; j < n; ++j) {
+                    const uint2 o = src[j];
+                    if (s_coarse[coarse_of(o.x)] != 0u && tf_pack(o) < me) ++r;
+                }
+                dst[out_off + r] = e.y;
+            }
+            return;
+        }
+        __syncthreads();
+        if (tid == 0) s_cnt = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < n; base += TFK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
+            const uint32_t i = base + (uint32_t)tid;
+            const uint2 e = src[min(i, n - 1u)];
+            const bool take = i < n && s_coarse[coarse_of(e.x)] != 0u;
+            const unsigned long long mm = __ballot(take);
+            if (mm) {
+                uint32_t wbase = 0;
+                const int leader = __ffsll((long long)mm) - 1;
+                if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(mm));
+                wbase = __shfl(wbase, leader);
+                if (take) {
+                    s_a[wbase + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = tf_pack(e);
+                    kmin = min(kmin, e.x);
+                    kmax = max(kmax, e.x);
+                }
+            }
+        }
+        tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);
+    }
+    tf_sort_group<TFK_THREADS, TFK_BIG_PER, TFK_BIG_BINS>(s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, dst + out_off);
+    R2_TS_AT(tilefirst, 4);
+}
+
+// ---- host side
+struct TFWorkspace { int dev; hipStream_t stream; TFCounters *ctr; uint32_t *nparts; bool dirty; };
+thread_local std::vector<TFWorkspace> g_tf_ws;
+
+TFWorkspace *tf_workspace(int dev, hipStream_t s)
+{
+    for (TFWorkspace &w : g_tf_ws)
+        if (w.dev == dev && w.stream == s) return &w;
+    if (g_tf_ws.size() >= 64) return nullptr;   // a thread cycling through ever new streams: the general path from here on
+    char *p = nullptr;
+    if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(TFCounters) + 64) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    g_tf_ws.push_back(TFWorkspace{dev, s, reinterpret_cast<TFCounters *>(p), reinterpret_cast<uint32_t *>(p + sizeof(TFCounters)), true});
+    return &g_tf_ws.back();
+}
+
+// the thread's recent instance counts per problem size: what the prediction is made of
+struct TFHint { int P, W, H; uint32_t recent[8]; uint32_t n; bool thin; };
+thread_local std::vector<TFHint> g_tf_hints;
+
+TFHint *tf_hint(int P, int W, int H, bool create)
+{
+    for (TFHint &h : g_tf_hints)
+        if (h.P == P && h.W == W && h.H == H) return &h;
+    if (!create) return nullptr;
+    if (g_tf_hints.size() >= 16) g_tf_hints.erase(g_tf_hints.begin());
+    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false});
+    return &g_tf_hints.back();
+}
+
+std::atomic<int> g_tf_mode{-1};   // -1: not decided yet (environment), 0: off, 1: on
+
+bool tf_enabled()
+{
+    int on = g_tf_mode.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char *e = getenv("R2_TILE_FIRST");
+        on = (e && e[0] == '0') ? 0 : 1;
+        g_tf_mode.store(on, std::memory_order_relaxed);
+    }
+    static signed char lds_state[R2_MAX_DEVICES] = {};
+    return on && TFK_LDS <= device_lds_optin_bytes() &&
+           allow_dynamic_lds(reinterpret_cast<const void *>(raster_tf_sort_kernel), (int)TFK_LDS, lds_state);
+}
+
+}  // namespace
+
+void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin)
+{
+    TFHint *h = tf_hint(P, W, H, true);
+    h->recent[h->n++ & 7u] = num_rendered;
+    h->thin = thin;
+}
+
+// -> num_rendered (>= 0), a negative error code, or TF_NOT_TAKEN: nothing was launched, run the general path
+int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer,
+                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height,
+                             const float *means3D, const float *opacities, const float *scales, float scale_modifier,
+                             const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
+                             float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s)
+{
+    const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
+    const size_t T = (size_t)gx * gy, N = (size_t)width * height;
+    const size_t wgs = ((size_t)P + TF_WG - 1) / TF_WG;
+    // rectangles are packed into bytes (<= 256 x 256 tiles), the LDS histogram holds <= 4096 tiles, instance offsets are 32-bit
+    if (T > TF_MAX_TILES || gx > 256 || gy > 256 || wgs * T > ((size_t)1 << 25) || P >= (1 << 24) || !tf_enabled())
+        return TF_NOT_TAKEN;
+    const TFHint *hint = tf_hint(P, width, height, false);
+    if (!hint || hint->n == 0) return TF_NOT_TAKEN;   // no prediction yet: the general path, which leaves one behind
+    int dev = 0;
+    R2_HIP_TRY(hipGetDevice(&dev));
+    TFWorkspace *ws = tf_workspace(dev, s);
+    if (!ws) return TF_NOT_TAKEN;
+    uint32_t rmax = 0;
+    for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
+    // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes)
+    size_t cap = (((size_t)rmax + rmax / 4 + 16384) + 65535) & ~(size_t)65535;
+    bool thin_guess = hint->thin;
+
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, T).bytes, geometry_user);
+    if (!gchunk) {
+        set_error("%s: state allocation callback returned NULL", what);
+        return R2_ERR_ALLOC;
+    }
+    const RasterGeom geom = RasterGeom::carve(gchunk, P, T);
+    if (ws->dirty) R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));   // first use, or a call that failed half way
+    ws->dirty = true;
+    uint32_t *mailbox = nullptr, mailbox_seq = 0;
+    int rc = host_mailbox_arm(&mailbox, &mailbox_seq);
+    if (rc) return rc;
+    { StageScope t(ST_RAS_PREPROCESS, s);
+    launch_raster_preprocess_tf(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix, projmatrix,
+                                width, height, tan_fovx, tan_fovy, mode, radii, ws->ctr, mailbox, mailbox_seq, s); }
+    R2_HIP_TRY(hipGetLastError());
+
+    RasterBinning bin{};
+    RasterImage img{};
+    auto enqueue = [&](size_t capacity, bool any_thin, bool render_only) -> int {
+        if (!render_only) {
+            char *bchunk = binningBuffer(RasterBinning::carve(nullptr, capacity).bytes, binning_user);
+            char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, capacity, false, true).bytes, image_user);
+            if (!bchunk || !ichunk) {
+                set_error("%s: binning/image allocation callback returned NULL", what);
+                return R2_ERR_ALLOC;
+            }
+            bin = RasterBinning::carve(bchunk, capacity);
+            img = RasterImage::carve(ichunk, T, N, capacity, false, true);
+            uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // backward scratch (32 bytes per instance), free until then
+            { StageScope t(ST_RAS_DUPLICATE, s);
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW};
+            raster_tf_scatter_kernel<<<dim3((unsigned)wgs + 1u), dim3(TFS_THREADS), T * sizeof(uint32_t), s>>>(
+                P, gx, (uint32_t)T, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, ws->ctr->tile_count,
+                geom.host_words, (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP,
+                img.tf_parts + img.NP, ws->nparts); }
+            R2_HIP_TRY(hipGetLastError());
+            { StageScope t(ST_RAS_SORT, s);
+            raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (T + 3) / 4)), dim3(TFK_THREADS), TFK_LDS, s>>>(
+                img.tf_parts, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr->tile_count, geom.host_words); }
+            R2_HIP_TRY(hipGetLastError());
+        } else {
+            R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, T * sizeof(uint32_t), s));   // the first render left its arrivals behind
+        }
+        { StageScope t(ST_RAS_RENDER_FWD, s);
+        launch_raster_render_forward(geom, bin, img, width, height, 1, out_color, false, bin.tiles, any_thin, true, s,
+                                     reinterpret_cast<char *>(bin.point_list), geom.host_words); }
+        R2_HIP_TRY(hipGetLastError());
+        return 0;
+    };
+    rc = enqueue(cap, thin_guess, false);
+    if (rc) return rc;
+    uint32_t hw[DW_COUNT] = { 0 };
+    rc = host_mailbox_wait(mailbox_seq, hw, DW_COUNT, s);
+    if (rc) return rc;
+    const uint32_t num_rendered = hw[DW_TOTAL];
+    const bool thin = hw[DW_USER] != 0u;
+    if (num_rendered > 0x7FFFFFFFu) {
+        set_error("%s: more than 2147483647 (tile, Gaussian) instances: they do not fit the 31-bit num_rendered", what);
+        return R2_ERR_INVALID;
+    }
+    if ((size_t)num_rendered > cap) {
+        rc = enqueue(num_rendered, thin, false);      // the prediction fell short: exact sizes, same kernels
+        if (rc) return rc;
+    } else if (thin && !thin_guess) {
+        rc = enqueue(cap, true, true);                // the scene holds thin Gaussians after all: render again with that variant
+        if (rc) return rc;
+    }
+    ws->dirty = false;
+    raster_tilefirst_note(P, width, height, num_rendered, thin);
+    return (int)num_rendered;
+}
+
+}  // namespace r2
+
+extern "C" void r2_tile_first_control(int mode)
+{
+    if (mode == 0 || mode == 1) r2::g_tf_mode.store(mode, std::memory_order_relaxed);
+    if (mode == 2) r2::g_tf_hints.clear();   // the calling thread's predictions
+}

@@ -212,7 +212,7 @@ int main(int argc, char **argv)
     // experiment builds (-DR2_EXP_TS) stamp s_memrealtime at phase boundaries inside selected kernels: one [phase][block]
     // table per translation unit; printed as one timeline of the last step (us since the earliest stamp)
     {
-        const char *units[] = {"order", "geom", "sort", "render"};
+        const char *units[] = {"order", "geom", "sort", "tilefirst", "render"};
         std::vector<std::vector<unsigned long long>> tabs;
         std::vector<std::string> names;
         bool any = false;

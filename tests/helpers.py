@@ -204,6 +204,13 @@ def ellipsoid_cloud(P, seed=0, scale_mult=1.0):
     return S.make_cloud(P, seed=seed, scale_mult=scale_mult)
 
 
+TF_MARK = 0x71FE   # host word DW_PMAX of a rasterizer forward that took the tile-first path
+
+
+def took_tile_first(h):
+    return int(h["host_words"][3]) == TF_MARK
+
+
 def check_binning(h, o):
     """Bit-exact comparison of the binning pipeline with the oracle.  The HIP path sorts the Gaussians by depth
     first and emits instances in that order (then sorts by tile only), so its UNSORTED arrays are a per-Gaussian
@@ -214,7 +221,8 @@ def check_binning(h, o):
     R = o["num_rendered"]
     assert np.array_equal(h["tiles_touched"], o["tiles_touched"])
     tt = o["tiles_touched"].astype(np.int64)
-    if int(h["host_words"][2]) == 0x5A11:
+    if int(h["host_words"][2]) == 0x5A11 or int(h["host_words"][3]) == TF_MARK:
+        # rasterizer, tile-first binning (csrc/raster_tilefirst.hip, marker in host word 3), or
         # voxelizer, small-grid path (csrc/voxel_small.hip): no global depth order and no emission list exist -- the per-tile
         # lists are built straight from the survivors.  What the reference defines must still match bit for bit: the sorted
         # (tile | depth) keys, point_list, ranges; and every visible Gaussian owns a run of tiles_touched scratch rows, the runs

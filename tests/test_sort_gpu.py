@@ -52,6 +52,7 @@ def test_depth_hint_paths_are_identical_and_stale_hints_are_harmless(oracle, gpu
     c = S.make_cloud(P, seed=5)
     v = S.make_view(0.0, (256, 256))   # looks along -x from (5, 0, 0): depth = 5 - x
     try:
+        L.r2_tile_first_control(0)                     # this test is about the general chain's depth order (tests/test_tilefirst_gpu.py has the other)
         L.r2_depth_hint_control(2)                     # forget the history: first call is un-hinted
         h0 = Hh.hip_raster(c, v, gpu)
         assert int(h0["host_words"][7]) == 0
@@ -107,3 +108,4 @@ def test_depth_hint_paths_are_identical_and_stale_hints_are_harmless(oracle, gpu
     finally:
         L.r2_depth_hint_control(1)
         L.r2_depth_hint_control(2)
+        L.r2_tile_first_control(1)

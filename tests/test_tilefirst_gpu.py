@@ -1,0 +1,210 @@
+"""GPU: the tile-first binning chain of the rasterizer forward (csrc/raster_tilefirst.hip, round 4).
+
+A forward takes it when the calling thread can predict the call's instance count from its recent calls with the same P and
+detector (the first call of a size runs the general chain and leaves the prediction behind).  Contract: num_rendered, radii,
+tiles_touched, point_list, ranges bit-identical to the oracle (= the reference's (tile | depth) order) and to the general chain;
+the image bit-identical to the general chain's (same lists, same work items, same summation order); every visible Gaussian owns
+a run of backward scratch rows, the runs a partition of [0, R); the backward unchanged.
+
+Cases: ordinary scenes incl. 4096 tiles; tile lists beyond one sort part (several workgroups per tile, split by depth range);
+thousands of equal depths in one tile (the rank-by-counting fallback); a prediction that falls short (second pass with exact
+sizes); a scene that turns out to hold thin Gaussians after the render was enqueued without that variant; nothing visible; two
+host threads.
+"""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from r2_gaussian_amd import scene as S
+from tests import helpers as Hh
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def L():
+    from r2_gaussian_amd import _lib
+    lib = _lib.lib()
+    lib.r2_tile_first_control(1)
+    lib.r2_tile_first_control(2)
+    yield lib
+    lib.r2_tile_first_control(1)
+    lib.r2_tile_first_control(2)
+
+
+def _both(L, c, v, gpu, **kw):
+    """-> (general chain's result, tile-first result) for the same call."""
+    L.r2_tile_first_control(0)
+    g = Hh.hip_raster(c, v, gpu, **kw)
+    assert not Hh.took_tile_first(g)
+    L.r2_tile_first_control(1)
+    L.r2_tile_first_control(2)
+    Hh.hip_raster(c, v, gpu, **kw)            # leaves the prediction
+    t = Hh.hip_raster(c, v, gpu, **kw)
+    assert Hh.took_tile_first(t), "the second call of a size did not take the tile-first chain"
+    return g, t
+
+
+def _same(g, t):
+    assert t["num_rendered"] == g["num_rendered"]
+    for k in ("radii", "tiles_touched", "point_list", "ranges", "depth_key", "color"):
+        assert np.array_equal(g[k], t[k]), k
+    vis = t["tiles_touched"] > 0
+    for k in ("cov3D", "rec"):                    # (rows of culled Gaussians are never written)
+        assert np.array_equal(g[k][vis], t[k][vis]), k
+    assert int(t["host_words"][7]) == int((t["tiles_touched"] > 0).sum())
+
+
+@pytest.mark.parametrize("P,det,seed,mult", [(7, (48, 48), 3, 1.0), (3000, (64, 100), 8, 1.0), (30000, (160, 144), 21, 1.0),
+                                             (120000, (512, 512), 5, 1.0), (60000, (512, 512), 6, 3.0), (400000, (1024, 1024), 2, 1.0)],
+                         ids=["tiny", "3k", "30k", "120k-512", "60k-big-gaussians", "400k-1024"])
+def test_identical_to_the_general_chain_and_the_oracle(P, det, seed, mult, L, oracle, gpu):
+    c = S.make_cloud(P, seed=seed, scale_mult=mult)
+    v = S.make_views(8, det)[3]
+    g, t = _both(L, c, v, gpu)
+    _same(g, t)
+    o = Hh.oracle_raster(oracle, c, v, render=False)
+    Hh.check_binning(t, o)
+    if det == (1024, 1024):
+        assert o["ranges"].shape[0] == 4096
+
+
+def test_long_lists_are_split_by_depth_range(L, oracle, gpu):
+    """Tile lists of > 4096 entries are sorted by several workgroups, each a range of the list's depth histogram."""
+    c = S.make_cloud(300000, seed=0)
+    v = S.make_views(50, (512, 512))[0]
+    g, t = _both(L, c, v, gpu)
+    _same(g, t)
+    lens = t["ranges"][:, 1].astype(np.int64) - t["ranges"][:, 0]
+    assert lens.max() > 2 * 4096, "the headline scene was meant to hold lists of three parts"
+    o = Hh.oracle_raster(oracle, c, v, render=False)
+    Hh.check_binning(t, o)
+    # ... and a list that needs many parts with a lopsided depth distribution: half of the cloud squeezed into a thin slab
+    xyz = c.xyz.clone()
+    xyz[::2, 0] = xyz[::2, 0] * 0.02 + 0.3
+    c2 = S.Cloud(xyz, c.scales * 2.0, c.rotations, c.density)
+    v0 = S.make_view(0.0, (256, 256))          # looks along -x: depth = 5 - x
+    g, t = _both(L, c2, v0, gpu)
+    _same(g, t)
+    assert (t["ranges"][:, 1].astype(np.int64) - t["ranges"][:, 0]).max() > 20000
+    Hh.check_binning(t, Hh.oracle_raster(oracle, c2, v0, render=False))
+
+
+def test_thousands_of_equal_depths_in_one_tile(L, oracle, gpu):
+    """All Gaussians at the same view depth: the depth histogram cannot split the lists, ids decide (the reference's tie rule);
+    parts too large for the LDS sort are ranked by counting."""
+    P = 20000
+    c = S.make_cloud(P, seed=11)
+    xyz = c.xyz.clone()
+    xyz[:, 0] = 0.25                             # view 0 looks along -x: one depth for all
+    xyz[:, 1:] *= 0.2                            # ... on a few tiles
+    c2 = S.Cloud(xyz, c.scales, c.rotations, c.density)
+    v = S.make_view(0.0, (128, 128))
+    g, t = _both(L, c2, v, gpu)
+    _same(g, t)
+    o = Hh.oracle_raster(oracle, c2, v, render=False)
+    assert len(np.unique(o["depths"][o["tiles_touched"] > 0])) == 1
+    assert (o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max() > 6144
+    Hh.check_binning(t, o)
+
+
+def test_a_prediction_that_falls_short_costs_a_second_pass_only(L, oracle, gpu):
+    P = 50000
+    small = S.make_cloud(P, seed=4, scale_mult=0.5)
+    big = S.make_cloud(P, seed=4, scale_mult=3.0)
+    v = S.make_views(8, (256, 256))[1]
+    Hh.hip_raster(small, v, gpu)                 # the prediction: a few instances per Gaussian
+    t = Hh.hip_raster(big, v, gpu)               # ... and then 30x as many
+    assert Hh.took_tile_first(t)
+    o = Hh.oracle_raster(oracle, big, v)
+    assert o["num_rendered"] > 4 * Hh.oracle_raster(oracle, small, v, render=False)["num_rendered"]
+    Hh.check_binning(t, o)
+    Hh.parity_image(oracle, o, t["color"], "tile-first after a short prediction")
+    dL = S.make_pixel_grad(256, 256).numpy()
+    gh = Hh.hip_raster_backward(t, big, v, dL, gpu)
+    Hh.parity_raster_grads(oracle, o, gh, big, v, dL, "tile-first after a short prediction")
+    # the other way round (far fewer instances than predicted) needs nothing special
+    t2 = Hh.hip_raster(small, v, gpu)
+    assert Hh.took_tile_first(t2)
+    Hh.check_binning(t2, Hh.oracle_raster(oracle, small, v, render=False))
+
+
+def test_thin_gaussians_discovered_after_the_render_was_enqueued(L, oracle, gpu):
+    """The render variant with the re-anchored row recurrence is chosen from the previous call's flag; a scene that needs it after
+    all is rendered again with it."""
+    P = 20000
+    plain = S.make_cloud(P, seed=9)
+    v = S.make_views(8, (192, 192))[5]
+    h0 = Hh.hip_raster(plain, v, gpu)
+    assert int(h0["host_words"][2]) == 0
+    sc = plain.scales.clone()
+    sc[:2000] *= 0.12                            # sub-pixel Gaussians: conditional sigma ~0.4 px
+    thin = S.Cloud(plain.xyz, sc, plain.rotations, plain.density)
+    t = Hh.hip_raster(thin, v, gpu)
+    assert Hh.took_tile_first(t) and int(t["host_words"][2]) == 1, "the scene was meant to raise the thin flag"
+    o = Hh.oracle_raster(oracle, thin, v)
+    Hh.check_binning(t, o)
+    Hh.parity_image(oracle, o, t["color"], "tile-first, thin Gaussians found late")
+    dL = S.make_pixel_grad(192, 192).numpy()
+    gh = Hh.hip_raster_backward(t, thin, v, dL, gpu)
+    # ... and image + every gradient are, bit for bit, what the general chain (which knows the flag before it renders) produces
+    L.r2_tile_first_control(0)
+    g = Hh.hip_raster(thin, v, gpu)
+    assert not Hh.took_tile_first(g) and np.array_equal(g["color"], t["color"])
+    gg = Hh.hip_raster_backward(g, thin, v, dL, gpu)
+    for k in gh:
+        assert np.array_equal(gh[k], gg[k]), k
+
+
+def test_forward_backward_parity_and_nothing_visible(L, oracle, gpu):
+    c = S.make_cloud(40000, seed=13)
+    v = S.make_views(8, (256, 200))[6]
+    Hh.hip_raster(c, v, gpu)
+    for rep in range(2):                          # the second one runs on the self-reset counters of the first
+        t = Hh.hip_raster(c, v, gpu)
+        assert Hh.took_tile_first(t)
+        o = Hh.oracle_raster(oracle, c, v)
+        Hh.check_binning(t, o)
+        Hh.parity_image(oracle, o, t["color"], "tile-first %d" % rep)
+        dL = S.make_pixel_grad(256, 200).numpy()
+        gh = Hh.hip_raster_backward(t, c, v, dL, gpu)
+        sg = Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "tile-first %d" % rep)
+        assert sg["after_flips"]["max_err_over_tol_after_flips"] <= 0.3
+    # every Gaussian behind the source: nothing visible, every pixel zero
+    xyz = c.xyz.clone()
+    xyz[:, 0] += 20.0
+    gone = S.Cloud(xyz, c.scales, c.rotations, c.density)
+    v0 = S.make_view(0.0, (256, 200))
+    Hh.hip_raster(gone, v0, gpu)
+    t = Hh.hip_raster(gone, v0, gpu)
+    assert t["num_rendered"] == 0 and not t["color"].any() and not t["radii"].any()
+    t = Hh.hip_raster(c, v0, gpu)                 # and the counters are clean afterwards
+    Hh.check_binning(t, Hh.oracle_raster(oracle, c, v0, render=False))
+
+
+def test_two_host_threads(L, oracle, gpu):
+    """Predictions and counters are per host thread (and stream): two threads in the forward at once."""
+    clouds = [S.make_cloud(25000, seed=31), S.make_cloud(26000, seed=32)]
+    v = S.make_views(8, (160, 160))[2]
+    refs = [Hh.oracle_raster(oracle, c, v, render=False) for c in clouds]
+    errs, took = [], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device=gpu)):
+                for _ in range(6):
+                    h = Hh.hip_raster(clouds[i], v, gpu)
+                    Hh.check_binning(h, refs[i])
+                took.append(Hh.took_tile_first(h))
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    assert took == [True, True]

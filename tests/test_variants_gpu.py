@@ -87,8 +87,15 @@ def _run_env(tmp_path, name, extra_env):
 
 
 def test_emission_paths_produce_identical_lists(tmp_path):
-    ref = _run_env(tmp_path, "gathers", {"R2_SORTED_RECORDS": "0"})
-    for name, env in (("sorted_records", {"R2_EMIT_HIST": "0"}), ("fused", {})):
+    off = {"R2_TILE_FIRST": "0"}   # the three emission kernels belong to the general chain
+    ref = _run_env(tmp_path, "gathers", dict(off, R2_SORTED_RECORDS="0"))
+    for name, env in (("sorted_records", dict(off, R2_EMIT_HIST="0")), ("fused", off)):
         got = _run_env(tmp_path, name, env)
         for k in ref.files:
             assert np.array_equal(ref[k], got[k]), (name, k)
+    # ... and the tile-first chain (round 4), which has no emission list at all: what the reference defines -- point_list,
+    # ranges, num_rendered -- and the image are bit-identical
+    got = _run_env(tmp_path, "tile_first", {})
+    for k in ref.files:
+        if k.split("_", 1)[1] in ("point_list", "ranges", "color", "R"):
+            assert np.array_equal(ref[k], got[k]), ("tile_first", k)
