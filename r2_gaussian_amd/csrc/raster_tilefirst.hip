@@ -39,19 +39,30 @@ namespace {
 constexpr int TFS_THREADS = TF_WG;      // scatter: the producer's mapping (raster_preprocess_tf_kernel)
 // ---- the sort kernel: 1024-thread workgroups of two kinds
 //   "big"    one tile list of > TFK_SMALL_CAP entries (or one depth range of a list beyond TFK_BIG_CAP) sorted by the whole workgroup;
-//   "quad"   four lists of <= TFK_SMALL_CAP entries, one per 256-thread quarter of the workgroup, in lockstep (same code, common
-//            barriers, own slice of the LDS).
-// (Measured on the way, 300k / 512^2: one workgroup per <= 4096-entry PART of a list, every part histogramming the whole list to
-//  find its depth range, spent 25 us -- the dense tiles hold most of the instances and were read 2-3 x S times; lists up to 12288
-//  entries now take ONE pass in one workgroup; 12288 entries / 116 KB of LDS = one workgroup per CU: 18 us, two rounds.)
+//   "group"  TFK_GROUPS lists of <= TFK_SMALL_CAP entries, one per 256-thread part of the workgroup, in lockstep (same code,
+//            common barriers, own slice of the LDS).
+// What was measured on the way (300k / 512^2, 1.16 M instances, list lengths 0 .. 8776, median 49; in-kernel stamps, -DR2_EXP_TS):
+//  * one workgroup per <= 4096-entry PART of a list, every part histogramming the whole list to find its depth range: 25 us --
+//    the dense tiles hold most of the instances and were read 2-3 x S times;
+//  * whole lists in one workgroup: 18 us with 1024 threads / <= 8192 entries (100 KB of LDS, one workgroup per CU), 22 us with
+//    512 threads / <= 4096 (three per CU, more lists in parts).  A workgroup's life is 7 us of dependent round trips -- counts
+//    -> descriptor -> entries, all written by the previous kernel on other XCDs, i.e. served from memory -- then 3.5 us of
+//    sorting; keeping the entries in registers, one entry per bucket (no rank reads), branch-free prefetch of every load and
+//    agent-scope stores in the scatter kernel (data past the L2s before the boundary: scatter + 9 us, loads unchanged) moved
+//    nothing: the kernel is those round trips times the number of rounds.
 constexpr int TFK_THREADS = 1024;
-constexpr uint32_t TFK_SMALL_CAP = 1536, TFK_SMALL_PER = 6, TFK_SMALL_BINS = 1024;     // per 256-thread quarter
-constexpr uint32_t TFK_BIG_CAP = 8192, TFK_BIG_PER = 8, TFK_BIG_BINS = 2048;           // whole workgroup (76 KB of LDS: two per CU)
+constexpr int TFK_GROUPS = TFK_THREADS / 256;
+// (the waves of a workgroup share ONE LDS pipe: entries stay in registers from the global load to the placement, buckets are as
+//  many as entries -- most hold one, whose rank needs no read at all)
+constexpr uint32_t TFK_SMALL_CAP = 1536, TFK_SMALL_PER = 6, TFK_SMALL_BINS = 1024;     // per 256-thread group
+constexpr uint32_t TFK_BIG_CAP = 8192, TFK_BIG_PER = 8, TFK_BIG_BINS = 2048;           // whole workgroup (78 KB of LDS, <= 64 VGPRs: two per CU)
 constexpr uint32_t TFK_BIG_TARGET = 5120;   // lists beyond TFK_BIG_CAP: ceil(n / 5120) parts, each a range of the list's depth histogram
 constexpr uint32_t TFK_COARSE = 1024;       // bins of that histogram (one per thread)
 constexpr size_t TFK_LDS = TFK_BIG_CAP * sizeof(unsigned long long) + (TFK_BIG_BINS + 1 + TFK_COARSE + 1) * sizeof(uint32_t);
-static_assert(4 * TFK_SMALL_CAP * sizeof(unsigned long long) + 4 * (TFK_SMALL_BINS + 1) * sizeof(uint32_t) <= TFK_LDS, "quads fit the big layout");
-static_assert(TFK_COARSE == TFK_THREADS && TFK_BIG_CAP >= TFK_BIG_TARGET + TFK_BIG_TARGET / 2, "parts need slack over their target size");
+static_assert(TFK_GROUPS * TFK_SMALL_CAP * sizeof(unsigned long long) + TFK_GROUPS * (TFK_SMALL_BINS + 1) * sizeof(uint32_t) <= TFK_LDS,
+              "the groups fit the big layout");
+static_assert(TFK_SMALL_CAP == TF_SMALL_CAP && TFK_COARSE == TFK_THREADS && TFK_BIG_CAP >= TFK_BIG_TARGET + TFK_BIG_TARGET / 2,
+              "parts need slack over their target size");
 
 // ---- 2. scatter.  Workgroup 0 does not scatter: it builds the tile ranges, the render kernel's work list and the sort kernel's
 // work lists from the tile counts while the others run (as block 0's epilogue this serial job was the kernel's tail)
@@ -105,8 +116,21 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
         return;
     }
     const uint32_t wg = blockIdx.x - 1u;
+    // this thread's Gaussian: requested now, used after the scan (everything here was written by the previous kernel on other
+    // XCDs, i.e. comes from memory: one round trip for all of it instead of one per dependent step)
+    const int idx = (int)wg * TFS_THREADS + tid;
+    const int idc = min(idx, P - 1);
+    const uint32_t g_tt = tiles_touched[idc], g_rect = rects[idc], g_key = depth_key[idc];
     // ---- exclusive scan of the tile counts (every workgroup for itself: <= 16 KB, cheaper than a launch boundary)
-    for (uint32_t t = tid; t < T; t += TFS_THREADS) s_pos[t] = tile_count[t];
+    const uint32_t *__restrict__ my_off = wgoff + (size_t)wg * T;
+    constexpr int MAXT = (int)(TF_MAX_TILES / TFS_THREADS);
+    uint32_t offs[MAXT];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        const uint32_t t = (uint32_t)(q * TFS_THREADS + tid);
+        offs[q] = my_off[min(t, T - 1u)];
+        s_pos[min(t, T - 1u)] = tile_count[min(t, T - 1u)];   // (clamped duplicates store the same value)
+    }
     __syncthreads();
     const uint32_t ipt = (T + TFS_THREADS - 1) / TFS_THREADS;
     const uint32_t t0 = (uint32_t)tid * ipt, t1 = min(t0 + ipt, T);
@@ -130,13 +154,15 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
     __syncthreads();
     // ... + where this workgroup's instances start inside each segment (rows of tiles it does not touch hold stale words:
     // they are added to slots nobody reads)
-    const uint32_t *__restrict__ my_off = wgoff + (size_t)wg * T;
-    for (uint32_t t = tid; t < T; t += TFS_THREADS) s_pos[t] += my_off[t];
+#pragma unroll
+    for (int q = 0; q < MAXT; ++q) {
+        const uint32_t t = (uint32_t)(q * TFS_THREADS + tid);
+        if (t < T) s_pos[t] += offs[q];
+    }
     __syncthreads();
     // ---- every instance of this workgroup's Gaussians
-    const int idx = (int)wg * TFS_THREADS + tid;
-    if (idx < P && tiles_touched[idx] != 0u) {
-        const uint32_t rect = rects[idx], key = depth_key[idx];
+    if (idx < P && g_tt != 0u) {
+        const uint32_t rect = g_rect, key = g_key;
         const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
         for (uint32_t r = 0; r < h; ++r) {
             const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
@@ -168,31 +194,32 @@ __device__ __forceinline__ void tf_group_minmax(uint32_t &kmin, uint32_t &kmax, 
     for (int w = 0; w < NT / 64; ++w) { kmin = min(kmin, s_mm[0][w0 + w]); kmax = max(kmax, s_mm[1][w0 + w]); }
 }
 
-// s_a[0, cnt) -> dst[rank by (key, id)] = id.  One-level bucket sort (see voxel_small.hip for the reasoning: a tile's depth keys
-// are float bit patterns in a narrow range, ~1.5 entries per value-linear bucket; position = bucket base + rank inside the bucket
-// by (key, id), exact whatever the distribution).  A group of NT threads (gtid = thread inside it, waves w0 ..); the barriers
-// are the WORKGROUP's: every group of the workgroup calls this together.
+// mine[u] (entry u * NT + gtid of the group's cnt entries, in registers; ~0 beyond cnt) -> dst[rank by (key, id)] = id.
+// One-level bucket sort (see voxel_small.hip for the reasoning: a tile's depth keys are float bit patterns in a narrow range, about
+// one entry per value-linear bucket; position = bucket base + rank inside the bucket by (key, id), exact whatever the
+// distribution).  A group of NT threads (gtid = thread inside it, waves w0 ..); s_a [>= cnt] receives the entries bucket by
+// bucket; the barriers are the WORKGROUP's: every group of the workgroup calls this together.
 template <int NT, uint32_t PER, uint32_t BINS>
-__device__ __forceinline__ void tf_sort_group(unsigned long long *s_a, uint32_t *s_bin, uint32_t *s_wsum /* workgroup's, per wave */,
-                                              int gtid, int lane, int wave, int w0, uint32_t cnt, uint32_t kmin, uint32_t kmax,
-                                              uint32_t *__restrict__ dst)
+__device__ __forceinline__ void tf_sort_group(unsigned long long (&mine)[PER], unsigned long long *s_a, uint32_t *s_bin,
+                                              uint32_t *s_wsum /* workgroup's, per wave */, int gtid, int lane, int wave, int w0,
+                                              uint32_t cnt, uint32_t kmin, uint32_t kmax, uint32_t *__restrict__ dst)
 {
+    R2_TS_AT(tilefirst, 6);
     for (uint32_t i = gtid; i <= BINS; i += NT) s_bin[i] = 0u;
     __syncthreads();
     const float scale = kmax > kmin ? (float)(BINS - 1) / (float)(kmax - kmin) : 0.f;
-    unsigned long long mine[PER];
     uint32_t my_bin[PER], my_ticket[PER];
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t i = u * NT + (uint32_t)gtid;
-        mine[u] = 0ull; my_bin[u] = 0u; my_ticket[u] = 0u;
+        my_bin[u] = 0u; my_ticket[u] = 0u;
         if (i < cnt) {
-            mine[u] = s_a[i];
             my_bin[u] = min((uint32_t)((float)((uint32_t)(mine[u] >> 32) - kmin) * scale), BINS - 1u);
             my_ticket[u] = atomicAdd(&s_bin[my_bin[u]], 1u);
         }
     }
     __syncthreads();
+    R2_TS_AT(tilefirst, 7);
     {
         constexpr uint32_t BPT = BINS / NT;
         static_assert(BINS % NT == 0, "whole buckets per thread");
@@ -214,30 +241,34 @@ __device__ __forceinline__ void tf_sort_group(unsigned long long *s_a, uint32_t 
         if (gtid == NT - 1) s_bin[BINS] = run;
     }
     __syncthreads();
+    R2_TS_AT(tilefirst, 8);
+    uint32_t b0[PER], b1[PER];
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t i = u * NT + (uint32_t)gtid;
-        if (i < cnt) s_a[s_bin[my_bin[u]] + my_ticket[u]] = mine[u];   // every thread holds its entries in registers by now
+        b0[u] = 0u; b1[u] = 0u;
+        if (i < cnt) {
+            b0[u] = s_bin[my_bin[u]];
+            b1[u] = s_bin[my_bin[u] + 1u];
+            if (b1[u] - b0[u] > 1u) s_a[b0[u] + my_ticket[u]] = mine[u];   // a bucket of one needs neither the store nor a rank
+        }
     }
     __syncthreads();
+    R2_TS_AT(tilefirst, 9);
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t i = u * NT + (uint32_t)gtid;
         if (i < cnt) {
-            const uint32_t b0 = s_bin[my_bin[u]], b1 = s_bin[my_bin[u] + 1u];
-            // the first four of the bucket with all reads in flight (most buckets hold fewer), the rest -- rare -- one by one
-            const unsigned long long e0 = s_a[b0], e1 = s_a[min(b0 + 1u, b1 - 1u)], e2 = s_a[min(b0 + 2u, b1 - 1u)],
-                                     e3 = s_a[min(b0 + 3u, b1 - 1u)];
-            uint32_t r = (e0 < mine[u] ? 1u : 0u) + ((b0 + 1u < b1 && e1 < mine[u]) ? 1u : 0u) +
-                         ((b0 + 2u < b1 && e2 < mine[u]) ? 1u : 0u) + ((b0 + 3u < b1 && e3 < mine[u]) ? 1u : 0u);
-            for (uint32_t q = b0 + 4u; q < b1; ++q) r += s_a[q] < mine[u] ? 1u : 0u;
-            dst[b0 + r] = (uint32_t)mine[u];
+            uint32_t r = 0;
+            if (b1[u] - b0[u] > 1u)
+                for (uint32_t q = b0[u]; q < b1[u]; ++q) r += s_a[q] < mine[u] ? 1u : 0u;
+            dst[b0[u] + r] = (uint32_t)mine[u];
         }
     }
 }
 
-__global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
-    const uint4 *__restrict__ big_parts, const uint4 *__restrict__ small_tiles, const uint32_t *__restrict__ nparts,
+__global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
+    const uint4 *__restrict__ big_parts, uint32_t big_cap, const uint4 *__restrict__ small_tiles, const uint32_t *__restrict__ nparts,
     const uint2 *__restrict__ pairs, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tile_count,
     const uint32_t *__restrict__ words)
 {
@@ -246,14 +277,17 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     R2_TS_AT(tilefirst, 3);
+    // the descriptor is requested together with the counts that say whether it exists (one round trip, not two): the big-part
+    // list has a slot for every workgroup below its capacity; the short list is indexed behind the big count, so it waits
+    const uint4 pd = big_parts[min(p, big_cap - 1u)];
     const uint32_t nbig = nparts[0], nsmall = nparts[1];
     if (p >= nbig) {
-        // ---- quad: four short lists, one per quarter of the workgroup
-        const uint32_t q0 = (p - nbig) * 4u;
+        // ---- group: TFK_GROUPS short lists, one per 256 threads of the workgroup
+        const uint32_t q0 = (p - nbig) * (uint32_t)TFK_GROUPS;
         if (q0 >= nsmall) return;
         const int g = tid >> 8, gtid = tid & 255, w0 = g * 4;
         unsigned long long *s_a = tfk_lds + (size_t)g * TFK_SMALL_CAP;
-        uint32_t *s_bin = reinterpret_cast<uint32_t *>(tfk_lds + 4 * TFK_SMALL_CAP) + (size_t)g * (TFK_SMALL_BINS + 1);
+        uint32_t *s_bin = reinterpret_cast<uint32_t *>(tfk_lds + TFK_GROUPS * TFK_SMALL_CAP) + (size_t)g * (TFK_SMALL_BINS + 1);
         uint32_t n = 0, start = 0;
         if (q0 + (uint32_t)g < nsmall) {
             const uint4 sd = small_tiles[q0 + g];
@@ -261,14 +295,24 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
             if (gtid == 0) tile_count[sd.x] = 0u;   // this call has read it for the last time: ready for the next one
         }
         uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
-        for (uint32_t i = gtid; i < n; i += 256u) {
-            const uint2 e = pairs[start + i];
-            s_a[i] = tf_pack(e);
-            kmin = min(kmin, e.x);
-            kmax = max(kmax, e.x);
+        unsigned long long mine[TFK_SMALL_PER];
+        {
+            // all loads in flight before the first use, BRANCH-FREE (clamped addresses): behind a per-lane branch hipcc drains the
+            // load queue at every use (s_waitcnt vmcnt(0)) -- six dependent round trips instead of one
+            uint2 e[TFK_SMALL_PER];
+            const uint32_t last = start + (n ? n - 1u : 0u);
+#pragma unroll
+            for (uint32_t u = 0; u < TFK_SMALL_PER; ++u) e[u] = pairs[min(start + u * 256u + (uint32_t)gtid, last)];
+#pragma unroll
+            for (uint32_t u = 0; u < TFK_SMALL_PER; ++u) {
+                const bool in = u * 256u + (uint32_t)gtid < n;
+                mine[u] = in ? tf_pack(e[u]) : ~0ull;
+                kmin = in ? min(kmin, e[u].x) : kmin;
+                kmax = in ? max(kmax, e[u].x) : kmax;
+            }
         }
         tf_group_minmax<256>(kmin, kmax, s_mm, lane, wave, w0);
-        tf_sort_group<256, TFK_SMALL_PER, TFK_SMALL_BINS>(s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, point_list + start);
+        tf_sort_group<256, TFK_SMALL_PER, TFK_SMALL_BINS>(mine, s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, point_list + start);
         R2_TS_AT(tilefirst, 4);
         return;
     }
@@ -276,19 +320,23 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
     unsigned long long *s_a = tfk_lds;                                             // [TFK_BIG_CAP]
     uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_a + TFK_BIG_CAP);             // [TFK_BIG_BINS + 1]
     uint32_t *s_coarse = s_bin + TFK_BIG_BINS + 1;                                 // [TFK_COARSE + 1]
-    const uint4 pd = big_parts[p];
     const uint32_t tile = pd.x, part = pd.y & 0xFFFFu, nparts_tile = pd.y >> 16, start = pd.z, n = pd.w;
     if (part == 0u && tid == 0) tile_count[tile] = 0u;
     const uint2 *__restrict__ src = pairs + start;
     uint32_t *__restrict__ dst = point_list + start;
     uint32_t cnt = n, out_off = 0u;
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+    unsigned long long mine[TFK_BIG_PER];
     if (nparts_tile == 1u) {
-        for (uint32_t i = tid; i < n; i += TFK_THREADS) {
-            const uint2 e = src[i];
-            s_a[i] = tf_pack(e);
-            kmin = min(kmin, e.x);
-            kmax = max(kmax, e.x);
+        uint2 e[TFK_BIG_PER];   // all loads in flight before the first use, branch-free (see the quad path)
+#pragma unroll
+        for (uint32_t u = 0; u < TFK_BIG_PER; ++u) e[u] = src[min(u * TFK_THREADS + (uint32_t)tid, n - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < TFK_BIG_PER; ++u) {
+            const bool in = u * TFK_THREADS + (uint32_t)tid < n;
+            mine[u] = in ? tf_pack(e[u]) : ~0ull;
+            kmin = in ? min(kmin, e[u].x) : kmin;
+            kmax = in ? max(kmax, e[u].x) : kmax;
         }
         tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);
     } else {
@@ -302,11 +350,17 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
         for (uint32_t i = tid; i <= TFK_COARSE; i += TFK_THREADS) s_coarse[i] = 0u;
         if (tid == 0) { s_cnt = 0u; s_off = 0xFFFFFFFFu; }
         __syncthreads();
-        for (uint32_t i = tid; i < n; i += TFK_THREADS) {
-            const uint32_t kk = src[i].x;
-            atomicAdd(&s_coarse[coarse_of(kk)], 1u);
-            kmin = min(kmin, kk);
-            kmax = max(kmax, kk);
+        for (uint32_t base = 0; base < n; base += 4u * TFK_THREADS) {   // four loads in flight, branch-free
+            uint32_t kk[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min(base + u * TFK_THREADS + (uint32_t)tid, n - 1u)].x;
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u)
+                if (base + u * TFK_THREADS + (uint32_t)tid < n) {
+                    atomicAdd(&s_coarse[coarse_of(kk[u])], 1u);
+                    kmin = min(kmin, kk[u]);
+                    kmax = max(kmax, kk[u]);
+                }
         }
         tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);   // (also orders the histogram's atomics before its readers)
         {
@@ -326,7 +380,14 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
                 lo = kmin;
                 cscale = kmax > kmin ? (float)(TFK_COARSE - 1) / (float)(kmax - kmin) : 0.f;
                 __syncthreads();
-                for (uint32_t i = tid; i < n; i += TFK_THREADS) atomicAdd(&s_coarse[coarse_of(src[i].x)], 1u);
+                for (uint32_t base = 0; base < n; base += 4u * TFK_THREADS) {
+                    uint32_t kk[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min(base + u * TFK_THREADS + (uint32_t)tid, n - 1u)].x;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u)
+                        if (base + u * TFK_THREADS + (uint32_t)tid < n) atomicAdd(&s_coarse[coarse_of(kk[u])], 1u);
+                }
             }
             __syncthreads();
         }
@@ -344,10 +405,10 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
         uint32_t excl = incl - c;
         for (int w = 0; w < wave; ++w) excl += s_wsum[w];
         const uint32_t owner = min((uint32_t)(((unsigned long long)excl * nparts_tile) / n), nparts_tile - 1u);
-        const bool mine = owner == part && c != 0u;
+        const bool my_bin_range = owner == part && c != 0u;
         __syncthreads();
-        s_coarse[tid] = mine ? 1u : 0u;   // from here on: "this bin is mine"
-        if (mine) {
+        s_coarse[tid] = my_bin_range ? 1u : 0u;   // from here on: "this bin is mine"
+        if (my_bin_range) {
             atomicAdd(&s_cnt, c);
             atomicMin(&s_off, excl);
         }
@@ -374,9 +435,14 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
         __syncthreads();
         if (tid == 0) s_cnt = 0u;
         __syncthreads();
-        for (uint32_t base = 0; base < n; base += TFK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
-            const uint32_t i = base + (uint32_t)tid;
-            const uint2 e = src[min(i, n - 1u)];
+        for (uint32_t base4 = 0; base4 < n; base4 += 4u * TFK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
+        uint2 e4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) e4[u] = src[min(base4 + u * TFK_THREADS + (uint32_t)tid, n - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = base4 + u * TFK_THREADS + (uint32_t)tid;
+            const uint2 e = e4[u];
             const bool take = i < n && s_coarse[coarse_of(e.x)] != 0u;
             const unsigned long long mm = __ballot(take);
             if (mm) {
@@ -391,9 +457,16 @@ __global__ void __launch_bounds__(TFK_THREADS) raster_tf_sort_kernel(
                 }
             }
         }
-        tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);
+        }
+        tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);   // (its barriers also order the appends before the reads)
+#pragma unroll
+        for (uint32_t u = 0; u < TFK_BIG_PER; ++u) {
+            const uint32_t i = u * TFK_THREADS + (uint32_t)tid;
+            mine[u] = i < cnt ? s_a[i] : ~0ull;
+        }
+        __syncthreads();   // everybody holds its entries: s_a may be overwritten by the placement
     }
-    tf_sort_group<TFK_THREADS, TFK_BIG_PER, TFK_BIG_BINS>(s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, dst + out_off);
+    tf_sort_group<TFK_THREADS, TFK_BIG_PER, TFK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, dst + out_off);
     R2_TS_AT(tilefirst, 4);
 }
 
@@ -515,8 +588,8 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
                 img.tf_parts + img.NP, ws->nparts); }
             R2_HIP_TRY(hipGetLastError());
             { StageScope t(ST_RAS_SORT, s);
-            raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (T + 3) / 4)), dim3(TFK_THREADS), TFK_LDS, s>>>(
-                img.tf_parts, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr->tile_count, geom.host_words); }
+            raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (T + TFK_GROUPS - 1) / TFK_GROUPS)), dim3(TFK_THREADS), TFK_LDS, s>>>(
+                img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr->tile_count, geom.host_words); }
             R2_HIP_TRY(hipGetLastError());
         } else {
             R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, T * sizeof(uint32_t), s));   // the first render left its arrivals behind
