@@ -340,32 +340,37 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
         }
         tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);
     } else {
-        // ---- this part's share of a very long list: a contiguous range of the bins of a depth histogram of the WHOLE list (bins
-        // laid over the key range of the call, which the preprocess left in the host words), chosen so that the parts are
-        // balanced whatever the distribution -- every part of the tile computes the same split
+        // ---- this part's share of a very long list: a contiguous range of the bins of a depth histogram of the list (bins laid
+        // over the key range of the call, which the preprocess left in the host words), chosen so that the parts are balanced
+        // whatever the distribution.  The histogram is built from every 8th entry -- every part of the tile takes the same
+        // sample, hence the same split; the split only balances the parts, membership and offsets below are exact.
+        constexpr uint32_t SAMPLE = 8;
+        const uint32_t ns = (n + SAMPLE - 1u) / SAMPLE;
         const uint32_t gmax = words[DW_NMAX];
         uint32_t lo = ~words[DW_NNMAX];
         float cscale = gmax > lo ? (float)(TFK_COARSE - 1) / (float)(gmax - lo) : 0.f;
         auto coarse_of = [&](uint32_t kk) { return min((uint32_t)((float)(max(kk, lo) - lo) * cscale), TFK_COARSE - 1u); };
+        auto sample_hist = [&](bool track) {
+            for (uint32_t base = 0; base < ns; base += 4u * TFK_THREADS) {   // four loads in flight, branch-free
+                uint32_t kk[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min((base + u * TFK_THREADS + (uint32_t)tid) * SAMPLE, n - 1u)].x;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u)
+                    if (base + u * TFK_THREADS + (uint32_t)tid < ns) {
+                        atomicAdd(&s_coarse[coarse_of(kk[u])], 1u);
+                        if (track) { kmin = min(kmin, kk[u]); kmax = max(kmax, kk[u]); }
+                    }
+            }
+        };
         for (uint32_t i = tid; i <= TFK_COARSE; i += TFK_THREADS) s_coarse[i] = 0u;
-        if (tid == 0) { s_cnt = 0u; s_off = 0xFFFFFFFFu; }
+        if (tid == 0) { s_cnt = 0u; s_off = 0u; }
         __syncthreads();
-        for (uint32_t base = 0; base < n; base += 4u * TFK_THREADS) {   // four loads in flight, branch-free
-            uint32_t kk[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min(base + u * TFK_THREADS + (uint32_t)tid, n - 1u)].x;
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u)
-                if (base + u * TFK_THREADS + (uint32_t)tid < n) {
-                    atomicAdd(&s_coarse[coarse_of(kk[u])], 1u);
-                    kmin = min(kmin, kk[u]);
-                    kmax = max(kmax, kk[u]);
-                }
-        }
+        sample_hist(true);
         tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);   // (also orders the histogram's atomics before its readers)
         {
             // a list whose depths crowd into a few of those bins (a thin slab seen face-on) cannot be split there: lay the bins
-            // over the list's own key range instead, at the price of a third pass
+            // over the sample's own key range instead (keys outside it clamp into the end bins)
             uint32_t mb = s_coarse[tid];
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) mb = max(mb, (uint32_t)__shfl_xor(mb, d));
@@ -374,25 +379,18 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < TFK_THREADS / 64; ++w) mb = max(mb, s_wsum[w]);
-            if (mb > TFK_BIG_CAP / 2u && (kmin > lo || kmax < gmax)) {   // workgroup-uniform
+            if (mb > TFK_BIG_CAP / (2u * SAMPLE) && (kmin > lo || kmax < gmax)) {   // workgroup-uniform
                 __syncthreads();
                 for (uint32_t i = tid; i <= TFK_COARSE; i += TFK_THREADS) s_coarse[i] = 0u;
                 lo = kmin;
                 cscale = kmax > kmin ? (float)(TFK_COARSE - 1) / (float)(kmax - kmin) : 0.f;
                 __syncthreads();
-                for (uint32_t base = 0; base < n; base += 4u * TFK_THREADS) {
-                    uint32_t kk[4];
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min(base + u * TFK_THREADS + (uint32_t)tid, n - 1u)].x;
-#pragma unroll
-                    for (uint32_t u = 0; u < 4u; ++u)
-                        if (base + u * TFK_THREADS + (uint32_t)tid < n) atomicAdd(&s_coarse[coarse_of(kk[u])], 1u);
-                }
+                sample_hist(false);
             }
             __syncthreads();
         }
         kmin = 0xFFFFFFFFu; kmax = 0u;   // reused below for this part's own range
-        // exclusive prefix over the bins (one per thread), part of a bin = floor(prefix * parts / n): monotone in the bin
+        // exclusive prefix over the bins (one per thread); owner of a bin = floor(prefix * parts / samples): monotone in the bin
         const uint32_t c = s_coarse[tid];
         uint32_t incl = c;
 #pragma unroll
@@ -404,59 +402,62 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
         __syncthreads();
         uint32_t excl = incl - c;
         for (int w = 0; w < wave; ++w) excl += s_wsum[w];
-        const uint32_t owner = min((uint32_t)(((unsigned long long)excl * nparts_tile) / n), nparts_tile - 1u);
-        const bool my_bin_range = owner == part && c != 0u;
+        const uint32_t owner = min((uint32_t)(((unsigned long long)excl * nparts_tile) / ns), nparts_tile - 1u);
         __syncthreads();
-        s_coarse[tid] = my_bin_range ? 1u : 0u;   // from here on: "this bin is mine"
-        if (my_bin_range) {
-            atomicAdd(&s_cnt, c);
-            atomicMin(&s_off, excl);
+        s_coarse[tid] = owner;   // from here on: the part that owns the bin
+        __syncthreads();
+        // ---- one pass over the whole list: entries of bins below mine are counted (my offset in the sorted list), mine appended
+        uint32_t below = 0;
+        bool overflow = false;
+        for (uint32_t base4 = 0; base4 < n; base4 += 4u * TFK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
+            uint2 e4[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) e4[u] = src[min(base4 + u * TFK_THREADS + (uint32_t)tid, n - 1u)];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) {
+                const uint32_t i = base4 + u * TFK_THREADS + (uint32_t)tid;
+                const uint2 e = e4[u];
+                const uint32_t own = i < n ? s_coarse[coarse_of(e.x)] : 0xFFFFFFFFu;
+                below += own < part ? 1u : 0u;
+                const bool take = own == part;
+                const unsigned long long mm = __ballot(take);
+                if (mm) {
+                    uint32_t wbase = 0;
+                    const int leader = __ffsll((long long)mm) - 1;
+                    if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(mm));
+                    wbase = __shfl(wbase, leader);
+                    const uint32_t slot = wbase + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                    if (take && slot < TFK_BIG_CAP) {
+                        s_a[slot] = tf_pack(e);
+                        kmin = min(kmin, e.x);
+                        kmax = max(kmax, e.x);
+                    }
+                }
+            }
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+        if (lane == 0) atomicAdd(&s_off, below);
         __syncthreads();
         cnt = s_cnt;
         out_off = s_off;
+        overflow = cnt > TFK_BIG_CAP;
         if (cnt == 0u) return;
-        if (cnt > TFK_BIG_CAP) {
-            // (more entries of one tile inside 1/1024 of its depth range than the LDS holds: equal depths.)  Rank by counting,
+        if (overflow) {
+            // (more entries of one tile inside a sliver of its depth range than the LDS holds: equal depths.)  Rank by counting,
             // straight from memory: O(cnt x n).  Exact like everything else.
             for (uint32_t i = tid; i < n; i += TFK_THREADS) {
                 const uint2 e = src[i];
-                if (s_coarse[coarse_of(e.x)] == 0u) continue;
+                if (s_coarse[coarse_of(e.x)] != part) continue;
                 const unsigned long long me = tf_pack(e);
                 uint32_t r = 0;
                 for (uint32_t j = 0; j < n; ++j) {
                     const uint2 o = src[j];
-                    if (s_coarse[coarse_of(o.x)] != 0u && tf_pack(o) < me) ++r;
+                    if (s_coarse[coarse_of(o.x)] == part && tf_pack(o) < me) ++r;
                 }
                 dst[out_off + r] = e.y;
             }
             return;
-        }
-        __syncthreads();
-        if (tid == 0) s_cnt = 0u;
-        __syncthreads();
-        for (uint32_t base4 = 0; base4 < n; base4 += 4u * TFK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
-        uint2 e4[4];
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) e4[u] = src[min(base4 + u * TFK_THREADS + (uint32_t)tid, n - 1u)];
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; ++u) {
-            const uint32_t i = base4 + u * TFK_THREADS + (uint32_t)tid;
-            const uint2 e = e4[u];
-            const bool take = i < n && s_coarse[coarse_of(e.x)] != 0u;
-            const unsigned long long mm = __ballot(take);
-            if (mm) {
-                uint32_t wbase = 0;
-                const int leader = __ffsll((long long)mm) - 1;
-                if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(mm));
-                wbase = __shfl(wbase, leader);
-                if (take) {
-                    s_a[wbase + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = tf_pack(e);
-                    kmin = min(kmin, e.x);
-                    kmax = max(kmax, e.x);
-                }
-            }
-        }
         }
         tf_group_minmax<TFK_THREADS>(kmin, kmax, s_mm, lane, wave, 0);   // (its barriers also order the appends before the reads)
 #pragma unroll
