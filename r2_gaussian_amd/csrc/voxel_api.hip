@@ -210,14 +210,19 @@ extern "C" int r2_voxel_backward(
         const VoxelImage img = VoxelImage::carve(img_buffer, T, (size_t)v.nx * v.ny * v.nz, (size_t)R, false);
         fill_tiles_from_ranges(img.ranges, T, bin.tiles, s);
     }
+    // patches (the TV regulariser): nearly every gradient row is a zero row, and the zero-fill rides along with the render backward
+    const bool zero_in_render = R > 0 && T <= VOX_SMALL_MAX_TILES;
+    const size_t Pz = (size_t)P;
+    const ZeroArrays za{{dL_dmean3D_norm, dL_dmean3D, dL_dconic3D, dL_dcov3D, dL_dopacity, dL_dscale, dL_drot},
+                        {3 * Pz, 3 * Pz, 6 * Pz, 6 * Pz, Pz, dL_dscale ? 3 * Pz : 0, dL_drot ? 4 * Pz : 0}};
     { StageScope t(ST_VOX_RENDER_BWD, s);
-    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, s); }
+    launch_voxel_render_backward(geom, bin, v, (size_t)R, dL_dvol, s, zero_in_render ? &za : nullptr); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_VOX_GEOM_BWD, s);
     launch_voxel_geom_backward(geom, v, P, radii_x, radii_y, radii_z, cov3D, cov3D_precomp ? nullptr : scales,
                                cov3D_precomp ? nullptr : rotations, scale_modifier, bin.part, dL_dconic3D,
-                               dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s); }
+                               dL_dmean3D_norm, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, s, zero_in_render); }
     R2_STAGE_CHECK(debug, s, "geometry backward");
     return 0;
 }

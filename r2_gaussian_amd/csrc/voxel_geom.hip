@@ -357,10 +357,8 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_zero_kernel(
 
 // Small grids (nearly everything is culled): ALL rows are zeroed with plain wide stores -- the compact kernel that follows
 // overwrites the visible ones (ordered by the kernel boundary).  The predicated 4-byte version above moves 31 MB at ~2 TB/s.
-struct ZeroArrays {
-    float *p[7];
-    size_t n[7];   // floats
-};
+// (Round 4: on a patch with instances the zero-fill rides along with the render backward instead -- extra workgroups of that
+// launch, voxel_render.hip -- so this kernel only serves patches nothing reaches.)
 __global__ void __launch_bounds__(256) voxel_zero_all_rows_kernel(ZeroArrays z)
 {
     const size_t t = (size_t)blockIdx.x * 256u + threadIdx.x, nt = (size_t)gridDim.x * 256u;
@@ -514,9 +512,11 @@ int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, co
                                float scale_modifier, const float *part, float *dL_dconic3D,
                                float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
-                               hipStream_t s)
+                               hipStream_t s, bool rows_already_zero)
 {
-    if ((size_t)v.gx * v.gy * v.gz <= VOX_SMALL_MAX_TILES) {   // a patch: nearly every row is a zero row
+    if (rows_already_zero) {
+        // the render backward's launch zeroed every row (patches, see launch_voxel_render_backward)
+    } else if ((size_t)v.gx * v.gy * v.gz <= VOX_SMALL_MAX_TILES) {   // a patch: nearly every row is a zero row
         const size_t Pz = (size_t)P;
         const ZeroArrays z{{dL_dmean3D_norm, dL_dmean3D, dL_dconic3D, dL_dcov3D, dL_dopacity, dL_dscale, dL_drot},
                            {3 * Pz, 3 * Pz, 6 * Pz, 6 * Pz, Pz, 3 * Pz, 4 * Pz}};

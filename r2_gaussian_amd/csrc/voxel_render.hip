@@ -496,8 +496,27 @@ __device__ __forceinline__ void slab_moments(const float4 p, const float4 q, con
 __global__ void __launch_bounds__(64) voxel_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list,
     const float4 *__restrict__ rec, const float4 *__restrict__ ext, const uint4 *__restrict__ cube, uint32_t R, VoxelGrid v,
-    uint32_t nchunks, uint32_t ipw, const float *__restrict__ dL_dvol, float4 *__restrict__ part)
+    uint32_t nchunks, uint32_t ipw, const float *__restrict__ dL_dvol, float4 *__restrict__ part, uint32_t work_grid,
+    ZeroArrays zero)
 {
+    if (blockIdx.x >= work_grid) {
+        // ---- zero-fill workgroups (patches only): slice (blockIdx - work_grid) of every gradient array, 16-byte stores
+        const size_t t = (size_t)(blockIdx.x - work_grid) * 64u + threadIdx.x, nt = (size_t)(gridDim.x - work_grid) * 64u;
+#pragma unroll
+        for (int a = 0; a < 7; ++a) {
+            float *__restrict__ p = zero.p[a];
+            if (p == nullptr) continue;
+            const size_t n = zero.n[a];
+            const size_t head = min(n, (size_t)((16u - ((uintptr_t)p & 15u)) & 15u) / 4u);   // floats before the first 16-byte boundary
+            float4 *__restrict__ p4 = reinterpret_cast<float4 *>(p + head);
+            const size_t n4 = (n - head) / 4;
+            for (size_t i = t; i < n4; i += nt) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < head) p[t] = 0.f;
+            const size_t tail0 = head + 4 * n4;
+            if (t < n - tail0) p[tail0 + t] = 0.f;
+        }
+        return;
+    }
     __shared__ float s_gt[VB_TILES * VB_GT];      // dL/dvol of the pass's tiles: [tile][x][y][z]
     __shared__ float4 s_p[64], s_q[64], s_r[64];  // the wave's 64 instance records
     __shared__ uint16_t s_queue[64 * TILE3D];     // items: (owner lane << 5) | (tile slot << 3) | slab
@@ -683,15 +702,21 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
 uint32_t voxel_short_list_min(bool debug) { return debug ? 0u : (uint32_t)VFWD_MIN_STEP; }
 
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
-                                 const float *dL_dvol, hipStream_t s)
+                                 const float *dL_dvol, hipStream_t s, const ZeroArrays *zero)
 {
-    if (R == 0) return 0;
+    if (R == 0) return 0;   // (the caller then zero-fills on its own)
     // instances per wave: 64, fewer when that would leave most SIMDs without a wave (the 32^3 TV patch has 45 k instances)
     const uint32_t ipw = R >= ((size_t)1 << 19) ? 64u : (R >= ((size_t)1 << 18) ? 32u : 16u);
     const uint32_t nchunks = (uint32_t)((R + ipw - 1) / ipw);
     const uint32_t grid = ((nchunks + 7u) >> 3) << 3;
-    voxel_render_backward_kernel<<<dim3(grid), dim3(64), 0, s>>>(b.tiles, b.point_list, g.rec, g.ext, g.cube, (uint32_t)R, v,
-                                                                 nchunks, ipw, dL_dvol, reinterpret_cast<float4 *>(b.part));
+    ZeroArrays z{};
+    uint32_t zgrid = 0;
+    if (zero) {
+        z = *zero;
+        zgrid = 8192;   // ~30 MB at 300k Gaussians: 3.7 KB per one-wave workgroup
+    }
+    voxel_render_backward_kernel<<<dim3(grid + zgrid), dim3(64), 0, s>>>(b.tiles, b.point_list, g.rec, g.ext, g.cube, (uint32_t)R, v,
+                                                                         nchunks, ipw, dL_dvol, reinterpret_cast<float4 *>(b.part), grid, z);
     return 0;
 }
 

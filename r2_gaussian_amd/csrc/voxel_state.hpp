@@ -167,11 +167,16 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
+// the seven gradient arrays of the voxelizer backward, for a kernel that zero-fills them
+struct ZeroArrays {
+    float *p[7];
+    size_t n[7];   // floats
+};
 int launch_voxel_geom_backward(const VoxelGeom &g, const VoxelGrid &v, int P, const int *radii_x, const int *radii_y,
                                const int *radii_z, const float *cov3D, const float *scales, const float *rotations,
                                float scale_modifier, const float *part, float *dL_dconic3D, float *dL_dmean3D_norm,
                                float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
-                               hipStream_t s);
+                               hipStream_t s, bool rows_already_zero = false);
 // tile lists shorter than this get no forward work item (a light kernel renders them); 0 in debug mode
 uint32_t voxel_short_list_min(bool debug);
 // Optional side job of the forward's last kernel (small-grid path): move the lists from where they were built into the binning /
@@ -188,8 +193,10 @@ struct VoxelPublish {
 int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const VoxelImage &im, const VoxelGrid &v,
                                 float *out_volume, bool write_ncontrib, hipStream_t s, bool no_short_kernel = false,
                                 const VoxelPublish *publish = nullptr);
+// zero (optional): gradient arrays to zero-fill with EXTRA workgroups of the same launch (patches: the render backward of a
+// 32^3 patch leaves most of the machine idle, and a zero-fill launch of its own was 10 of the TV step's 91 us)
 int launch_voxel_render_backward(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, size_t R,
-                                 const float *dL_dvol, hipStream_t s);
+                                 const float *dL_dvol, hipStream_t s, const ZeroArrays *zero = nullptr);
 
 
 }  // namespace r2
