@@ -259,3 +259,32 @@ def test_backward_after_a_hinted_overflow(oracle, gpu):
     finally:
         L.r2_depth_hint_control(1)
         L.r2_depth_hint_control(2)
+
+
+@pytest.mark.parametrize("n,s,ctr,P,mult", [((20, 13, 27), (0.5, 0.4, 0.6), (0.1, 0.0, -0.1), 8000, 1.0),
+                                            ((32, 32, 32), (0.25, 0.25, 0.25), (-0.2, 0.1, 0.0), 60000, 3.0),
+                                            ((8, 8, 8), (0.06, 0.06, 0.06), (0.0, 0.0, 0.0), 30000, 1.0)],
+                         ids=["ragged-20x13x27", "big-gaussians-32cube", "one-tile"])
+def test_patch_backward_ragged_big_and_single_tile(n, s, ctr, P, mult, oracle, gpu):
+    """Backward on patches (<= 64 tiles; since round 4 the gradient zero-fill rides along with the render backward's launch):
+    ragged grids (rows that are not whole float4s, tiles that stick out of the volume), Gaussians spanning the whole patch, a
+    single tile; twice, on recycled gradient buffers: every culled row zero, results bit-reproducible."""
+    c = S.make_cloud(P, seed=17, scale_mult=mult)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr)
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert h["num_rendered"] == o["num_rendered"] > 0
+    g = torch.Generator().manual_seed(5)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    first = None
+    for rep in range(2):
+        gh = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+        sg = Hh.parity_voxel_grads(oracle, o, gh, c, dL, "patch backward %s (%d)" % ("x".join(map(str, n)), rep))
+        for k in ("dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dscales", "dL_drotations"):
+            assert sg[k]["max_err_over_scale_unflagged"] <= 2e-4, (k, sg[k])
+        assert sg["after_flips"]["max_err_over_tol_after_flips"] <= 0.3, sg["after_flips"]
+        culled = o["tiles_touched"] == 0
+        for k in gh:
+            assert not gh[k].reshape(P, -1)[culled].any(), k      # every culled row is a zero row
+            if first is not None:
+                assert np.array_equal(gh[k], first[k]), k          # bit-reproducible
+        first = gh
