@@ -117,11 +117,13 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 {
     const uint32_t w = blockIdx.x;
     R2_TS_AT(render, 0);
+    // the descriptor is requested together with the count that says whether it exists (the list has a slot for every workgroup
+    // of the grid): one round trip instead of two at the head of every workgroup's chain of dependent loads
+    const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     if (w >= chunk_base[FUSED ? T + 1 : T]) return;
     // tile-first forward: the binning buffer was carved with a PREDICTED instance count; the backward will carve it with the true
     // one, so the per-instance tile ids go where that carve puts them (raster_state.hpp)
     if (FUSED && tf_bin_base != nullptr) tiles = binning_tiles_ptr(tf_bin_base, (size_t)tf_words[DW_TOTAL]);
-    const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
     int tx, ty, tv;   // tile column / row inside its view, view (batched views stack their tile grids)
     tile_decode<MV>(tile, gx, gy, tx, ty, tv);

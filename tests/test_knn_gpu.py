@@ -37,3 +37,59 @@ def test_create_from_pcd_usage(oracle, gpu):
     xyz = S.make_cloud(5000, seed=9).xyz.to(gpu)
     dist = torch.sqrt(torch.clamp_min(distCUDA2(xyz), 0.001 ** 2))
     assert dist.shape == (5000,) and torch.isfinite(dist).all() and (dist > 0).all()
+
+
+def _grid_vs_exhaustive(pts, gpu, tmp_env=None):
+    """distCUDA2 through the grid search (P >= 4096) vs the exhaustive kernel of the same library (a sub-4096 call cannot be
+    forced, so the exhaustive result comes from a subprocess with R2_KNN_GRID=0)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    from r2_gaussian_amd import distCUDA2
+    got = distCUDA2(pts.to(gpu)).cpu().numpy()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "p.npy"), pts.numpy())
+        code = ("import sys, numpy as np, torch; sys.path.insert(0, %r); from r2_gaussian_amd import distCUDA2; "
+                "p = torch.from_numpy(np.load(%r)).cuda(); np.save(%r, distCUDA2(p).cpu().numpy())"
+                % (root, os.path.join(d, "p.npy"), os.path.join(d, "o.npy")))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, R2_KNN_GRID="0"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ref = np.load(os.path.join(d, "o.npy"))
+    return got, ref
+
+
+@pytest.mark.parametrize("kind", ["cloud-50k", "cloud-300k", "lattice", "clustered", "flat", "collinear", "duplicates", "identical"])
+def test_knn_grid_search_is_bit_identical_to_the_exhaustive_one(kind, oracle, gpu):
+    """Round 4: P >= 4096 points take a uniform-grid search (csrc/knn.hip) -- the same 3-best multiset, hence the same bits, as the
+    exhaustive kernel (and as the oracle's brute force where that is affordable): a cloud, the voxel lattice initialize_pcd.py
+    samples from (many exactly equal distances), heavy clustering (long cells, many rings for the outliers), a plane, a line,
+    exact duplicates, all points identical (no grid possible: the exhaustive kernel serves it)."""
+    g = torch.Generator().manual_seed(3)
+    if kind == "cloud-50k":
+        pts = S.make_cloud(50000, seed=4).xyz
+    elif kind == "cloud-300k":
+        pts = S.make_cloud(300000, seed=5).xyz
+    elif kind == "lattice":
+        idx = torch.randperm(64 ** 3, generator=g)[:40000]
+        pts = torch.stack([idx // 4096, (idx // 64) % 64, idx % 64], 1).float() * (2.0 / 64) - 1.0
+    elif kind == "clustered":
+        pts = torch.cat([torch.randn(30000, 3, generator=g) * 0.003 + 0.4, torch.rand(2000, 3, generator=g) * 2 - 1,
+                         torch.randn(8000, 3, generator=g) * 0.01 - 0.5])
+    elif kind == "flat":
+        pts = torch.rand(20000, 3, generator=g) * 2 - 1
+        pts[:, 2] = 0.25
+    elif kind == "collinear":
+        pts = torch.zeros(10000, 3)
+        pts[:, 0] = torch.rand(10000, generator=g)
+    elif kind == "duplicates":
+        base = S.make_cloud(3000, seed=6).xyz
+        pts = base.repeat(3, 1)
+    else:
+        pts = torch.full((5000, 3), 0.125)
+    pts = pts.contiguous()
+    got, ref = _grid_vs_exhaustive(pts, gpu)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), kind
+    if pts.shape[0] <= 50000:
+        assert np.array_equal(got.view(np.uint32), oracle.knn_dist2(pts.numpy()).view(np.uint32)), kind
