@@ -54,8 +54,10 @@ STAGE_KERNEL = {
     "raster.render_bwd": "r2::raster_render_backward_kernel<false>",
     "raster.render_fwd": "r2::raster_render_forward_kernel<false, true, false>",
     "raster.geom_bwd": "r2::raster_geom_backward_kernel<false>",
-    "raster.preprocess": "r2::raster_preprocess_kernel",
-    "raster.duplicate": "r2::raster_emit_hist_kernel",
+    # (tile-first binning chain, round 4; the general chain's kernels are r2::raster_preprocess_kernel / raster_emit_hist_kernel)
+    "raster.preprocess": "r2::raster_preprocess_tf_kernel",
+    "raster.duplicate": "r2::raster_tf_scatter_kernel",
+    "raster.sort": "r2::raster_tf_sort_kernel",
 }
 
 

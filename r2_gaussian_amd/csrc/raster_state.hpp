@@ -75,6 +75,12 @@ __device__ __forceinline__ bool block_live(float px, float py, float hx, float h
 // of the (entry, block) pairs -- was built and measured in round 2: parity green, forward 47.5 -> 50.9 us (the test costs more
 // than the dropped entries save), backward unchanged (its rounds are quantised: 118 or 104 items per chunk are both 2 rounds).)
 
+#ifndef R2_EXP_TF_WG
+#define R2_EXP_TF_WG 1024
+#endif
+constexpr int TF_WG = R2_EXP_TF_WG;                 // tile-first: Gaussians per producer workgroup (preprocess and scatter share the mapping);
+                                            // large, so that few workgroups bump the same tile counter (same-address atomics
+                                            // retire at ~90 per microsecond device-wide) and the scatter's per-workgroup scan amortises
 struct RasterGeom {
     float4 *rec;              // [2P]  {px, py, A2, B2} {C2, L, hx, hy}: A2,B2,C2 = conic * (-log2e/2, -log2e, -log2e/2),
                               //       L = log2(opacity*mu), (hx, hy) = half-extents of the alpha >= 1e-5 bounding box
@@ -124,8 +130,8 @@ struct RasterGeom {
         g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order (kept apart: the control block at
         g.psort_temp = b.take<char>(g.psort_bytes);   // the start of dorder_temp must survive until the backward)
         g.tf_rect = b.take<uint32_t>(tf_T ? (size_t)P : 0);
-        g.tf_wgoff = b.take<uint32_t>(tf_T ? ((size_t)P + 1023) / 1024 * tf_T : 0);
-        g.tf_wgmm = b.take<uint32_t>(tf_T ? ((size_t)P + 1023) / 1024 * 2 : 0);
+        g.tf_wgoff = b.take<uint32_t>(tf_T ? ((size_t)P + TF_WG - 1) / TF_WG * tf_T : 0);
+        g.tf_wgmm = b.take<uint32_t>(tf_T ? ((size_t)P + TF_WG - 1) / TF_WG * 2 : 0);
         g.bytes = b.total();
         return g;
     }
@@ -173,9 +179,6 @@ __host__ __device__ __forceinline__ uint32_t *binning_tiles_ptr(char *base, size
 }
 
 constexpr uint32_t TF_SMALL_CAP = 1536;     // tile-first: tile lists beyond this many entries get a whole sort workgroup (raster_tilefirst.hip)
-constexpr int TF_WG = 1024;                 // tile-first: Gaussians per producer workgroup (preprocess and scatter share the mapping);
-                                            // large, so that few workgroups bump the same tile counter (same-address atomics
-                                            // retire at ~90 per microsecond device-wide) and the scatter's per-workgroup scan amortises
 constexpr uint32_t TF_MAX_TILES = 4096;     // tile-first: per-workgroup LDS histogram over the tiles
 constexpr int TF_NOT_TAKEN = -1000001;      // raster_forward_tilefirst: nothing launched, run the general chain
 constexpr uint32_t TF_MARK = 0x71FEu;       // host word DW_PMAX of a forward that took the tile-first path (introspection)

@@ -1,0 +1,66 @@
+"""profiles/<tag>_* from what scripts/gpu_profile3.sh left under gpurun_out/ (round 3: rocprofv3 passes over
+`bench.py --headline-only`, so every kernel row is the single-view forward + backward step):
+    python scripts/make_profile_summary3.py r03 "title"
+"""
+import csv, json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+title = sys.argv[2] if len(sys.argv) > 2 else tag
+P = os.path.join(ROOT, "profiles")
+G = os.path.join(ROOT, "gpurun_out")
+
+
+def cp(src, dst):
+    if os.path.exists(src):
+        shutil.copy(src, dst)
+        return True
+    return False
+
+
+cp(os.path.join(G, "prof/%s/%s_kernel_stats.csv" % (tag, tag)), os.path.join(P, "%s_kernel_stats.csv" % tag))
+cp(os.path.join(G, "prof/%s_vox_kernel_stats.csv" % tag), os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag))
+cp(os.path.join(G, "pmc/%s_pmc_per_launch.json" % tag), os.path.join(P, "%s_pmc.json" % tag))
+cp(os.path.join(G, "pmc/%s_pmc_per_launch.json" % tag), os.path.join(P, "pmc_latest.json"))
+for suffix in ("", "_driver", "_B", "_C", "_E"):
+    cp(os.path.join(G, "bench_%s%s.json" % (tag, suffix)), os.path.join(P, "%s_bench%s.json" % (tag, suffix)))
+cp(os.path.join(G, "cbench_%s.txt" % tag), os.path.join(P, "%s_cbench.txt" % tag))
+for f in ("train_synthetic_fused.json",):
+    cp(os.path.join(G, f), os.path.join(P, "%s_%s" % (tag, f)))
+
+
+def short(n):
+    m = re.search(r'(r2::(?:\(anonymous namespace\)::)?[a-zA-Z_0-9]+(?:<[^>(]*>)?)', n)
+    return m.group(1).replace('(anonymous namespace)::', '') if m else n.split('(')[0][:70]
+
+
+rows = list(csv.DictReader(open(os.path.join(P, "%s_kernel_stats.csv" % tag))))
+pmc = json.load(open(os.path.join(P, "%s_pmc.json" % tag)))
+with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
+    f.write("# %s\n\n" % title)
+    f.write("`rocprofv3 --kernel-trace --stats -- python bench.py --headline-only --steps 30 --warmup 5 --repeats 3` on MI355X: the "
+            "single-view forward + backward step and nothing else (no batched / concurrent / voxelizer / CPU-baseline sections), so "
+            "every row below IS the headline step (full CSV: %s_kernel_stats.csv).  PMC columns: separate rocprofv3 passes over the "
+            "same command, one TCC counter per pass (FETCH_SIZE, WRITE_SIZE; SQ_* in a third), averaged per launch (%s_pmc.json = "
+            "pmc_latest.json, which bench.py reads for `roofline.traffic` when its source hash matches); KB in the json, MB here.  "
+            "Bench lines of the same build: %s_bench.json (default run), %s_bench_driver.json (--steps 20 --warmup 5), "
+            "%s_bench_{B,C,E}.json (BASELINE configs B 50k/512^2, C 300k/560^2, E 1M/1024^2/360 views).\n\n" % (tag, tag, tag, tag, tag))
+    f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) |\n|---|---|---|---|---|---|---|\n")
+    for r in rows[:30]:
+        k = short(r['Name']); p = pmc.get(k, {})
+        f.write("| `%s` | %s | %.1f | %s | %s | %s | %s |\n" % (
+            k, r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'],
+            ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
+            ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
+            ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else ""))
+    f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
+            "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  Kernels named "
+            "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
+            "Gaussians, and every 64th call, which refreshes the depth-range hint); `__amd_rocclr_*` are the runtime's fill / copy "
+            "kernels (torch tensor initialisation).  Counters of the single-view step with derived utilisations: "
+            "r03a_single_view_summary.txt (same kernels except the tile sort, collected through the C harness).\n")
+    v = os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag)
+    if os.path.exists(v):
+        f.write("\n## Voxelizer alone: 256^3 query of the same cloud (`scripts/voxel_query_only.py 12`)\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
+        for r in list(csv.DictReader(open(v)))[:16]:
+            f.write("| `%s` | %s | %.1f | %s |\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+print(open(os.path.join(P, "%s_summary.md" % tag)).read()[:2500])
