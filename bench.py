@@ -543,7 +543,7 @@ def main():
     import ctypes as _ct
     import numpy as _np
     Lc = _lib.lib()
-    lens, n_over, n_thin, n_hinted = [], 0, 0, 0
+    lens, n_over, n_thin, n_hinted, n_tf = [], 0, 0, 0, 0
     with torch.no_grad():
         for vi in range(0, len(views), max(1, len(views) // 10)):
             s = settings[vi]
@@ -555,7 +555,8 @@ def main():
             hwd = r_[3 + bid.value][off:off + 32].cpu().numpy().view(_np.uint32)
             n_over += int(hwd[1] != 0)
             n_thin += int(hwd[2] != 0)
-            n_hinted += int(hwd[7] != 0)
+            n_tf += int(hwd[3] == 0x71FE)                      # the tile-first binning chain ran (csrc/raster_tilefirst.hip)
+            n_hinted += int(hwd[7] != 0 and hwd[3] != 0x71FE)  # the general chain with a hinted depth order
             off = Lc.r2_raster_state_offset(6, P, r_[0], HW, HW, _ct.byref(bid))
             rg_ = r_[3 + bid.value][off:off + 8 * T].cpu().numpy().view(_np.uint32).reshape(T, 2).astype(_np.int64)
             lens.append(rg_[:, 1] - rg_[:, 0])
@@ -563,7 +564,7 @@ def main():
     cloud_stats = {"views_sampled": len(Rl), "instances_per_gaussian": round(R / max(P, 1), 2),
                    "tile_list_len": {"p50": float(_np.percentile(lens, 50)), "p90": float(_np.percentile(lens, 90)),
                                      "p99": float(_np.percentile(lens, 99)), "max": int(lens.max())},
-                   "depth_hint_used": n_hinted, "depth_hint_overflow": n_over, "thin_variant_ANY4": n_thin}
+                   "tile_first_chain": n_tf, "depth_hint_used": n_hinted, "depth_hint_overflow": n_over, "thin_variant_ANY4": n_thin}
     if cloud_info:
         cloud_stats.update(cloud_info)
     kernels = {}

@@ -1,6 +1,7 @@
-"""profiles/<tag>_* from what scripts/gpu_profile3.sh left under gpurun_out/ (round 3: rocprofv3 passes over
-`bench.py --headline-only`, so every kernel row is the single-view forward + backward step):
-    python scripts/make_profile_summary3.py r03 "title"
+"""profiles/<tag>_* from what scripts/gpu_profile4.sh left under gpurun_out/ (round 4: rocprofv3 passes over
+`bench.py --headline-only`, so every kernel row is the single-view forward + backward step, + the same for the 256^3 voxel
+query alone, + the bench lines of the trained clouds and of the one-rank collective path):
+    python scripts/make_profile_summary4.py r04e "title"
 """
 import csv, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,7 +22,11 @@ cp(os.path.join(G, "prof/%s/%s_kernel_stats.csv" % (tag, tag)), os.path.join(P, 
 cp(os.path.join(G, "prof/%s_vox_kernel_stats.csv" % tag), os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag))
 cp(os.path.join(G, "pmc/%s_pmc_per_launch.json" % tag), os.path.join(P, "%s_pmc.json" % tag))
 cp(os.path.join(G, "pmc/%s_pmc_per_launch.json" % tag), os.path.join(P, "pmc_latest.json"))
-for suffix in ("", "_driver", "_B", "_C", "_E"):
+cp(os.path.join(G, "pmc/%s_vox_pmc_per_launch.json" % tag), os.path.join(P, "%s_voxel256_pmc.json" % tag))
+for suffix in ("_tf0", "_tf1"):
+    cp(os.path.join(G, "cbench_%s%s.txt" % (tag, suffix)), os.path.join(P, "%s_cbench%s.txt" % (tag, suffix)))
+cp(os.path.join(G, "timeline_%s.txt" % tag), os.path.join(P, "%s_timeline_stamps.txt" % tag))
+for suffix in ("", "_driver", "_B", "_C", "_E", "_trained_small", "_trained_large", "_forcecomm"):
     cp(os.path.join(G, "bench_%s%s.json" % (tag, suffix)), os.path.join(P, "%s_bench%s.json" % (tag, suffix)))
 cp(os.path.join(G, "cbench_%s.txt" % tag), os.path.join(P, "%s_cbench.txt" % tag))
 for f in ("train_synthetic_fused.json",):
@@ -57,10 +62,31 @@ with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
             "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
             "Gaussians, and every 64th call, which refreshes the depth-range hint); `__amd_rocclr_*` are the runtime's fill / copy "
             "kernels (torch tensor initialisation).  Counters of the single-view step with derived utilisations: "
-            "r03a_single_view_summary.txt (same kernels except the tile sort, collected through the C harness).\n")
+            "r03a_single_view_summary.txt (round 3's kernels; the render / geometry-backward kernels are unchanged since).\n")
     v = os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag)
     if os.path.exists(v):
         f.write("\n## Voxelizer alone: 256^3 query of the same cloud (`scripts/voxel_query_only.py 12`)\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
         for r in list(csv.DictReader(open(v)))[:16]:
             f.write("| `%s` | %s | %.1f | %s |\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
 print(open(os.path.join(P, "%s_summary.md" % tag)).read()[:2500])
+
+
+# ---- the 256^3 voxel query alone (counters of the final voxel kernels)
+vs = os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag)
+vp = os.path.join(P, "%s_voxel256_pmc.json" % tag)
+if os.path.exists(vs):
+    vrows = list(csv.DictReader(open(vs)))
+    vpmc = json.load(open(vp)) if os.path.exists(vp) else {}
+    with open(os.path.join(P, "%s_voxel256_summary.md" % tag), "w") as f:
+        f.write("# Voxelizer, 256^3 query of the 300k-Gaussian benchmark cloud alone (%s)\n\n" % tag)
+        f.write("`rocprofv3 --kernel-trace --stats -- python scripts/voxel_query_only.py 12` (12 calls; the first takes the un-hinted depth "
+                "order) and separate `--pmc` passes over the same command (FETCH_SIZE, WRITE_SIZE, SQ_*), averaged per launch.\n\n")
+        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) | waves |\n|---|---|---|---|---|---|---|---|\n")
+        for r in vrows[:24]:
+            k = short(r['Name']); p = vpmc.get(k, {})
+            f.write("| `%s` | %s | %.1f | %s | %s | %s | %s | %s |\n" % (
+                k, r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'],
+                ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
+                ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
+                ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else "",
+                ("%d" % p['SQ_WAVES']) if 'SQ_WAVES' in p else ""))
