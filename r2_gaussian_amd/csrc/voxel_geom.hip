@@ -114,25 +114,34 @@ __device__ __forceinline__ void voxel_preprocess_one(
     // bounding box of {alpha >= 1e-6} (VOX/forward.cu:293): q = d^T C d <= 2 ln2 (L - log2(1e-6)), half-widths
     // sqrt(qmax * (C^-1)_kk), from the float inverse covariance the kernels evaluate, in double, padded; +inf (never
     // cull) unless C is safely positive definite, -inf (never live) when the opacity is below the cut-off.
-    float hx = INFINITY, hy = INFINITY, hz = INFINITY;
+    // Round 4: instead of the y / z half-widths of the whole box the record keeps the CROSS-SECTION of the cut-off ellipsoid
+    // at a given x offset dx (what an x-slab of voxels sees): an ellipse centred at (y, z) = p_yz - (ky, kz) * dx whose own
+    // bounding box has the half-widths (hyc, hzc) * sqrt(1 - (dx / hx)^2), hyc^2 = qmax * F / m00, hzc^2 = qmax * D / m00,
+    // (ky, kz) = -[[D, E], [E, F]]^-1 (B, C).  The slab test built on it (slab_live, voxel_render.hip) drops the slabs in the
+    // corners between the box and the ellipsoid: 21 % of the (instance, slab) pairs of a 256^3 query
+    // (scripts/voxel_pair_fractions.py: slab_cond).
+    float hx = INFINITY, hyc = INFINITY, hzc = INFINITY, ky = 0.f, kz = 0.f;
     {
         const double qmax = 2.0 * (double)LN2 * ((double)L - (double)LOG2_ALPHA_MIN_3D) + 1e-3;
         const double A = inv_a, B = inv_b, C = inv_c, D = inv_d, E = inv_e, F = inv_f;
         const double m00 = D * F - E * E, m11 = A * F - C * C, m22 = A * D - B * B;
         const double det3 = A * m00 - B * (B * F - C * E) + C * (B * E - C * D);
         if (!(qmax > 0.0)) {
-            hx = hy = hz = -INFINITY;
-        } else if (A > 0.0 && m22 > 0.0 && det3 > 0.0 && m00 > 0.0 && m11 > 0.0 &&
+            hx = hyc = hzc = -INFINITY;
+        } else if (A > 0.0 && m22 > 0.0 && det3 > 0.0 && m00 > 0.0 && m11 > 0.0 && D > 0.0 && F > 0.0 &&
                    (A + D + F) * (m00 + m11 + m22) <= 1.0e4 * det3) {
-            const double ex = sqrt(qmax * m00 / det3) * 1.004 + 0.05, ey = sqrt(qmax * m11 / det3) * 1.004 + 0.05,
-                         ez = sqrt(qmax * m22 / det3) * 1.004 + 0.05;
-            if (ex < 1.0e30 && ey < 1.0e30 && ez < 1.0e30) { hx = (float)ex; hy = (float)ey; hz = (float)ez; }
+            const double ex = sqrt(qmax * m00 / det3) * 1.004 + 0.05, ey = sqrt(qmax * F / m00) * 1.004 + 0.05,
+                         ez = sqrt(qmax * D / m00) * 1.004 + 0.05;
+            const double sy = -(F * B - E * C) / m00, sz = -(D * C - E * B) / m00;
+            if (ex < 1.0e30 && ey < 1.0e30 && ez < 1.0e30 && fabs(sy) < 1.0e6 && fabs(sz) < 1.0e6) {
+                hx = (float)ex; hyc = (float)ey; hzc = (float)ez; ky = (float)sy; kz = (float)sz;
+            }
         }
     }
     rec[3 * idx] = make_float4(pv.x, pv.y, pv.z, op);
     rec[3 * idx + 1] = make_float4((-0.5f * LOG2E) * inv_a, (-LOG2E) * inv_b, (-LOG2E) * inv_c, (-0.5f * LOG2E) * inv_d);
-    rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, L, 0.f);
-    ext[idx] = make_float4(hx, hy, hz, 0.f);
+    rec[3 * idx + 2] = make_float4((-LOG2E) * inv_e, (-0.5f * LOG2E) * inv_f, L, kz);
+    ext[idx] = make_float4(hx, hyc, hzc, ky);
 }
 
 __global__ void __launch_bounds__(256) voxel_preprocess_kernel(

@@ -27,18 +27,44 @@ namespace r2 {
 // Gaussian is walked with the recurrence G(c+1) = G(c) r(c), r(c+1) = r(c) exp2(2 F2), re-anchored every 4 voxels (two
 // v_exp_f32 per 4 voxels instead of four); a 64x64 transpose-reduction leaves voxel (y, z) of the slab in lane y*8+z.
 constexpr int VFWD_BATCH = 256;   // list entries staged per round: one per thread of the workgroup
-constexpr int VFWD_MIN_STEP = 25;  // fewer live entries than this are cheaper voxel-parallel (20 vs ~500/64 instr per entry)
+constexpr int VFWD_MIN_STEP = 25;  // tile lists shorter than this go to the one-wave-per-tile kernel (voxel-parallel)
+// Within a work item, a wave's remainder of fewer live entries than VFWD_STEP_MIN is evaluated voxel-parallel instead of as a
+// (partly filled) lane-per-entry step.  Round 4: the remainder loop is a chain of dependent LDS reads that costs about as much
+// as 80 instructions per entry (fitted from SQ_INSTS_VALU and time of two builds), a step ~420 whatever its fill: break-even
+// at 5-6 entries, not at the 25 this used until round 4 (scripts: /profiles r04f_voxel_steps.txt).
+#ifndef R2_VFWD_STEP_MIN
+#define R2_VFWD_STEP_MIN 6
+#endif
+constexpr int VFWD_STEP_MIN = R2_VFWD_STEP_MIN;
 
-__device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h, float xc, float y0, float z0)
+__device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h, float kz, float xc, float y0, float z0)
 {
-    // slab = voxel centres x = xc, y in [y0+0.5, y0+7.5], z in [z0+0.5, z0+7.5]
-    return (fabsf(px - xc) <= h.x) && (py - h.y <= y0 + 7.5f) && (py + h.y >= y0 + 0.5f) && (pz - h.z <= z0 + 7.5f) &&
-           (pz + h.z >= z0 + 0.5f);
+    // slab = voxel centres x = xc, y in [y0+0.5, y0+7.5], z in [z0+0.5, z0+7.5]; h = {hx, hyc, hzc, ky} (VoxelGeom::ext).
+    // At the offset dx the cut-off ellipsoid's cross-section is an ellipse around (py - ky dx, pz - kz dx) inside the box
+    // +-(hyc, hzc) * sqrt(1 - (dx/hx)^2): the slab is live if that box touches its 8x8 voxel centres.  Conservative: hx, hyc,
+    // hzc are padded (0.4 % + 0.05 voxel), so the root is >= 0.09 wherever the true ellipsoid reaches.  hx = +inf (no
+    // culling): dx/hx = 0, hyc = hzc = +inf; hx = -inf (nothing passes): the first comparison fails.
+    const float dx = px - xc;
+    const float u = dx * __builtin_amdgcn_rcpf(h.x);
+    const float t = __builtin_amdgcn_sqrtf(fmaxf(1.0f - u * u, 0.0f));   // raw v_sqrt_f32 (1 ulp): sqrtf costs ~20 instructions here
+    const float cy = py - h.w * dx, cz = pz - kz * dx;
+#if defined(R2_EXP_SLAB) && R2_EXP_SLAB == 1
+    return true;
+#elif defined(R2_EXP_SLAB) && R2_EXP_SLAB == 2
+    const float ey = 0.5f * h.y * t, ez = 0.5f * h.z * t;
+#else
+    const float ey = h.y * t, ez = h.z * t;
+#endif
+    return (fabsf(dx) <= h.x) && (cy - ey <= y0 + 7.5f) && (cy + ey >= y0 + 0.5f) && (cz - ez <= z0 + 7.5f) &&
+           (cz + ez >= z0 + 0.5f);
 }
 
 // Measured and left out: a second step body that walks whole rows of 8 voxels with one recurrence for the entries that allow
 // it (85 % here; three compaction queues, one tier per step): 0.666 -> 0.718 ms at 256^3 -- two ~2000-instruction bodies and
 // more partly filled steps cost more than the two v_exp_f32 per row it saves.
+// Measured and left out (round 4): the recurrence state of two rows in one register pair and v_pk_mul_f32 for its two
+// multiplications per voxel (4 -> 3 VALU instructions per voxel): 425 -> 435 us.  Packed f32 multiplies do not issue at twice
+// the scalar rate here.
 __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const float4 r, float xc, float y0, float z0,
                                           float (&acc)[64])
 {
@@ -88,6 +114,21 @@ __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const 
     }
 }
 
+// number of set bits of a ballot below this lane (v_mbcnt: no 64-bit lane mask to keep in registers)
+__device__ __forceinline__ uint32_t lanes_below(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// one entry, voxel-parallel: lane = voxel y*8+z of the slab at x = xc (exact exp; ~20 instructions per entry)
+__device__ __forceinline__ float vfwd_voxel_parallel(const float4 p, const float4 q, const float4 r, float xc, float y0, float z0, int lane)
+{
+    const float dx = p.x - xc, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);
+    const float pl = dx * (q.x * dx + q.y * dy + q.z * dz) + dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
+    const float al = __builtin_amdgcn_exp2f(pl);
+    return ((pl <= r.z) && (al >= ALPHA_MIN_3D)) ? al : 0.f;
+}
+
 #ifndef R2_VFWD_WGS
 #define R2_VFWD_WGS 4
 #endif
@@ -115,11 +156,11 @@ __device__ __forceinline__ void vfwd_item_body(
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = half * 4 + wave;
     const float xc = (float)(tx * TILE3D + slab) + 0.5f, y0 = (float)(ty * TILE3D), z0 = (float)(tz * TILE3D);
-    const unsigned long long lt_mask = (1ull << lane) - 1ull;
 
     // the workgroup stages VFWD_BATCH entries at a time (one per thread); every wave then picks the entries whose
     // bounding box touches ITS x-slab
-    __shared__ float4 s0[VFWD_BATCH], s1[VFWD_BATCH], s2[VFWD_BATCH], s3[VFWD_BATCH];   // p, q, r, extents
+    // p, q, r (+ per wave 64 carry rows behind the batch: records of the live entries a batch left over), extents
+    __shared__ float4 s0[VFWD_BATCH + 256], s1[VFWD_BATCH + 256], s2[VFWD_BATCH + 256], s3[VFWD_BATCH];
     __shared__ uint16_t sQ[4][VFWD_BATCH];
 
     if (end - beg < (uint32_t)VFWD_MIN_STEP) {
@@ -137,8 +178,8 @@ __device__ __forceinline__ void vfwd_item_body(
             float sum = 0.f;
             for (int j = 0; j < n; ++j) {
                 const float4 p = s0[j], h = s3[j];
-                if (!slab_live(p.x, p.y, p.z, h, xs, y0, z0)) continue;   // wave-uniform
                 const float4 q = s1[j], r = s2[j];
+                if (!slab_live(p.x, p.y, p.z, h, r.w, xs, y0, z0)) continue;   // wave-uniform
                 const float dx = p.x - xs, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);
                 const float pl = dx * (q.x * dx + q.y * dy + q.z * dz) + dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
                 const float al = __builtin_amdgcn_exp2f(pl);
@@ -159,17 +200,22 @@ __device__ __forceinline__ void vfwd_item_body(
     for (int i = 0; i < 64; ++i) acc[i] = 0.f;
     float tail = 0.f;   // voxel-parallel contributions: already in the final (lane = voxel) layout
     bool stepped = false;   // wave-uniform: did any lane-per-entry step run (else acc is still all zero)
+    int ncarry = 0;         // wave-uniform: entries in the wave's carry rows
+    const int carry0 = VFWD_BATCH + wave * 64;
 
-    for (uint32_t base = beg; base < end; base += VFWD_BATCH) {
-        {
+    for (uint32_t base = beg;; base += VFWD_BATCH) {
+        // one extra pass after the last batch flushes the carry buffer through the same step code (a second copy of the step
+        // body costs registers: 126 -> 128 VGPRs + scratch)
+        const bool flush = base >= end;   // workgroup-uniform
+        if (!flush) {
             const uint32_t k = base + (uint32_t)tid;
             const uint32_t id = point_list[k < end ? k : beg];
             const float4 np = rec[3 * id], nq = rec[3 * id + 1], nr = rec[3 * id + 2], nh = ext[id];
             __syncthreads();   // the previous batch has been consumed
             s0[tid] = np; s1[tid] = nq; s2[tid] = nr; s3[tid] = nh;
+            __syncthreads();
         }
-        __syncthreads();
-        const int nbatch = (int)min((uint32_t)VFWD_BATCH, end - base);
+        const int nbatch = flush ? 0 : (int)min((uint32_t)VFWD_BATCH, end - base);
         // compaction: entries that may use the row recurrence queue up from the front of sQ, the few that need the exact
         // evaluation (needs_exact_row3: very thin along z, or no finite culling box) from the back -- they are evaluated
         // voxel-parallel with the tail, so that the lane-per-entry step is straight-line code (the exact variant of the step
@@ -180,44 +226,51 @@ __device__ __forceinline__ void vfwd_item_body(
             const int e = r * 64 + lane;
             const float4 p = s0[e], h = s3[e];
             const float4 g = s2[e];
-            const bool live = e < nbatch && slab_live(p.x, p.y, p.z, h, xc, y0, z0);
+            const bool live = e < nbatch && slab_live(p.x, p.y, p.z, h, g.w, xc, y0, z0);
             const bool ex = live && needs_exact_row3(g.y, g.z, h.z);
             const bool keep = live && !ex;
             const unsigned long long m = __ballot(keep), mx = __ballot(ex);
-            if (keep) sQ[wave][cnt + __popcll(m & lt_mask)] = (uint16_t)e;
-            if (ex) sQ[wave][VFWD_BATCH - 1 - (cntx + __popcll(mx & lt_mask))] = (uint16_t)e;
+            if (keep) sQ[wave][cnt + (int)lanes_below(m)] = (uint16_t)e;
+            if (ex) sQ[wave][VFWD_BATCH - 1 - (cntx + (int)lanes_below(mx))] = (uint16_t)e;
             cnt += __popcll(m);
             cntx += __popcll(mx);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // Round 4: a batch's remainder of fewer than 64 live entries is not flushed as a partly filled step; its records move
+        // to the wave's carry buffer and open the next batch's first step (fill of the steps at 256^3: 80 % -> 91 %).
         int head = 0;
-        for (; cnt - head >= VFWD_MIN_STEP; head += 64) {
+        while (ncarry + (cnt - head) >= (flush ? VFWD_STEP_MIN : 64)) {
             float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = make_float4(0.f, 0.f, -INFINITY, 0.f);   // idle lane
-            if (head + lane < cnt) {
-                const int e = sQ[wave][head + lane];
+            if (head + lane - ncarry < cnt) {
+                const int e = lane < ncarry ? carry0 + lane : (int)sQ[wave][head + lane - ncarry];
                 ep = s0[e]; eq = s1[e]; er = s2[e];
             }
             vfwd_item(ep, eq, er, xc, y0, z0, acc);
             stepped = true;
+            head += 64 - ncarry;
+            ncarry = 0;
         }
-        // a tail too short to fill a lane-per-entry step, and the exact entries, are evaluated voxel-parallel instead (lane =
-        // voxel y*8+z of the slab, entries broadcast from LDS, exact exp): ~20 instructions per entry instead of a
-        // ~500-instruction step
-        // (head may have stepped past cnt: the last lane-per-entry step was a partial one.  Round 2 computed the tail length as
-        // (cnt - head) + cntx without the clamp: a negative remainder swallowed that many of the EXACT entries -- found in round 3
-        // by a 32^3 grid whose voxels are larger than most Gaussians, where thin entries are the rule, not the exception)
-        const int rem = max(cnt - head, 0);
-        const int ntail = rem + cntx;
-        for (int t = 0; t < ntail; ++t) {
-            const int j = t < rem ? head + t : VFWD_BATCH - 1 - (t - rem);
-            const int e = sQ[wave][j];
-            const float4 p = s0[e], q = s1[e], r = s2[e];
-            const float dx = p.x - xc, dy = p.y - (y0 + (float)(lane >> 3) + 0.5f), dz = p.z - (z0 + (float)(lane & 7) + 0.5f);
-            const float pl = dx * (q.x * dx + q.y * dy + q.z * dz) + dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
-            const float al = __builtin_amdgcn_exp2f(pl);
-            const bool ok = (pl <= r.z) && (al >= ALPHA_MIN_3D);
-            tail += ok ? al : 0.f;
+        if (flush) {
+            // fewer than VFWD_STEP_MIN entries left: voxel-parallel (a step would be mostly idle)
+            for (int t = 0; t < ncarry; ++t) tail += vfwd_voxel_parallel(s0[carry0 + t], s1[carry0 + t], s2[carry0 + t], xc, y0, z0, lane);
+            break;
+        }
+        {
+            const int rem = cnt - head;   // < 64 - ncarry
+            __builtin_amdgcn_wave_barrier();   // (the step above has read the carry rows this overwrites)
+            if (lane < rem) {
+                const int e = sQ[wave][head + lane];
+                s0[carry0 + ncarry + lane] = s0[e]; s1[carry0 + ncarry + lane] = s1[e]; s2[carry0 + ncarry + lane] = s2[e];
+            }
+            ncarry += rem;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // the exact entries are evaluated voxel-parallel (lane = voxel y*8+z of the slab, entries broadcast from LDS, exact exp)
+        for (int t = 0; t < cntx; ++t) {
+            const int e = sQ[wave][VFWD_BATCH - 1 - t];
+            tail += vfwd_voxel_parallel(s0[e], s1[e], s2[e], xc, y0, z0, lane);
         }
     }
 
@@ -293,21 +346,34 @@ __device__ __forceinline__ void vfwd_short_body(
         ep = rec[3 * id]; eq = rec[3 * id + 1]; er = rec[3 * id + 2]; eh = ext[id];
     }
     const float vy = y0 + (float)(lane >> 3) + 0.5f, vz = z0 + (float)(lane & 7) + 0.5f;
+    // Round 4: every lane first tests ITS entry against the 8 slabs (one pass of 8 tests for the whole list); the walk over
+    // the entries then broadcasts only the entries that touch a slab at all and evaluates only the slabs of their masks.
+    // (Until round 4 each of the n x 8 tests ran wave-uniformly, 64 lanes computing the same thing: 36 M of the kernel's
+    // 229 M VALU instructions at 256^3 for 3 % of the instances.)
+    uint32_t mask8 = 0;
+    if (lane < n) {
+#pragma unroll
+        for (int sl = 0; sl < TILE3D; ++sl)
+            if (slab_live(ep.x, ep.y, ep.z, eh, er.w, (float)(tx * TILE3D + sl) + 0.5f, y0, z0)) mask8 |= 1u << sl;
+    }
     float sum[TILE3D];
 #pragma unroll
     for (int sl = 0; sl < TILE3D; ++sl) sum[sl] = 0.f;
-    for (int j = 0; j < n; ++j) {
+    unsigned long long todo = __ballot(mask8 != 0);
+    while (todo) {
+        const int j = __ffsll((long long)todo) - 1;   // list order: the summation order of the reference
+        todo &= todo - 1;
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readlane((int)mask8, j);
         const float4 p = make_float4(lane_bcast(ep.x, j), lane_bcast(ep.y, j), lane_bcast(ep.z, j), 0.f);
         const float4 q = make_float4(lane_bcast(eq.x, j), lane_bcast(eq.y, j), lane_bcast(eq.z, j), lane_bcast(eq.w, j));
         const float4 r = make_float4(lane_bcast(er.x, j), lane_bcast(er.y, j), lane_bcast(er.z, j), 0.f);
-        const float4 h = make_float4(lane_bcast(eh.x, j), lane_bcast(eh.y, j), lane_bcast(eh.z, j), 0.f);
         const float dy = p.y - vy, dz = p.z - vz;
         const float kyz = dy * (q.w * dy + r.x * dz) + ((r.y * dz) * dz + r.z);
         const float kx = q.y * dy + q.z * dz;
 #pragma unroll
         for (int sl = 0; sl < TILE3D; ++sl) {
+            if (!((m >> sl) & 1u)) continue;   // wave-uniform (scalar)
             const float xs = (float)(tx * TILE3D + sl) + 0.5f;
-            if (!slab_live(p.x, p.y, p.z, h, xs, y0, z0)) continue;   // wave-uniform (scalar operands)
             const float dx = p.x - xs;
             // same expression tree as the item kernel's voxel-parallel paths
             const float pl = dx * (q.x * dx + kx) + kyz;
@@ -589,7 +655,7 @@ __global__ void __launch_bounds__(64) voxel_render_backward_kernel(
         if (mine) {
 #pragma unroll
             for (int sl = 0; sl < TILE3D; ++sl)
-                if (slab_live(p.x, p.y, p.z, h, tx0 + (float)sl + 0.5f, ty0, tz0)) mask |= 1u << sl;
+                if (slab_live(p.x, p.y, p.z, h, r.w, tx0 + (float)sl + 0.5f, ty0, tz0)) mask |= 1u << sl;
         }
         const int cnt = __popc(mask);
         int incl = cnt;

@@ -33,10 +33,11 @@ __device__ __forceinline__ bool needs_exact_row3(float F2, float L, float hx)
 }
 
 struct VoxelGeom {
-    float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,L,-}: inverse covariance
+    float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,L,kz}: inverse covariance
                               //      (xx,xy,xz,yy,yz,zz) pre-scaled by -log2e/2 (diagonal) or -log2e (off-diagonal),
                               //      L = log2(opacity)
-    float4 *ext;              // [P]  {hx,hy,hz,-}: half-extents (voxels) of the bounding box of alpha >= 1e-6
+    float4 *ext;              // [P]  {hx,hyc,hzc,ky}: x half-extent (voxels) of the bounding box of alpha >= 1e-6; half-extents
+                              //      of its central y-z cross-section; with kz: how the cross-section's centre moves with x
     uint32_t *depth_key;      // [P]  bits of world z, the arbitrary low sort word of the reference (Q10); 
     uint32_t *iota;           // [P]
     uint32_t *depth_sorted;   // [P]

@@ -35,7 +35,7 @@ def main():
     co = st["conic_opacity"][ids].astype(np.float64)
     rad = np.stack([st["radii_x"][ids], st["radii_y"][ids], st["radii_z"][ids]], 1).astype(np.float64)
     g = n // 8
-    tot = dict(instances=0, evaluated_now=0, subtile_4=0, slab_rows=0, live=0, tiles_dead=0)
+    tot = dict(instances=0, evaluated_now=0, slab_cond=0, slab_exact=0, subtile_4=0, slab_rows=0, live=0, tiles_dead=0)
     for k in range(len(ids)):
         a, b, cc, d, e, f, op = co[k]
         C = np.array([[a, b, cc], [b, d, e], [cc, e, f]])
@@ -75,11 +75,31 @@ def main():
         tot["slab_rows"] += tx1.sum() * ty1.sum() * tz8.sum() * 8
         tot["subtile_4"] += tx4.sum() * ty4.sum() * tz4.sum() * 64
         tot["tiles_dead"] += ninst - tx8.sum() * ty8.sum() * tz8.sum()
+        # slab_cond (round 4): the cross-section of the cut-off ellipsoid at the slab's x is an ellipse centred at
+        # p_yz - k * dx with the half-extents hc * sqrt(1 - (dx / hx)^2); its bounding box against the tile's y / z range
+        M = np.array([[d, e], [e, f]])
+        Minv = np.linalg.inv(M)
+        kyz = -Minv @ np.array([b, cc])            # conditional centre of (dy, dz) per unit dx
+        hc = np.sqrt(qmax * np.diag(Minv)) * 1.004 + 0.05
+        t = np.sqrt(np.clip(1.0 - (dx / h[0]) ** 2, 0.0, None))       # per slab x
+        cy = pv[k, 1] - kyz[0] * dx
+        cz = pv[k, 2] - kyz[1] * dx
+        y8 = np.arange(lo[1], hi[1]) * 8.0
+        z8 = np.arange(lo[2], hi[2]) * 8.0
+        oky = (cy[:, None] - hc[0] * t[:, None] <= y8[None, :] + 7.5) & (cy[:, None] + hc[0] * t[:, None] >= y8[None, :] + 0.5)
+        okz = (cz[:, None] - hc[1] * t[:, None] <= z8[None, :] + 7.5) & (cz[:, None] + hc[1] * t[:, None] >= z8[None, :] + 0.5)
+        cond = tx1[:, None, None] & oky[:, :, None] & okz[:, None, :]
+        tot["slab_cond"] += cond.sum() * 64
+        lv = live.reshape(len(x), hi[1] - lo[1], 8, hi[2] - lo[2], 8).any(axis=(2, 4))
+        assert not (lv & ~cond).any(), "the conditional test dropped a slab that holds a live voxel"
+        tot["slab_exact"] += lv.sum() * 64
     v = tot["instances"] * 512.0
     print("sampled Gaussians %d, instances %d (%.1f per Gaussian)" % (len(ids), tot["instances"], tot["instances"] / len(ids)))
     print("instances whose tile the alpha >= 1e-6 box does not touch at all: %.3f" % (tot["tiles_dead"] / tot["instances"]))
-    for kx in ("evaluated_now", "subtile_4", "slab_rows", "live"):
+    for kx in ("evaluated_now", "slab_cond", "slab_exact", "subtile_4", "slab_rows", "live"):
         print("%-14s %.4f of instances x 512 voxels" % (kx, tot[kx] / v))
+    print("slab_cond / evaluated_now = %.3f   slab_exact / evaluated_now = %.3f" % (
+        tot["slab_cond"] / tot["evaluated_now"], tot["slab_exact"] / tot["evaluated_now"]))
     print("live / evaluated_now = %.3f   subtile_4 / evaluated_now = %.3f   slab_rows / evaluated_now = %.3f" % (
         tot["live"] / tot["evaluated_now"], tot["subtile_4"] / tot["evaluated_now"], tot["slab_rows"] / tot["evaluated_now"]))
 
