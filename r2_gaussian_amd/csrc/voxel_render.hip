@@ -68,50 +68,84 @@ __device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h
 __device__ __forceinline__ void vfwd_item(const float4 p, const float4 q, const float4 r, float xc, float y0, float z0,
                                           float (&acc)[64])
 {
-    // log2(alpha) = a2 dx^2 + b2 dx dy + c2 dx dz + d2 dy^2 + e2 dy dz + f2 dz^2 + L
+    // log2(alpha) = E(y, z) = a2 dx^2 + b2 dx dy + c2 dx dz + d2 dy^2 + e2 dy dz + f2 dz^2 + L, dy = p.y - (y0 + y + 0.5), ...
+    // Round 4: a second recurrence ACROSS the rows.  Until then every row of a slab took 4 v_exp_f32 (two z segments x {start
+    // value, ratio}): 32 quarter-rate instructions and their arguments per step, a quarter of its cycles.  Now per z segment:
+    //   rows 4..7: g(4) = 2^E(4, s), then g(y+1) = g(y) rho(y), rho(y+1) = rho(y) kappa    rho(4) = 2^(E(5,s) - E(4,s))
+    //   rows 3..0: g(3) = 2^E(3, s), then g(y-1) = g(y) rho'(y), rho'(y-1) = rho'(y) kappa  rho'(3) = 2^(E(2,s) - E(3,s))
+    //   z ratio:   rt(4) = 2^(E(4,s+1) - E(4,s)), rt(y+1) = rt(y) chi, rt(y-1) = rt(y) / chi
+    // with kappa = 2^(2 d2), chi = 2^e2 (one v_exp_f32 each per entry): 5 exponentials per segment instead of 16.  The clamps
+    // keep the ratios finite where the Gaussian is long dead (0 * inf); needs_exact_slab3 (voxel_state.hpp) keeps out the
+    // entries for which a walk could start from an underflowed value and climb back above the cut-off.
     const float dx = p.x - xc;
     const float adx2L = q.x * dx * dx + r.z;
     const float bdx = q.y * dx, cdx = q.z * dx;
     const float dz0 = p.z - (z0 + 0.5f);
     const float kf1 = r.y * (1.0f - 2.0f * dz0);
     const float rr = __builtin_amdgcn_exp2f(2.0f * r.y);
+    const float kap = __builtin_amdgcn_exp2f(2.0f * q.w);
+    const float chi = __builtin_amdgcn_exp2f(r.x), chii = __builtin_amdgcn_exp2f(-r.x);
+    const float dy4 = p.y - (y0 + 4.5f), dy3 = p.y - (y0 + 3.5f);
+    const float k0u = dy4 * (q.w * dy4 + bdx) + adx2L, k1u = r.x * dy4 + cdx;
+    const float k0d = dy3 * (q.w * dy3 + bdx) + adx2L, k1d = r.x * dy3 + cdx;
+    const float eu = q.w * (1.0f - 2.0f * dy4) - bdx;   // E(5, z) - E(4, z) + e2 dz
+    const float ed = q.w * (1.0f + 2.0f * dy3) + bdx;   // E(2, z) - E(3, z) - e2 dz
 #if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
 #error "the inline asm below assumes a 64-lane EXEC mask (wave64)"
 #endif
     const unsigned long long full_exec = __builtin_amdgcn_read_exec();
     (void)full_exec;
-#pragma unroll
-    for (int iy = 0; iy < TILE3D; ++iy) {
-        const float dy = p.y - (y0 + (float)iy + 0.5f);
-        const float k0 = dy * (q.w * dy + bdx) + adx2L;
-        const float k1 = r.x * dy + cdx;
-#pragma unroll
-        for (int seg = 0; seg < TILE3D; seg += VOX_RECUR_STEPS) {   // re-anchor every VOX_RECUR_STEPS voxels
-            const float dzs = dz0 - (float)seg;
-            float g = __builtin_amdgcn_exp2f(dzs * (r.y * dzs + k1) + k0);
-            float rt = __builtin_amdgcn_exp2f(fminf(kf1 + (2.0f * (float)seg) * r.y - k1, 120.0f));
-#pragma unroll
-            for (int c = 0; c < VOX_RECUR_STEPS; ++c) {
-                // power <= 0 (VOX/forward.cu:288) holds: entries that reach this path have a positive definite conic;
-                // alpha >= 1e-6: VOX/forward.cu:293
-                // acc += (g >= 1e-6) ? g : 0 as an EXEC mask: compare + masked add instead of compare + select + add (487 ->
-                // 467 us at 256^3 once the kernel runs 4 waves/SIMD; it changed nothing at 3)
+    // one row of a segment: acc += (g >= 1e-6) ? g : 0 for VOX_RECUR_STEPS voxels.  power <= 0 (VOX/forward.cu:288) holds:
+    // entries that reach this path have a positive definite conic; alpha >= 1e-6: VOX/forward.cu:293.  The EXEC-mask form
+    // (compare + masked add instead of compare + select + add) took 487 -> 467 us at 256^3 in round 3.
 #ifndef R2_EXP_NO_CMPX
-                asm volatile("v_cmpx_le_f32_e32 %[thr], %[g]\n\t"
-                             "v_add_f32_e32 %[a], %[a], %[g]\n\t"
-                             "s_mov_b64 exec, %[ex]"
-                             : [a] "+v"(acc[iy * TILE3D + seg + c])
-                             : [thr] "n"(0x358637bd), [g] "v"(g), [ex] "s"(full_exec)
-                             : "vcc");
+#define R2_VFWD_ROW(ROW, SEG, G0, RT0)                                                                      \
+    {                                                                                                       \
+        float g_ = (G0), rt_ = (RT0);                                                                       \
+        _Pragma("unroll") for (int c = 0; c < VOX_RECUR_STEPS; ++c) {                                       \
+            asm volatile("v_cmpx_le_f32_e32 %[thr], %[g]\n\t"                                               \
+                         "v_add_f32_e32 %[a], %[a], %[g]\n\t"                                               \
+                         "s_mov_b64 exec, %[ex]"                                                            \
+                         : [a] "+v"(acc[(ROW) * TILE3D + (SEG) + c])                                        \
+                         : [thr] "n"(0x358637bd), [g] "v"(g_), [ex] "s"(full_exec)                          \
+                         : "vcc");                                                                          \
+            g_ *= rt_;                                                                                      \
+            rt_ *= rr;                                                                                      \
+        }                                                                                                   \
+    }
 #else   // the portable statement of the same arithmetic (built as libr2hip_nocmpx.so and compared in tests/test_variants_gpu.py)
-                acc[iy * TILE3D + seg + c] += (g >= ALPHA_MIN_3D) ? g : 0.f;
+#define R2_VFWD_ROW(ROW, SEG, G0, RT0)                                                                      \
+    {                                                                                                       \
+        float g_ = (G0), rt_ = (RT0);                                                                       \
+        _Pragma("unroll") for (int c = 0; c < VOX_RECUR_STEPS; ++c) {                                       \
+            acc[(ROW) * TILE3D + (SEG) + c] += (g_ >= ALPHA_MIN_3D) ? g_ : 0.f;                             \
+            g_ *= rt_;                                                                                      \
+            rt_ *= rr;                                                                                      \
+        }                                                                                                   \
+    }
 #endif
-                g *= rt;
-                rt *= rr;
-            }
+#pragma unroll
+    for (int seg = 0; seg < TILE3D; seg += VOX_RECUR_STEPS) {   // z segments: the z walk is re-anchored every VOX_RECUR_STEPS voxels
+        const float dzs = dz0 - (float)seg;
+        const float zq = r.y * dzs, ez = r.x * dzs;
+        float gu = __builtin_amdgcn_exp2f(dzs * (zq + k1u) + k0u), gd = __builtin_amdgcn_exp2f(dzs * (zq + k1d) + k0d);
+        float ru = __builtin_amdgcn_exp2f(fminf(eu - ez, 100.0f)), rd = __builtin_amdgcn_exp2f(fminf(ed + ez, 100.0f));
+        float rtu = __builtin_amdgcn_exp2f(fminf(kf1 + (2.0f * (float)seg) * r.y - k1u, 100.0f));
+        float rtd = rtu * chii;
+#pragma unroll
+        for (int j = 0; j <= VOX_RECUR_YSTEPS; ++j) {
+            R2_VFWD_ROW(4 + j, seg, gu, rtu)
+            gu *= ru; ru *= kap; rtu *= chi;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j <= VOX_RECUR_YSTEPS; ++j) {
+            R2_VFWD_ROW(3 - j, seg, gd, rtd)
+            gd *= rd; rd *= kap; rtd *= chii;
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef R2_VFWD_ROW
 }
 
 // number of set bits of a ballot below this lane (v_mbcnt: no 64-bit lane mask to keep in registers)
@@ -216,8 +250,12 @@ __device__ __forceinline__ void vfwd_item_body(
             __syncthreads();
         }
         const int nbatch = flush ? 0 : (int)min((uint32_t)VFWD_BATCH, end - base);
+        // (opaque copy of the flag for the code below: otherwise the compiler threads the flush pass into a second copy of
+        // the step body -- 2 x 500 instructions)
+        int flush_pass = __builtin_amdgcn_readfirstlane(flush ? 1 : 0);
+        asm volatile("" : "+s"(flush_pass));
         // compaction: entries that may use the row recurrence queue up from the front of sQ, the few that need the exact
-        // evaluation (needs_exact_row3: very thin along z, or no finite culling box) from the back -- they are evaluated
+        // evaluation (needs_exact_slab3: very thin along y or z, or no finite culling box) from the back -- they are evaluated
         // voxel-parallel with the tail, so that the lane-per-entry step is straight-line code (the exact variant of the step
         // cost 24 VGPRs = one wave per SIMD, and 50 us at 256^3 whenever a single lane of a step asked for it)
         int cnt = 0, cntx = 0;
@@ -227,7 +265,7 @@ __device__ __forceinline__ void vfwd_item_body(
             const float4 p = s0[e], h = s3[e];
             const float4 g = s2[e];
             const bool live = e < nbatch && slab_live(p.x, p.y, p.z, h, g.w, xc, y0, z0);
-            const bool ex = live && needs_exact_row3(g.y, g.z, h.z);
+            const bool ex = live && needs_exact_slab3(s1[e].w, g.y, g.z, h.z);
             const bool keep = live && !ex;
             const unsigned long long m = __ballot(keep), mx = __ballot(ex);
             if (keep) sQ[wave][cnt + (int)lanes_below(m)] = (uint16_t)e;
@@ -240,7 +278,8 @@ __device__ __forceinline__ void vfwd_item_body(
         // Round 4: a batch's remainder of fewer than 64 live entries is not flushed as a partly filled step; its records move
         // to the wave's carry buffer and open the next batch's first step (fill of the steps at 256^3: 80 % -> 91 %).
         int head = 0;
-        while (ncarry + (cnt - head) >= (flush ? VFWD_STEP_MIN : 64)) {
+#pragma nounroll   // (also keeps the first pass -- the only one with carry rows -- from being peeled into a second copy)
+        while (ncarry + (cnt - head) >= (flush_pass ? VFWD_STEP_MIN : 64)) {
             float4 ep = make_float4(0.f, 0.f, 0.f, 0.f), eq = ep, er = make_float4(0.f, 0.f, -INFINITY, 0.f);   // idle lane
             if (head + lane - ncarry < cnt) {
                 const int e = lane < ncarry ? carry0 + lane : (int)sQ[wave][head + lane - ncarry];
@@ -251,7 +290,7 @@ __device__ __forceinline__ void vfwd_item_body(
             head += 64 - ncarry;
             ncarry = 0;
         }
-        if (flush) {
+        if (flush_pass) {
             // fewer than VFWD_STEP_MIN entries left: voxel-parallel (a step would be mostly idle)
             for (int t = 0; t < ncarry; ++t) tail += vfwd_voxel_parallel(s0[carry0 + t], s1[carry0 + t], s2[carry0 + t], xc, y0, z0, lane);
             break;
@@ -500,6 +539,38 @@ __global__ void __launch_bounds__(512) voxel_combine_kernel(
     }
 }
 
+// Production form of the combine pass (round 4): ONE WAVE per tile.  Almost every tile of a query has been written by the
+// forward kernels already (one work item, or a short list), so the pass is a test per tile; with a 512-thread workgroup per
+// tile it was 262144 waves at 256^3 (23 us) to find the 53 empty tiles.  A wave that has work walks the tile's 8 slabs.
+__global__ void __launch_bounds__(512) voxel_combine_tiles_kernel(
+    const uint32_t *__restrict__ chunk_base, const float *__restrict__ partial, VoxelGrid v, float *__restrict__ out,
+    const uint2 *__restrict__ ranges, uint32_t T, uint32_t short_min, VoxelPublish pub)
+{
+    for (uint32_t i = blockIdx.x * 512u + threadIdx.x; i < pub.n; i += gridDim.x * 512u) {   // side job: see voxel_combine_kernel
+        if (i < pub.R) { pub.dst_plist[i] = pub.src_plist[i]; pub.dst_tiles[i] = pub.src_tiles[i]; }
+        if (i < pub.T) pub.dst_ranges[i] = pub.src_ranges[i];
+        if (i < pub.T + 1u) pub.dst_chunk_base[i] = pub.src_chunk_base[i];
+        if (i < pub.NW) pub.dst_work[i] = pub.src_work[i];
+    }
+    const uint32_t tile = blockIdx.x * 8u + (threadIdx.x >> 6);
+    if (tile >= T) return;
+    if (short_min) {   // tiles with a short list were rendered by the short-list kernel
+        const uint2 rg = ranges[tile];
+        if (rg.y != rg.x && rg.y - rg.x < short_min) return;
+    }
+    const uint32_t w0 = chunk_base[tile], w1 = chunk_base[tile + 1];
+    if (w1 - w0 == 1u) return;   // written directly by the forward kernel
+    const int lane = threadIdx.x & 63;
+    const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
+    const int vy = ty * TILE3D + (lane >> 3), vz = tz * TILE3D + (lane & 7);
+    for (int sl = 0; sl < TILE3D; ++sl) {
+        float C = 0.f;
+        for (uint32_t w = w0; w < w1; ++w) C += partial[(size_t)w * 512 + sl * 64 + lane];   // list order
+        const int vx = tx * TILE3D + sl;
+        if (vx < v.nx && vy < v.ny && vz < v.nz) out[((size_t)vx * v.ny + vy) * v.nz + vz] = C;
+    }
+}
+
 __device__ __forceinline__ void voxel_moments(const float4 p, float ry2, float dz, float k0, float k1, float g,
                                               float &r0, float &r1, float &r2)
 {
@@ -734,8 +805,7 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
         if (im.NW > 0)
             voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
-        voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
-                                                                  im.n_contrib, im.ranges, 0u, pub);
+        voxel_combine_tiles_kernel<<<dim3((T + 7) / 8), dim3(512), 0, s>>>(im.chunk_base, im.partial, v, out_volume, im.ranges, T, 0u, pub);
         return 0;
     }
     if (write_ncontrib) {
@@ -760,8 +830,8 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
                 item_blocks, im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
         }
     }
-    voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
-                                                              im.n_contrib, im.ranges, im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u, pub);
+    voxel_combine_tiles_kernel<<<dim3((T + 7) / 8), dim3(512), 0, s>>>(im.chunk_base, im.partial, v, out_volume, im.ranges, T,
+                                                                        im.NW > 0 ? (uint32_t)VFWD_MIN_STEP : 0u, pub);
     return 0;
 }
 
