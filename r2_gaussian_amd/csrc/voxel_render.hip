@@ -167,7 +167,7 @@ __device__ __forceinline__ float vfwd_voxel_parallel(const float4 p, const float
 #define R2_VFWD_WGS 4
 #endif
 __device__ __forceinline__ void vfwd_item_body(
-    const uint32_t bid /* workgroup index among the item workgroups */,
+    const uint32_t hb /* half-item: work item hb / 2, x-slabs 4 (hb & 1) .. + 3 */,
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
     VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
@@ -175,13 +175,6 @@ __device__ __forceinline__ void vfwd_item_body(
     // two workgroups of 4 waves per work item (x-slabs 0-3 and 4-7): tile lists are short (~150 entries at 256^3), so
     // a workgroup is one dependent chain of gathers followed by 2-3 evaluation steps -- small workgroups let 4+ of them
     // overlap on a CU
-    // XCD-aware order: workgroup b runs on XCD b % 8.  Runs of 128 consecutive half-items (64 tiles in list order:
-    // neighbours that share most of their Gaussians) go to one XCD, so their record gathers hit that XCD's L2; the
-    // runs are dealt round-robin over the 8 XCDs, which keeps the dense middle of the volume spread over all of them.
-    const uint32_t nhalf = 2u * chunk_base[T];
-    const uint32_t seq = bid >> 3;
-    const uint32_t hb = ((seq >> 7) * 8u + (bid & 7u)) * 128u + (seq & 127u);
-    if (hb >= nhalf) return;
     const uint32_t w = hb >> 1;
     const int half = (int)(hb & 1u);
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
@@ -348,12 +341,34 @@ __device__ __forceinline__ void vfwd_item_body(
     }
 }
 
+// The item workgroups of a launch: workgroup `bid` of `item_grid` (a multiple of 1024) takes the half-items hb(bid),
+// hb(bid) + item_grid, ...  The host sizes item_grid from an estimate of the work list's length (the list itself exists only on
+// the device): with the upper bound it used until round 4, two thirds of the workgroups of a 256^3 query found nothing to do and
+// cost 10 us of dispatch; an estimate that falls short just means a second pass for some workgroups.
+__device__ __forceinline__ void vfwd_items(
+    const uint32_t bid, const uint32_t item_grid,
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
+    uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
+    VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
+{
+    // XCD-aware order: workgroup b runs on XCD b % 8.  Runs of 128 consecutive half-items (64 tiles in list order:
+    // neighbours that share most of their Gaussians) go to one XCD, so their record gathers hit that XCD's L2; the
+    // runs are dealt round-robin over the 8 XCDs, which keeps the dense middle of the volume spread over all of them.
+    const uint32_t nhalf = 2u * chunk_base[T];
+    const uint32_t seq = bid >> 3;
+#pragma nounroll
+    for (uint32_t hb = ((seq >> 7) * 8u + (bid & 7u)) * 128u + (seq & 127u); hb < nhalf; hb += item_grid) {
+        vfwd_item_body(hb, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
+        __syncthreads();   // the next item reuses the LDS buffers
+    }
+}
+
 __global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, const float4 *__restrict__ ext,
     VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
 {
-    vfwd_item_body(blockIdx.x, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
+    vfwd_items(blockIdx.x, gridDim.x, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
 }
 
 // Short tile lists (fewer than VFWD_MIN_STEP entries: 71 % of the non-empty tiles of a 256^3 query, 3 % of the instances).
@@ -444,7 +459,7 @@ __global__ void __launch_bounds__(256, R2_VFWD_WGS) voxel_render_forward_both_ke
     const uint4 *__restrict__ work_tile, uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
     const float4 *__restrict__ ext, VoxelGrid v, float *__restrict__ partial, float *__restrict__ out)
 {
-    if (blockIdx.x < item_blocks) vfwd_item_body(blockIdx.x, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
+    if (blockIdx.x < item_blocks) vfwd_items(blockIdx.x, item_blocks, ranges, chunk_base, work_tile, T, point_list, rec, ext, v, partial, out);
     else vfwd_short_body(blockIdx.x - item_blocks, ranges, T, point_list, rec, ext, v, out);
 }
 
@@ -805,7 +820,9 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
         if (im.NW > 0)
             voxel_render_forward_kernel<<<dim3((unsigned)(((2 * im.NW + 1023) / 1024) * 1024)), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, g.ext, v, im.partial, out_volume);
-        voxel_combine_tiles_kernel<<<dim3((T + 7) / 8), dim3(512), 0, s>>>(im.chunk_base, im.partial, v, out_volume, im.ranges, T, 0u, pub);
+        // (a workgroup per tile here: on a small grid most tiles hold several work items, and the publish job wants the lanes)
+        voxel_combine_kernel<false><<<dim3(T), dim3(512), 0, s>>>(im.chunk_base, im.partial, im.partial_last, v, out_volume,
+                                                                  im.n_contrib, im.ranges, 0u, pub);
         return 0;
     }
     if (write_ncontrib) {
@@ -819,7 +836,16 @@ int launch_voxel_render_forward(const VoxelGeom &g, const VoxelBinning &b, const
     if (im.NW > 0) {
         // short lists: one wave per tile (the work list holds no item for them, see voxel_short_list_min())
         // grid rounded up to whole 1024-block XCD interleave groups (the in-kernel block -> work item map)
-        const unsigned item_blocks = (unsigned)(((2 * im.NW + 1023) / 1024) * 1024);
+        // item workgroups: an estimate of the work list (two per ~512 instances; im.NW is the upper bound), see vfwd_items
+        unsigned item_blocks = (unsigned)(((std::min<size_t>(2 * im.NW, std::max<size_t>(1024, im.R / 256)) + 1023) / 1024) * 1024);
+#ifdef R2_EXP_EXACT_GRID   // experiment: what do the workgroups beyond the work list cost?  (host read-back: not a product path)
+        {
+            uint32_t nitems = 0;
+            (void)hipMemcpyAsync(&nitems, im.chunk_base + T, 4, hipMemcpyDeviceToHost, s);
+            (void)hipStreamSynchronize(s);
+            item_blocks = (unsigned)(((2 * (size_t)nitems + 1023) / 1024) * 1024);
+        }
+#endif
         static const bool split = [] { const char *e = getenv("R2_VOXEL_SPLIT_SHORT"); return e && e[0] == '1'; }();
         if (split) {
             voxel_render_short_kernel<<<dim3((T + 3) / 4), dim3(256), 0, s>>>(im.ranges, T, b.point_list, g.rec, g.ext, v, out_volume);

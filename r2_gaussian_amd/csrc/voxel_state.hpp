@@ -132,11 +132,13 @@ struct VoxelImage {
     uint32_t *n_contrib;    // [V], debug only
     char *work_temp;       // scratch of the parallel work-list construction
     size_t NW;
+    size_t R;               // instances (host-side copy: launch sizing)
     size_t bytes;
     static VoxelImage carve(char *chunk, size_t T, size_t V, size_t R, bool debug)
     {
         VoxelImage s;
         Bump b(chunk);
+        s.R = R;
         s.NW = R / vox_chunk_for(R) + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 1);
