@@ -365,9 +365,9 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(const uint32_t *__rest
 }
 
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
-                size_t R, uint2 *ranges, size_t T, hipStream_t s)
+                size_t R, uint2 *ranges, size_t T, hipStream_t s, bool ranges_zeroed)
 {
-    R2_HIP_TRY(hipMemsetAsync(ranges, 0, T * sizeof(uint2), s));
+    if (!ranges_zeroed) R2_HIP_TRY(hipMemsetAsync(ranges, 0, T * sizeof(uint2), s));   // (else: an earlier kernel of the caller did it)
     if (R > 0)
         tile_ranges_kernel<<<dim3((unsigned)((R + 255) / 256)), dim3(256), 0, s>>>(tiles_sorted, perm, vals_unsorted,
                                                                                   point_list, (uint32_t)R, ranges);

@@ -259,7 +259,7 @@ int host_mailbox_arm(uint32_t **mailbox /* device-visible pinned host memory, 16
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
-                size_t R, uint2 *ranges, size_t T, hipStream_t s);
+                size_t R, uint2 *ranges, size_t T, hipStream_t s, bool ranges_zeroed = false);
 uint32_t higher_msb(uint32_t n);
 // forward work list: tile t owns work items [chunk_base[t], chunk_base[t+1]), one per `chunk` list entries
 size_t build_work_temp_bytes(size_t T);

@@ -112,7 +112,9 @@ __global__ void __launch_bounds__(RS_THREADS) rs_upsweep_kernel(Buffers buf, uin
     const int e = executed_before(skip, pass);
     const uint32_t *__restrict__ keys = rd_k(buf, e == 0 ? 0 : target_of(e - 1, phase));
     for (uint32_t d = threadIdx.x; d < radix; d += RS_THREADS) hist[d] = 0;
-    if (clear_skip && blockIdx.x == 0 && threadIdx.x == 0) clear_skip[0] = 0u;   // single-pass sorts: spares a memset launch
+    // (first pass of a sort: the skip words start out clear -- spares a memset launch; the word of this pass is set by the scan
+    // kernel that follows, the others by later passes)
+    if (clear_skip && blockIdx.x == 0 && threadIdx.x < RS_MAX_PASSES * 2) clear_skip[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t base = blockIdx.x * (uint32_t)(ipt * RS_THREADS);
     if (ipt == RS_IPT) {
@@ -446,11 +448,10 @@ int sort_pairs_ex(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *
     const int phase = plan.npass & 1;
     const bool has_w = win != nullptr;
     Buffers buf{kin, vin, win, t.keys_alt, t.vals_alt, t.vals2_alt, kout, vout, wout};
-    R2_HIP_TRY(hipMemsetAsync(t.skip, 0, sizeof(uint32_t) * RS_MAX_PASSES * 2, s));
     for (int p = 0; p < plan.npass; ++p) {
         const int bits = plan.bits[p], radix = 1 << bits;
         rs_upsweep_kernel<<<dim3(ntiles), dim3(RS_THREADS), 0, s>>>(buf, (uint32_t)n, plan.shift[p], bits, p, phase, t.skip,
-                                                                     t.H, nullptr);
+                                                                     t.H, p == 0 ? t.skip : nullptr);
         rs_scan_kernel<<<dim3((radix + RS_SCAN_DIGITS - 1) / RS_SCAN_DIGITS), dim3(RS_SCAN_THREADS), 0, s>>>(
             t.H, ntiles, bits, (uint32_t)n, p, allow_skip ? 1 : 0, t.skip, t.totals);
         // per-wave histograms + digit offsets (+ for narrow digits: regrouped tile starts and the staged tile itself)

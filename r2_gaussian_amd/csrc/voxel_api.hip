@@ -139,9 +139,13 @@ extern "C" int r2_voxel_forward(
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0);
     const uint32_t *tile_counts = nullptr;
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
+    bool ranges_zeroed = false;   // img.ranges zero-filled by the duplicate kernel
     if (R > 0) {
         { StageScope t(ST_VOX_DUPLICATE, s);
-        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, full_order ? nullptr : host_words + DW_NVIS, s); }
+        const int bit0 = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));
+        ranges_zeroed = !sort_is_single_pass(bit0);   // the multi-pass path below builds the ranges with tile_ranges()
+        launch_voxel_duplicate(geom, bin, v, P, radii_x, radii_y, radii_z, full_order ? nullptr : host_words + DW_NVIS, s,
+                               ranges_zeroed ? img.ranges : nullptr, T); }
         R2_STAGE_CHECK(debug, s, "duplicateWithKeys");
         const int bit = (int)higher_msb((uint32_t)(T > 1 ? T - 1 : 1));   // bits of the largest tile id (the reference
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)
@@ -167,7 +171,7 @@ extern "C" int r2_voxel_forward(
         launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(R), img.ranges, img.chunk_base, img.work_tile, s,
                                voxel_short_list_min(debug != 0));
     } else {
-        rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s);
+        rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s, ranges_zeroed);
         if (rc) return rc;
         launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(R), img.chunk_base, img.work_tile, img.work_temp, s,
                           voxel_short_list_min(debug != 0));

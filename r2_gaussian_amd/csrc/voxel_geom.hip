@@ -253,8 +253,11 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     int P, const float4 *__restrict__ rec, const uint32_t *__restrict__ order, const uint32_t *__restrict__ offsets,
     const int *__restrict__ radii_x, const int *__restrict__ radii_y, const int *__restrict__ radii_z, int gx, int gy,
     int gz, uint32_t *__restrict__ first, uint4 *__restrict__ cube, uint32_t *__restrict__ tiles, uint32_t *__restrict__ vals,
-    const uint32_t *__restrict__ nvis)
+    const uint32_t *__restrict__ nvis, uint2 *__restrict__ zero_ranges, uint32_t zero_T)
 {
+    // side job: the tile ranges start out empty (tile_ranges_kernel only writes the tiles that hold instances) -- a separate
+    // fill launch costs ~5 us
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < zero_T; i += gridDim.x * 256u) zero_ranges[i] = make_uint2(0u, 0u);
     if (nvis) P = min(P, (int)*nvis);   // hinted depth order: only the visible prefix of order / offsets is written
     const int j = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -508,11 +511,13 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
 }
 
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
-                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s)
+                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s, uint2 *zero_ranges,
+                           size_t zero_T)
 {
     voxel_duplicate_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, g.rec, g.order, g.offsets, radii_x, radii_y,
                                                                        radii_z, v.gx, v.gy, v.gz, g.first, g.cube,
-                                                                       b.tiles_unsorted, b.vals_unsorted, nvis);
+                                                                       b.tiles_unsorted, b.vals_unsorted, nvis, zero_ranges,
+                                                                       zero_ranges ? (uint32_t)zero_T : 0u);
     return 0;
 }
 

@@ -182,7 +182,7 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
                         const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
-                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s);
+                           const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s, uint2 *zero_ranges = nullptr, size_t zero_T = 0);
 // the seven gradient arrays of the voxelizer backward, for a kernel that zero-fills them
 struct ZeroArrays {
     float *p[7];
