@@ -31,7 +31,7 @@ constexpr int VFWD_MIN_STEP = 25;  // tile lists shorter than this go to the one
 // Within a work item, a wave's remainder of fewer live entries than VFWD_STEP_MIN is evaluated voxel-parallel instead of as a
 // (partly filled) lane-per-entry step.  Round 4: the remainder loop is a chain of dependent LDS reads that costs about as much
 // as 80 instructions per entry (fitted from SQ_INSTS_VALU and time of two builds), a step ~420 whatever its fill: break-even
-// at 5-6 entries, not at the 25 this used until round 4 (scripts: /profiles r04f_voxel_steps.txt).
+// at 5-6 entries, not at the 25 this used until round 4 (profiles/r04f_voxel_steps.txt).
 #ifndef R2_VFWD_STEP_MIN
 #define R2_VFWD_STEP_MIN 6
 #endif
