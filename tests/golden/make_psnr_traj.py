@@ -4,6 +4,7 @@ tests/test_psnr_parity_gpu.py trains the same case with the HIP kernels and comp
 
     python tests/golden/make_psnr_traj.py            (about 10 minutes on 8 cores)
     python tests/golden/make_psnr_traj.py medium     (256^2 detector / 128^3 volume / 50k-Gaussian phantom; about an hour)
+    python tests/golden/make_psnr_traj.py large      (512^2 detector / 256^3 volume / 150k-Gaussian phantom; 1-2 hours on 8 cores)
 """
 import json
 import os
@@ -18,14 +19,19 @@ EVAL_EVERY = 100
 MEDIUM = dict(case=dict(detector=256, n_vol=128, n_views=50, p_gt=50000, n_init=12000, seed=3),
               opt=dict(iterations=2000, densify_from_iter=300, densify_until_iter=1500, densification_interval=100),
               eval_every=200, file="psnr_traj_oracle_medium.json")
+# round 4: the headline's detector and query volume (512^2 / 256^3), a 150k-Gaussian phantom, 40k -> ~150k Gaussians
+LARGE = dict(case=dict(detector=512, n_vol=256, n_views=50, p_gt=150000, n_init=40000, seed=4),
+             opt=dict(iterations=1200, densify_from_iter=200, densify_until_iter=900, densification_interval=100),
+             eval_every=200, file="psnr_traj_oracle_large.json")
 
 if __name__ == "__main__":
     import torch
     from tests import mini_trainer as T
     torch.set_num_threads(int(os.environ.get("R2_GOLDEN_THREADS", os.cpu_count())))
     name = "psnr_traj_oracle.json"
-    if len(sys.argv) > 1 and sys.argv[1] == "medium":
-        CASE, OPT, EVAL_EVERY, name = MEDIUM["case"], MEDIUM["opt"], MEDIUM["eval_every"], MEDIUM["file"]
+    if len(sys.argv) > 1 and sys.argv[1] in ("medium", "large"):
+        PRESET = MEDIUM if sys.argv[1] == "medium" else LARGE
+        CASE, OPT, EVAL_EVERY, name = PRESET["case"], PRESET["opt"], PRESET["eval_every"], PRESET["file"]
     case = T.Case(**CASE)
     out = T.train(case, T.Opt(**OPT), "oracle", eval_every=EVAL_EVERY, seed=0, log=print)
     out.update(case=CASE, opt=OPT, eval_every=EVAL_EVERY)
