@@ -39,7 +39,8 @@ __device__ __forceinline__ void voxel_preprocess_one(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const VoxelGrid &v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out,
+    uint4 *__restrict__ cube = nullptr)
 {
     key_out = DEPTH_CULLED_KEY;
     radii_x[idx] = 0;
@@ -107,6 +108,12 @@ __device__ __forceinline__ void voxel_preprocess_one(
     radii_y[idx] = (int)rad.y;
     radii_z[idx] = (int)rad.z;
     tiles_touched[idx] = n;
+    // the tile cube, written here in Gaussian order (coalesced); the duplicate kernel, which walks the Gaussians in DEPTH order,
+    // then needs one 16-byte gather per Gaussian instead of three radii + the record + the cube arithmetic (round 4: its
+    // per-Gaussian part was 20 of its 38 us at 256^3) and fills in .x, the first instance
+    if (cube)
+        cube[idx] = make_uint4(0u, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
+                               (uint32_t)(hi.y - lo.y));
     key_out = __float_as_uint(p.z);   // visible: hinted depth order, the key goes straight into its bucket
     bt_out = depth_register_key(reg, key_out, n);
     const float op = opacities[idx];
@@ -149,14 +156,14 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg, uint4 *__restrict__ cube)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P)
         voxel_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z,
-                             rec, depth_key, cov3Ds, tiles_touched, ext, reg, key, bt);
+                             rec, depth_key, cov3Ds, tiles_touched, ext, reg, key, bt, cube);
     depth_register_end(reg, (uint32_t)idx, key, bt);
 }
 
@@ -264,31 +271,28 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
     const int wave_first = j - lane;
     if (wave_first >= P) return;
     uint32_t id = 0;
-    int rx = 0, ry = 0, rz = 0;
-    if (j < P) {
-        id = order[j];
-        rx = radii_x[id]; ry = radii_y[id]; rz = radii_z[id];
-    }
-    const bool live = rx > 0 && ry > 0 && rz > 0;
     uint32_t excl, incl;
     if (j < P) {
+        id = order[j];
         incl = offsets[j];
         excl = j == 0 ? 0u : offsets[j - 1];
     } else {
         incl = excl = offsets[P - 1];
     }
-    int3 lo = make_int3(0, 0, 0), hi = lo;
-    if (live) {
-        const float4 r0 = rec[3 * id];
-        tile_cube(make_float3(r0.x, r0.y, r0.z), make_float3((float)rx, (float)ry, (float)rz), gx, gy, gz, lo, hi);
+    // a Gaussian emits instances <=> it is visible; its tile cube was left by the preprocess (see there)
+    int3 lo = make_int3(0, 0, 0);
+    int rw = 0, rh = 0;
+    if (incl != excl) {
+        const uint4 c = cube[id];
+        lo = make_int3((int)(c.y & 0xFFFFu), (int)(c.y >> 16), (int)(c.z & 0xFFFFu));
+        rw = (int)(c.z >> 16);
+        rh = (int)c.w;
         first[id] = excl;
-        cube[id] = make_uint4(excl, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
-                              (uint32_t)(hi.y - lo.y));
+        reinterpret_cast<uint32_t *>(cube + id)[0] = excl;
     }
     const uint32_t wbeg = __shfl(excl, 0);
     const int last_lane = min(63, P - 1 - wave_first);
     const uint32_t wend = __shfl(incl, last_lane);
-    const int rw = hi.x - lo.x, rh = hi.y - lo.y;
     for (uint32_t base = wbeg; base < wend; base += 64) {
         const uint32_t k = base + lane;
         int own = 0;
@@ -506,7 +510,7 @@ int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
                                                                         radii_z, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr,
-                                                                        g.tiles_touched, g.ext, reg);
+                                                                        g.tiles_touched, g.ext, reg, g.cube);
     return 0;
 }
 
