@@ -309,10 +309,22 @@ __global__ void __launch_bounds__(256) voxel_duplicate_kernel(
         if (k < wend) {
             const uint32_t local = k - o_excl;
             const uint32_t xy = (uint32_t)orw * (uint32_t)orh;
-            const int z = oz + (int)(local / xy);
-            const uint32_t rem = local % xy;
-            const int y = oy + (int)(rem / (uint32_t)orw);
-            const int x = ox + (int)(rem % (uint32_t)orw);
+            // local / xy and rem / orw through the float reciprocal: floor((n + 0.5) * rcp(d)) is exact while the product's
+            // rounding error (~1.2e-7 n / d) stays below the 0.5 / d that separates (n + 0.5) / d from an integer, i.e. for
+            // n < 4e6 -- a Gaussian's cube holds a few hundred tiles (the u32 division is ~25 instructions, twice per instance)
+            uint32_t qz, qy;
+            if (local < (1u << 20)) {
+                qz = (uint32_t)(((float)local + 0.5f) * __builtin_amdgcn_rcpf((float)xy));
+                const uint32_t rem0 = local - qz * xy;
+                qy = (uint32_t)(((float)rem0 + 0.5f) * __builtin_amdgcn_rcpf((float)orw));
+            } else {
+                qz = local / xy;
+                qy = (local - qz * xy) / (uint32_t)orw;
+            }
+            const uint32_t rem = local - qz * xy;
+            const int z = oz + (int)qz;
+            const int y = oy + (int)qy;
+            const int x = ox + (int)(rem - qy * (uint32_t)orw);
             tiles[k] = (uint32_t)(z * gy * gx + y * gx + x);
             vals[k] = o_id;
         }
