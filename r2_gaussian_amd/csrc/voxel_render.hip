@@ -48,9 +48,7 @@ __device__ __forceinline__ bool slab_live(float px, float py, float pz, float4 h
     const float u = dx * __builtin_amdgcn_rcpf(h.x);
     const float t = __builtin_amdgcn_sqrtf(fmaxf(1.0f - u * u, 0.0f));   // raw v_sqrt_f32 (1 ulp): sqrtf costs ~20 instructions here
     const float cy = py - h.w * dx, cz = pz - kz * dx;
-#if defined(R2_EXP_SLAB) && R2_EXP_SLAB == 1
-    return true;
-#elif defined(R2_EXP_SLAB) && R2_EXP_SLAB == 2
+#ifdef R2_EXP_SLAB_HALF   // sensitivity experiment of profiles/r04f_voxel_steps.txt: halved cross-section (WRONG volumes)
     const float ey = 0.5f * h.y * t, ez = 0.5f * h.z * t;
 #else
     const float ey = h.y * t, ez = h.z * t;
