@@ -38,37 +38,38 @@ def short(n):
     return m.group(1).replace('(anonymous namespace)::', '') if m else n.split('(')[0][:70]
 
 
-rows = list(csv.DictReader(open(os.path.join(P, "%s_kernel_stats.csv" % tag))))
-pmc = json.load(open(os.path.join(P, "%s_pmc.json" % tag)))
-with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
-    f.write("# %s\n\n" % title)
-    f.write("`rocprofv3 --kernel-trace --stats -- python bench.py --headline-only --steps 30 --warmup 5 --repeats 3` on MI355X: the "
-            "single-view forward + backward step and nothing else (no batched / concurrent / voxelizer / CPU-baseline sections), so "
-            "every row below IS the headline step (full CSV: %s_kernel_stats.csv).  PMC columns: separate rocprofv3 passes over the "
-            "same command, one TCC counter per pass (FETCH_SIZE, WRITE_SIZE; SQ_* in a third), averaged per launch (%s_pmc.json = "
-            "pmc_latest.json, which bench.py reads for `roofline.traffic` when its source hash matches); KB in the json, MB here.  "
-            "Bench lines of the same build: %s_bench.json (default run), %s_bench_driver.json (--steps 20 --warmup 5), "
-            "%s_bench_{B,C,E}.json (BASELINE configs B 50k/512^2, C 300k/560^2, E 1M/1024^2/360 views).\n\n" % (tag, tag, tag, tag, tag))
-    f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) |\n|---|---|---|---|---|---|---|\n")
-    for r in rows[:30]:
-        k = short(r['Name']); p = pmc.get(k, {})
-        f.write("| `%s` | %s | %.1f | %s | %s | %s | %s |\n" % (
-            k, r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'],
-            ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
-            ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
-            ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else ""))
-    f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
-            "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  Kernels named "
-            "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
-            "Gaussians, and every 64th call, which refreshes the depth-range hint); `__amd_rocclr_*` are the runtime's fill / copy "
-            "kernels (torch tensor initialisation).  Counters of the single-view step with derived utilisations: "
-            "r03a_single_view_summary.txt (round 3's kernels; the render / geometry-backward kernels are unchanged since).\n")
-    v = os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag)
-    if os.path.exists(v):
-        f.write("\n## Voxelizer alone: 256^3 query of the same cloud (`scripts/voxel_query_only.py 12`)\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
-        for r in list(csv.DictReader(open(v)))[:16]:
-            f.write("| `%s` | %s | %.1f | %s |\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
-print(open(os.path.join(P, "%s_summary.md" % tag)).read()[:2500])
+if os.path.exists(os.path.join(P, "%s_kernel_stats.csv" % tag)):   # (a voxel-only set has no headline pass: scripts/gpu_vq_profile.sh)
+    rows = list(csv.DictReader(open(os.path.join(P, "%s_kernel_stats.csv" % tag))))
+    pmc = json.load(open(os.path.join(P, "%s_pmc.json" % tag)))
+    with open(os.path.join(P, "%s_summary.md" % tag), "w") as f:
+        f.write("# %s\n\n" % title)
+        f.write("`rocprofv3 --kernel-trace --stats -- python bench.py --headline-only --steps 30 --warmup 5 --repeats 3` on MI355X: the "
+                "single-view forward + backward step and nothing else (no batched / concurrent / voxelizer / CPU-baseline sections), so "
+                "every row below IS the headline step (full CSV: %s_kernel_stats.csv).  PMC columns: separate rocprofv3 passes over the "
+                "same command, one TCC counter per pass (FETCH_SIZE, WRITE_SIZE; SQ_* in a third), averaged per launch (%s_pmc.json = "
+                "pmc_latest.json, which bench.py reads for `roofline.traffic` when its source hash matches); KB in the json, MB here.  "
+                "Bench lines of the same build: %s_bench.json (default run), %s_bench_driver.json (--steps 20 --warmup 5), "
+                "%s_bench_{B,C,E}.json (BASELINE configs B 50k/512^2, C 300k/560^2, E 1M/1024^2/360 views).\n\n" % (tag, tag, tag, tag, tag))
+        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) |\n|---|---|---|---|---|---|---|\n")
+        for r in rows[:30]:
+            k = short(r['Name']); p = pmc.get(k, {})
+            f.write("| `%s` | %s | %.1f | %s | %s | %s | %s |\n" % (
+                k, r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'],
+                ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
+                ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
+                ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else ""))
+        f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
+                "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  Kernels named "
+                "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
+                "Gaussians, and every 64th call, which refreshes the depth-range hint); `__amd_rocclr_*` are the runtime's fill / copy "
+                "kernels (torch tensor initialisation).  Counters of the single-view step with derived utilisations: "
+                "r03a_single_view_summary.txt (round 3's kernels; the render / geometry-backward kernels are unchanged since).\n")
+        v = os.path.join(P, "%s_voxel256_kernel_stats.csv" % tag)
+        if os.path.exists(v):
+            f.write("\n## Voxelizer alone: 256^3 query of the same cloud (`scripts/voxel_query_only.py 12`)\n\n| kernel | calls | avg us | % |\n|---|---|---|---|\n")
+            for r in list(csv.DictReader(open(v)))[:16]:
+                f.write("| `%s` | %s | %.1f | %s |\n" % (short(r['Name']), r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage']))
+    print(open(os.path.join(P, "%s_summary.md" % tag)).read()[:2500])
 
 
 # ---- the 256^3 voxel query alone (counters of the final voxel kernels)
