@@ -427,6 +427,8 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
     if (tid == 0) chunk_base[T] = carry;
 }
 
+// (Measured and left out, round 4: ONE workgroup for 32768 tiles as well, every thread owning 32 consecutive tiles, two passes over
+// the L2-resident ranges with eight loads in flight -- one launch instead of four, but 45 us slower: 43 k stores through one CU.)
 // many tiles (256^3 volume: 32768): the same in three parallel steps -- per-tile work item counts, their prefix sum
 // (own scan above), then every tile writes its base and its work items
 __global__ void __launch_bounds__(256) work_count_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,

@@ -44,6 +44,10 @@ constexpr int RS_MAX_RADIX = 1 << RS_MAX_BITS;
 constexpr int RS_MAX_PASSES = 4;
 constexpr int RS_SCAN_DIGITS = 32;             // digits per scan workgroup (one 128-byte row segment of H)
 constexpr int RS_SCAN_ROWS = RS_SCAN_THREADS / RS_SCAN_DIGITS;
+#ifndef R2_RS_SCAN_BATCH
+#define R2_RS_SCAN_BATCH 16
+#endif
+constexpr int RS_SCAN_BATCH = R2_RS_SCAN_BATCH;   // tile rows a scan thread requests at once
 
 struct Plan {
     int npass;
@@ -153,8 +157,15 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
     const uint32_t per = (ntiles + RS_SCAN_ROWS - 1) / RS_SCAN_ROWS;
     const uint32_t t0 = row * per, t1 = min(ntiles, t0 + per);
     uint32_t sum = 0;
-    if (d < radix)
-        for (uint32_t t = t0; t < t1; ++t) sum += H[(size_t)t * radix + d];
+    if (d < radix) {   // RS_SCAN_BATCH loads in flight at a time (one load per iteration behind a counted wait was half of this kernel)
+        for (uint32_t t = t0; t < t1; t += RS_SCAN_BATCH) {
+            uint32_t v[RS_SCAN_BATCH];
+#pragma unroll
+            for (int u = 0; u < RS_SCAN_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * radix + d];   // branch-free: clamped
+#pragma unroll
+            for (int u = 0; u < RS_SCAN_BATCH; ++u) sum += (t + (uint32_t)u < t1) ? v[u] : 0u;
+        }
+    }
     part[row][dl] = sum;
     __syncthreads();
     uint32_t run = 0, total = 0;
@@ -165,14 +176,16 @@ __global__ void __launch_bounds__(RS_SCAN_THREADS) rs_scan_kernel(uint32_t *__re
         total += v;
     }
     if (d < radix) {
-        for (uint32_t t = t0; t < t1; t += 8) {   // 8 loads in flight, then the 8 dependent stores
-            uint32_t v[8];
+        for (uint32_t t = t0; t < t1; t += RS_SCAN_BATCH) {   // RS_SCAN_BATCH loads in flight, then the dependent stores
+            uint32_t v[RS_SCAN_BATCH];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (t + u < t1) ? H[(size_t)(t + u) * radix + d] : 0u;
+            for (int u = 0; u < RS_SCAN_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * radix + d];   // branch-free: clamped
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                if (t + u < t1) H[(size_t)(t + u) * radix + d] = run;
-                run += v[u];
+            for (int u = 0; u < RS_SCAN_BATCH; ++u) {
+                if (t + u < t1) {
+                    H[(size_t)(t + u) * radix + d] = run;
+                    run += v[u];
+                }
             }
         }
         if (row == 0) {
