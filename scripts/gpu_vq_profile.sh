@@ -2,7 +2,7 @@
 # kernel stats + TCC / SQ counters of the 256^3 voxel query alone (the voxel part of gpu_profile4.sh): gpurun -- bash scripts/gpu_vq_profile.sh
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-TAG=r04j
+TAG=${1:-r04m}
 mkdir -p gpurun_out/prof gpurun_out/pmc
 VQ="python scripts/voxel_query_only.py 12"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/${TAG}_vox -o vox -- $VQ > /dev/null 2> gpurun_out/prof/rocprof_${TAG}_vox.err
