@@ -52,7 +52,15 @@ extern "C" {
 #define R2_ERR_ALLOC   (-10002) /* an r2_alloc_fn callback returned NULL */
 
 /* Returns a device pointer to at least `bytes` bytes (128-byte aligned), valid until the matching
- * backward call has been enqueued.  `user` is passed through untouched. */
+ * backward call has been enqueued.  `user` is passed through untouched.
+ * The rasterizer forward may call the binning and image callbacks a SECOND time within one call (tile-first chain: the state
+ * was sized by a prediction that fell short and is asked for again with the exact size, see r2_tile_first_control).  Kernels
+ * enqueued on `stream` before the second request still hold pointers into the first buffer (they find the true count on the
+ * device and do nothing, but they do read and write a few words of it), so a callback that releases or reuses the first buffer
+ * must do so IN STREAM ORDER on `stream` -- true of a stream-ordered allocator such as torch's caching allocator on the
+ * current stream, of hipFreeAsync on `stream`, and of a synchronous hipFree; a callback that recycles memory on ANOTHER
+ * stream must keep the first buffer alive until `stream` has passed the forward.  The buffer the backward must be given is the
+ * one returned LAST. */
 typedef char *(*r2_alloc_fn)(size_t bytes, void *user);
 
 R2_API int r2_abi_version(void);
@@ -234,7 +242,15 @@ R2_API int r2_voxel_backward(
     int debug, void *stream);
 
 /* ---- simple-knn ------------------------------------------------------------------------------ */
-/* mean of the 3 smallest squared distances to the other points; out[P].  No workspace needed. */
+/* mean of the 3 smallest squared distances to the other points; out[P].  The exact uniform-grid search (P >= 4096) works inside
+ * a caller-provided workspace of r2_knn_workspace_bytes(P) bytes (any alignment >= 256 B); without one (NULL / too small) the
+ * exhaustive O(P^2) kernel runs, which needs none.  Synchronises the stream twice (bounding box, fullest cell): it is called
+ * once per training run (gaussian_model.py:145-150). */
+R2_API size_t r2_knn_workspace_bytes(int P);
+R2_API int r2_knn_dist2_ws(int P, const float *points /* [P,3] */, float *out /* [P] */, void *workspace, size_t workspace_bytes,
+                           void *stream);
+/* the reference's signature: obtains the workspace itself (hipMalloc; hipFree after waiting for the stream) -- the one entry
+ * point of the library that allocates; callers with an allocator use the two above */
 R2_API int r2_knn_dist2(int P, const float *points /* [P,3] */, float *out /* [P] */, void *stream);
 
 /* ---- measurement: per-stage HIP-event timing on the caller's stream ---------------------------- */
@@ -284,6 +300,18 @@ R2_API void r2_depth_hint_control(int mode);
  * environment variable R2_TILE_FIRST=0 also switches it off), 2: forget the calling thread's predictions (its next call of any
  * size takes the general chain). */
 R2_API void r2_tile_first_control(int mode);
+/* process-wide counts since the last reset: out[0] forwards that took the tile-first chain, [1] forwards that did not (no
+ * prediction yet, or beyond its limits), [2] chains enqueued a second time because the prediction fell short, [3] renders
+ * repeated with the thin-Gaussian variant, [4] forwards whose prediction was seeded from another Gaussian count (the call after
+ * a densification).  out may be NULL (reset only). */
+R2_API void r2_tile_first_stats(long long out[5], int reset);
+
+/* Per-thread state.  The library keeps a few KB per host thread: self-resetting device counters of the tile-first rasterizer chain
+ * and of the small-grid voxelizer path (one block per (device, stream) the thread has used, at most 16 of each: the least
+ * recently used one is evicted), 128 bytes of pinned host memory for the num_rendered read-back, and the thread's predictions.
+ * These -- and the convenience form r2_knn_dist2 -- are the only memory the library obtains itself; all of it is released when the
+ * thread exits, or earlier by this call (waits for the device; the thread's next forward starts over). */
+R2_API void r2_thread_release(void);
 
 /* ---- introspection used by the parity tests (bit-exact tile / sort indices) ------------------- */
 /* Byte offsets of the private arrays inside the state buffers of a forward call with the given sizes; lets

@@ -425,7 +425,11 @@ def distCUDA2(points):
     P = points.shape[0]
     out = torch.zeros((P,), dtype=_F32, device=dev)
     if P != 0:
+        L = _lib.lib()
+        # the library does not allocate: the grid search's workspace comes from torch's allocator (r2hip.h)
+        nbytes = int(L.r2_knn_workspace_bytes(P))
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         with _on_device(dev):
-            rc = _lib.lib().r2_knn_dist2(P, _ptr(pts), out.data_ptr(), _stream(dev))
-        _lib.check(rc, "r2_knn_dist2")
+            rc = L.r2_knn_dist2_ws(P, _ptr(pts), out.data_ptr(), ws.data_ptr(), nbytes, _stream(dev))
+        _lib.check(rc, "r2_knn_dist2_ws")
     return out

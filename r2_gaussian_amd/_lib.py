@@ -35,6 +35,10 @@ _SIGNATURES = {
     "r2_voxel_backward": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _fp, _f, _fp, _fp, _p, _p, _p,
                                     _p, _p, _p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _p]),
     "r2_knn_dist2": (C.c_int, [_i, _fp, _fp, _p]),
+    "r2_knn_workspace_bytes": (C.c_size_t, [_i]),
+    "r2_knn_dist2_ws": (C.c_int, [_i, _fp, _fp, _p, C.c_size_t, _p]),
+    "r2_tile_first_stats": (None, [C.POINTER(C.c_longlong), _i]),
+    "r2_thread_release": (None, []),
     "r2_densify_stats": (C.c_int, [_i, _p, _fp, _fp, _fp, _fp, _p]),
     "r2_densify_scratch_bytes": (C.c_size_t, [_i]),
     "r2_densify_classify": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _f, _f, _p, _p, _p]),

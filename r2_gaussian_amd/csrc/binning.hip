@@ -76,7 +76,14 @@ void host_mark_forward_end()
 // pinned destination (pageable ones are staged and synchronised by the runtime) and a busy-wait on an event: the GPU is
 // idle until the host has seen these words and launched the rest of the forward pass, so wake-up latency is on the
 // critical path -- a blocking hipStreamSynchronize may sleep on an interrupt (tens of microseconds)
-static thread_local uint32_t *g_pinned = nullptr;
+// pinned host words of the calling thread (the device -> host read-back and the mailbox below): released when the thread exits
+struct PinnedWords {
+    uint32_t *p = nullptr;
+    void release() { if (p) { if (hipHostFree(p) != hipSuccess) (void)hipGetLastError(); p = nullptr; } }
+    ~PinnedWords() { release(); }
+};
+static thread_local PinnedWords g_pinned_holder, g_mailbox_holder;
+#define g_pinned g_pinned_holder.p
 // one event per device: an event can only be recorded on a stream of the device it was created on, and one host thread may
 // drive several GPUs (the caller makes the stream's device current, like every HIP API that takes a stream)
 constexpr int MAX_DEVICES = R2_MAX_DEVICES;
@@ -166,7 +173,7 @@ int read_host_words_wait(uint32_t *out, int n)
 // Zero-copy variant for the hinted forward path: the kernel that produces the last of the words stores them, then a
 // sequence number (release, system scope), straight into pinned host memory, and the host spins on the sequence number.
 // No copy kernel (4 us of stream time on this runtime + a ~5 us signalling gap behind it) and no event.
-static thread_local uint32_t *g_mailbox = nullptr;   // [16]: words 0..14, sequence number at 15
+#define g_mailbox g_mailbox_holder.p   // [16]: words 0..14, sequence number at 15
 static thread_local uint32_t g_mailbox_seq = 0;
 
 int host_mailbox_arm(uint32_t **mailbox, uint32_t *seq)
@@ -181,6 +188,8 @@ int host_mailbox_arm(uint32_t **mailbox, uint32_t *seq)
     *seq = g_mailbox_seq;
     return 0;
 }
+
+void host_words_release() { g_pinned_holder.release(); g_mailbox_holder.release(); }
 
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
 {

@@ -119,6 +119,17 @@ __global__ void __launch_bounds__(256) knn_count_kernel(int P, const float *__re
     atomicAdd(&count[((size_t)c.z * g.gy + c.y) * g.gx + c.x], 1u);
 }
 
+// the fullest cell (one word, zeroed with the counters): a clustered cloud defeats the grid -- every query of a cell holding
+// O(P) points scans all of them, one lane per query -- and is handed to the exhaustive kernel instead
+__global__ void __launch_bounds__(256) knn_maxcount_kernel(size_t cells, const uint32_t *__restrict__ count, uint32_t *__restrict__ out)
+{
+    uint32_t m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < cells; i += (size_t)gridDim.x * 256) m = max(m, count[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = max(m, (uint32_t)__shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // sorted[pos] = {x, y, z, bits(original index)}; start[c] = exclusive prefix of the counts (incl[c - 1]), cursor starts at 0
 __global__ void __launch_bounds__(256) knn_scatter_kernel(int P, const float *__restrict__ pts, KnnGrid g, const uint32_t *__restrict__ incl,
                                                           uint32_t *__restrict__ cursor, float4 *__restrict__ sorted)
@@ -179,42 +190,74 @@ __global__ void __launch_bounds__(256) knn_query_kernel(int P, KnnGrid g, const 
                     }
                 }
             }
-        // everything inside the block of cells [c - r, c + r]^3 has been seen; whatever lies outside is at least `reach` away
-        // (sides where the block already touches the grid's border hold nothing).  Shrunk a little against the rounding of the
-        // cell assignment.
+        // everything inside the block of cells [c - r, c + r]^3 has been seen (sides where the block already touches the grid's
+        // border hold nothing).  How far away is whatever lies outside?  Derived from the cell function itself, not from the
+        // nominal cell walls: a point p in a cell >= K along x satisfies fl(fl(p.x - ox) * inv_h) >= K, hence (two roundings,
+        // each relative to its own result) p.x - ox >= K / inv_h * (1 - 3 * 2^-24) in exact arithmetic, wherever the cloud sits
+        // and however many cells the axis has; a point in a cell <= K' satisfies p.x - ox < (K' + 1) / inv_h * (1 + 3 * 2^-24).
+        // Evaluated in double (round 4 used the float walls shrunk by an ad hoc margin, which an elongated cloud of hundreds
+        // of cells or a cloud far from the origin could exhaust: ADVICE r4).
         const bool all = x0 == 0 && y0 == 0 && z0 == 0 && x1 == g.gx - 1 && y1 == g.gy - 1 && z1 == g.gz - 1;
         if (all) break;
-        float reach = FLT_MAX;
-        if (c.x - r > 0) reach = fminf(reach, q.x - (g.ox + (float)(c.x - r) * g.h));
-        if (c.x + r < g.gx - 1) reach = fminf(reach, (g.ox + (float)(c.x + r + 1) * g.h) - q.x);
-        if (c.y - r > 0) reach = fminf(reach, q.y - (g.oy + (float)(c.y - r) * g.h));
-        if (c.y + r < g.gy - 1) reach = fminf(reach, (g.oy + (float)(c.y + r + 1) * g.h) - q.y);
-        if (c.z - r > 0) reach = fminf(reach, q.z - (g.oz + (float)(c.z - r) * g.h));
-        if (c.z + r < g.gz - 1) reach = fminf(reach, (g.oz + (float)(c.z + r + 1) * g.h) - q.z);
-        reach = reach * 0.9999f - 1.0e-4f * g.h;
-        if (reach > 0.f && b2 <= reach * reach) break;
+        constexpr double EPS3 = 3.0 / 16777216.0;
+        const double ih = 1.0 / (double)g.inv_h;
+        double reach = 1.0e300;
+        if (c.x - r > 0) reach = fmin(reach, ((double)q.x - (double)g.ox) - (double)(c.x - r) * ih * (1.0 + EPS3));
+        if (c.x + r < g.gx - 1) reach = fmin(reach, (double)(c.x + r + 1) * ih * (1.0 - EPS3) - ((double)q.x - (double)g.ox));
+        if (c.y - r > 0) reach = fmin(reach, ((double)q.y - (double)g.oy) - (double)(c.y - r) * ih * (1.0 + EPS3));
+        if (c.y + r < g.gy - 1) reach = fmin(reach, (double)(c.y + r + 1) * ih * (1.0 - EPS3) - ((double)q.y - (double)g.oy));
+        if (c.z - r > 0) reach = fmin(reach, ((double)q.z - (double)g.oz) - (double)(c.z - r) * ih * (1.0 + EPS3));
+        if (c.z + r < g.gz - 1) reach = fmin(reach, (double)(c.z + r + 1) * ih * (1.0 - EPS3) - ((double)q.z - (double)g.oz));
+        // an unseen point's float distance (three squares and two sums, each rounded) is >= its true one * (1 - 2^-21): it cannot
+        // displace b2, and the 3-best multiset is the exhaustive search's
+        if (reach > 0.0 && (double)b2 <= reach * reach * (1.0 - 1.0e-6)) break;
     }
     out[self] = (b0 + b1 + b2) / 3.0f;
 }
 
 }  // namespace r2
 
-// -> 0, or a negative error code; KNN_GRID_NOT_TAKEN: run the exhaustive kernel (tiny inputs, degenerate boxes, no memory)
-static int knn_grid(int P, const float *points, float *out, hipStream_t s)
+// ---- host side.  The library does not allocate (include/r2hip.h): the grid search works inside a caller-provided workspace of
+// r2_knn_workspace_bytes(P) bytes -- bounding-box partials, cell counters / cursors / prefix, scan temp, the points sorted by
+// cell -- sized for the most cells the grid is allowed to have (2 P + 4096: the cell size is grown until it fits).
+namespace {
+constexpr int KNN_BBOX_BLOCKS = 256;
+constexpr int KNN_GRID_MIN_POINTS = 4096;
+inline size_t knn_align(size_t b) { return (b + 255) & ~(size_t)255; }
+inline size_t knn_max_cells(int P) { return 2 * (size_t)P + 4096; }
+struct KnnWs { size_t off_bbox, off_cnt, off_cur, off_max, off_incl, off_tmp, off_sorted, total, tmp_bytes; };
+KnnWs knn_ws_layout(int P)
+{
+    KnnWs w;
+    const size_t cb = knn_align(knn_max_cells(P) * 4);
+    w.tmp_bytes = r2::scan_temp_bytes((int)knn_max_cells(P));
+    w.off_bbox = 0;
+    w.off_cnt = knn_align(sizeof(float) * 6 * KNN_BBOX_BLOCKS);
+    w.off_cur = w.off_cnt + cb;
+    w.off_max = w.off_cur + cb;           // (counters, cursors and this word are zeroed by one fill)
+    w.off_incl = w.off_max + 256;
+    w.off_tmp = w.off_incl + cb;
+    w.off_sorted = w.off_tmp + knn_align(w.tmp_bytes);
+    w.total = w.off_sorted + (size_t)P * sizeof(float4);
+    return w;
+}
+}  // namespace
+
+// -> 0, or a negative error code; 1 = not taken: run the exhaustive kernel (tiny inputs, degenerate boxes, clustered clouds)
+static int knn_grid(int P, const float *points, float *out, char *ws, hipStream_t s)
 {
     using namespace r2;
     constexpr int NOT_TAKEN = 1;
     static const bool on = [] { const char *e = getenv("R2_KNN_GRID"); return !(e && e[0] == '0'); }();
-    if (!on || P < 4096) return NOT_TAKEN;
+    if (!on || P < KNN_GRID_MIN_POINTS) return NOT_TAKEN;
+    const KnnWs L = knn_ws_layout(P);
     // ---- bounding box (one small read-back: this call runs once per training run)
-    const int nb = 256;
-    float *partial = nullptr;
-    if (hipMalloc(reinterpret_cast<void **>(&partial), sizeof(float) * 6 * nb) != hipSuccess) { (void)hipGetLastError(); return NOT_TAKEN; }
+    const int nb = KNN_BBOX_BLOCKS;
+    float *partial = reinterpret_cast<float *>(ws + L.off_bbox);
     knn_bbox_kernel<<<dim3(nb), dim3(256), 0, s>>>(P, points, partial);
     float hp[6 * nb];
     hipError_t e = hipMemcpyAsync(hp, partial, sizeof(hp), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(partial);
     if (e != hipSuccess) { set_error("r2_knn_dist2: %s", hipGetErrorString(e)); return -(int)e; }
     float lo[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, hi[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
     for (int b = 0; b < nb; ++b)
@@ -230,46 +273,49 @@ static int knn_grid(int P, const float *points, float *out, hipStream_t s)
     const double emax = std::max(ext[0], std::max(ext[1], ext[2]));
     if (!(emax > 0.0)) return NOT_TAKEN;   // all points identical
     for (int a = 0; a < 3; ++a) vol *= std::max(ext[a], emax * 1e-3);   // flat clouds: a thin slab of cells
-    // ~2 points per cell; at most 512 cells per axis and 2^25 cells in all
+    // ~2 points per cell; at most 512 cells per axis and as many cells as the workspace was sized for
     double h = std::cbrt(vol / (0.5 * (double)P));
     h = std::max(h, emax / 512.0);
     KnnGrid g;
+    size_t cells = 0;
+    for (int it = 0; it < 64; ++it, h *= 1.1) {
+        g.gx = std::max(1, (int)std::ceil(ext[0] / h)); g.gy = std::max(1, (int)std::ceil(ext[1] / h)); g.gz = std::max(1, (int)std::ceil(ext[2] / h));
+        cells = (size_t)g.gx * g.gy * g.gz;
+        if (cells <= knn_max_cells(P)) break;
+    }
+    if (cells > knn_max_cells(P)) return NOT_TAKEN;
     g.ox = lo[0]; g.oy = lo[1]; g.oz = lo[2];
     g.h = (float)h;
     g.inv_h = (float)(1.0 / h);
-    g.gx = std::max(1, (int)std::ceil(ext[0] / h)); g.gy = std::max(1, (int)std::ceil(ext[1] / h)); g.gz = std::max(1, (int)std::ceil(ext[2] / h));
-    const size_t cells = (size_t)g.gx * g.gy * g.gz;
-    if (cells > ((size_t)1 << 25)) return NOT_TAKEN;
-    // ---- workspace: counts / inclusive prefix, cursors, scan temp, sorted points
-    const size_t tb = scan_temp_bytes((int)cells);
-    char *ws = nullptr;
-    const size_t cb = (cells * 4 + 255) & ~(size_t)255;
-    const size_t off_cnt = 0, off_cur = cb, off_incl = 2 * cb, off_tmp = 3 * cb, off_sorted = off_tmp + ((tb + 255) & ~(size_t)255),
-                 total = off_sorted + (size_t)P * sizeof(float4);
-    if (hipMalloc(reinterpret_cast<void **>(&ws), total) != hipSuccess) { (void)hipGetLastError(); return NOT_TAKEN; }
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(ws + off_cnt), *cur = reinterpret_cast<uint32_t *>(ws + off_cur),
-             *incl = reinterpret_cast<uint32_t *>(ws + off_incl);
-    float4 *sorted = reinterpret_cast<float4 *>(ws + off_sorted);
-    int rc = 0;
-    e = hipMemsetAsync(ws, 0, off_incl, s);   // counts and cursors
-    if (e == hipSuccess) {
-        const unsigned blocks = (unsigned)((P + 255) / 256);
-        knn_count_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, points, g, cnt);
-        rc = inclusive_scan_u32(ws + off_tmp, tb, cnt, incl, (int)cells, s);
-        if (!rc) {
-            knn_scatter_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, points, g, incl, cur, sorted);
-            knn_query_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, g, incl, sorted, out);
-            e = hipGetLastError();
-        }
-    }
-    if (e == hipSuccess) e = hipStreamSynchronize(s);   // the workspace is freed below
-    (void)hipFree(ws);
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(ws + L.off_cnt), *cur = reinterpret_cast<uint32_t *>(ws + L.off_cur),
+             *mx = reinterpret_cast<uint32_t *>(ws + L.off_max), *incl = reinterpret_cast<uint32_t *>(ws + L.off_incl);
+    float4 *sorted = reinterpret_cast<float4 *>(ws + L.off_sorted);
+    e = hipMemsetAsync(ws + L.off_cnt, 0, L.off_incl - L.off_cnt, s);   // counts, cursors, the maximum
+    if (e != hipSuccess) { set_error("r2_knn_dist2: %s", hipGetErrorString(e)); return -(int)e; }
+    const unsigned blocks = (unsigned)((P + 255) / 256);
+    knn_count_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, points, g, cnt);
+    knn_maxcount_kernel<<<dim3((unsigned)std::min<size_t>((cells + 255) / 256, 1024)), dim3(256), 0, s>>>(cells, cnt, mx);
+    uint32_t fullest = 0;
+    e = hipMemcpyAsync(&fullest, mx, sizeof(fullest), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) { set_error("r2_knn_dist2: %s", hipGetErrorString(e)); return -(int)e; }
+    // a query scans ~27 cells, one lane per query; the exhaustive kernel pays P pairs per query but ~10x faster per pair
+    if ((size_t)fullest > std::max<size_t>(256, (size_t)P / 256)) return NOT_TAKEN;
+    const int rc = inclusive_scan_u32(ws + L.off_tmp, L.tmp_bytes, cnt, incl, (int)cells, s);
     if (rc) return rc;
+    knn_scatter_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, points, g, incl, cur, sorted);
+    knn_query_kernel<<<dim3(blocks), dim3(256), 0, s>>>(P, g, incl, sorted, out);
+    e = hipGetLastError();
     if (e != hipSuccess) { set_error("r2_knn_dist2: %s", hipGetErrorString(e)); return -(int)e; }
     return 0;
 }
 
-extern "C" int r2_knn_dist2(int P, const float *points, float *out, void *stream)
+extern "C" size_t r2_knn_workspace_bytes(int P)
+{
+    return P >= KNN_GRID_MIN_POINTS ? knn_ws_layout(P).total : 256;
+}
+
+extern "C" int r2_knn_dist2_ws(int P, const float *points, float *out, void *workspace, size_t workspace_bytes, void *stream)
 {
     if (P == 0) return 0;
     if (P < 0 || !points || !out) {
@@ -277,9 +323,26 @@ extern "C" int r2_knn_dist2(int P, const float *points, float *out, void *stream
         return R2_ERR_INVALID;
     }
     { r2::StageScope t(r2::ST_KNN, (hipStream_t)stream);
-    const int g = knn_grid(P, points, out, (hipStream_t)stream);
+    int g = 1;
+    if (workspace != nullptr && workspace_bytes >= r2_knn_workspace_bytes(P))
+        g = knn_grid(P, points, out, static_cast<char *>(workspace), (hipStream_t)stream);
     if (g <= 0) return g;
     r2::knn_dist2_kernel<<<dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(P, points, out); }
     R2_STAGE_CHECK(0, (hipStream_t)stream, "knn");
     return 0;
+}
+
+// convenience form (the reference's signature): obtains the workspace itself -- hipMalloc, and hipFree after waiting for the
+// stream.  Callers that own an allocator (the torch boundary does) use r2_knn_workspace_bytes + r2_knn_dist2_ws.
+extern "C" int r2_knn_dist2(int P, const float *points, float *out, void *stream)
+{
+    void *ws = nullptr;
+    const size_t bytes = P > 0 ? r2_knn_workspace_bytes(P) : 0;
+    if (P >= KNN_GRID_MIN_POINTS && hipMalloc(&ws, bytes) != hipSuccess) { (void)hipGetLastError(); ws = nullptr; }
+    const int rc = r2_knn_dist2_ws(P, points, out, ws, ws ? bytes : 0, stream);
+    if (ws) {
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        (void)hipFree(ws);
+    }
+    return rc;
 }

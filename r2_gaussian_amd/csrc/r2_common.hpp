@@ -257,6 +257,7 @@ void host_mark_forward_begin();
 void host_mark_forward_end();
 int host_mailbox_arm(uint32_t **mailbox /* device-visible pinned host memory, 16 words */, uint32_t *seq);
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s);
+void host_words_release();   // the calling thread's pinned words (r2_thread_release; also at thread exit)
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s, bool ranges_zeroed = false);

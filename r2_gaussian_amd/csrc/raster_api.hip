@@ -1,6 +1,7 @@
 // raster_api.hip -- extern "C" entry points of the rasterizer (see include/r2hip.h).
 // Host orchestration of Rasterizer::forward / backward (RAS/rasterizer_impl.cu:196-421).
 #include "raster_state.hpp"
+#include "voxel_state.hpp"
 
 using namespace r2;
 
@@ -324,4 +325,15 @@ extern "C" long long r2_raster_state_offset(int which, int P, long long R, int w
     }
     if (buffer_id) *buffer_id = buf;
     return (long long)(p - base);
+}
+
+// Everything the library keeps per host thread -- the self-resetting counter blocks of the tile-first rasterizer chain and of the
+// small-grid voxelizer path (a few KB of device memory per (device, stream) the thread has used), its pinned mailbox words, its
+// predictions -- is released when the thread exits; a long-lived thread can give it back earlier with this call.  Waits for
+// the device (hipFree).  The next forward of the thread simply starts over.
+extern "C" void r2_thread_release(void)
+{
+    r2::raster_tilefirst_release();
+    r2::voxel_small_release();
+    r2::host_words_release();
 }

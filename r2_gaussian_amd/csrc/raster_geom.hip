@@ -183,140 +183,126 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     R2_TS_AT(geom, 2);
 }
 
-// ---- tile-first binning (round 4; raster_tilefirst.hip has the rest of the chain and the rationale).  The same per-Gaussian
+// ---- tile-first binning (rounds 4-5; raster_tilefirst.hip has the rest of the chain and the rationale).  The same per-Gaussian
 // work as above, without the depth-bucket registration; instead the workgroup
 //   * counts its instances per tile in an LDS histogram (one LDS atomic per instance) and adds every non-zero count to the
-//     global per-tile counter with ONE returning atomic per (workgroup, tile) -- the returned value is where this workgroup's
-//     instances start inside that tile's list, kept in tf_wgoff[workgroup][tile] for the scatter kernel;
+//     global per-tile counter with ONE returning atomic per (workgroup, tile) it touches -- the returned value is where this
+//     workgroup's instances start inside that tile's list, kept in tf_wgoff[workgroup][tile] for the scatter kernel;
 //   * hands every visible Gaussian its run of backward scratch rows: a workgroup scan of tiles_touched + one returning 64-bit
-//     atomic {visible << 32 | instances} for the workgroup's base (any disjoint assignment serves the backward);
-//   * the LAST workgroup to finish posts the totals to the state's host words and to the host mailbox, and zeroes the
-//     scalar counters for the next call (the per-tile counters are zeroed by their last reader, the sort kernel).
-__global__ void __launch_bounds__(TF_WG) raster_preprocess_tf_kernel(
-    int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+//     atomic {visible << 40 | instances} for the workgroup's base (any disjoint assignment serves the backward);
+//   * leaves its key range in its slot of tf_wgmm.
+// Round 5: (1) no epilogue.  Round 4's last workgroup to finish (a `done` counter behind s_waitcnt vmcnt(0)) reduced the key
+// ranges and posted the totals to the host: 4.1 us between the end of the slowest workgroup and the end of the kernel, on the
+// critical path of everything (stamps: profiles/experiments/r05_round4_chain_stamps.txt).  The totals now simply stay in the
+// counters and workgroup 0 of the NEXT kernel -- which starts when this one has drained anyway -- posts them.  (2) the Gaussians
+// are dealt evenly to one workgroup per CU (tf_grid): a thread owns up to TF_PER_THREAD_MAX of them.
+__global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
+    int P, uint32_t per_wg, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
     int *__restrict__ radii, float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
     float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float2 *__restrict__ op_mu,
     uint32_t *__restrict__ first, uint32_t *__restrict__ rects, uint32_t *__restrict__ wgoff, uint32_t *__restrict__ wgmm,
-    TFCounters *__restrict__ ctr, uint32_t *__restrict__ words, uint32_t *__restrict__ mailbox, uint32_t seq)
+    TFCounters *__restrict__ ctr)
 {
     extern __shared__ uint32_t tf_hist[];   // [T]
-    constexpr int NW = TF_WG / 64;
-    __shared__ uint32_t s_wn[NW], s_wv[NW], s_kmx[NW], s_nkmn[NW], s_thin, s_base, s_last;
+    constexpr int MAXW = (int)(TF_THREADS_MAX / 64), NI = (int)TF_PER_THREAD_MAX;
+    __shared__ uint32_t s_wn[NI][MAXW], s_wv[MAXW], s_kmx[MAXW], s_nkmn[MAXW], s_thin, s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int idx = blockIdx.x * TF_WG + tid;
+    const uint32_t NT = blockDim.x;
+    const int nw = (int)(NT >> 6);
     const uint32_t T = (uint32_t)(gx * gy);
+    const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);   // this workgroup's Gaussians
     R2_TS_AT(geom, 0);
-    for (uint32_t t = tid; t < T; t += (uint32_t)TF_WG) tf_hist[t] = 0u;
+    for (uint32_t t = tid; t < T; t += NT) tf_hist[t] = 0u;
     if (tid == 0) s_thin = 0u;
-    uint32_t key = DEPTH_CULLED_KEY, rect = 0u, thin = 0u;
-    uint2 bt = make_uint2(0u, 0u);
+    uint32_t key[NI], rect[NI], thin = 0u;
     const DepthReg noreg{};
-    if (idx < P)
-        raster_preprocess_one(idx, idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H,
-                              tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds, tiles_touched, op_mu,
-                              &thin, noreg, key, bt, rect);
-    const bool vis = key != DEPTH_CULLED_KEY;
-    const uint32_t n = vis ? depth_rect_count(rect) : 0u;
-    __syncthreads();                           // the histogram is clear
-    if (vis) {
-        const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
-        for (uint32_t r = 0; r < h; ++r) {
-            const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
-            for (uint32_t c = 0; c < w; ++c) atomicAdd(&tf_hist[row + c], 1u);
-        }
-        rects[idx] = rect;
-    }
-    // the workgroup's instances and visible Gaussians; exclusive prefix of n inside the workgroup
-    uint32_t incl = n;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d);
-        if (lane >= d) incl += up;
+    for (int it = 0; it < NI; ++it) {
+        key[it] = DEPTH_CULLED_KEY; rect[it] = 0u;
+        const uint32_t idx = g0 + (uint32_t)it * NT + (uint32_t)tid;
+        uint2 bt = make_uint2(0u, 0u);
+        if ((it == 0 || NT * (uint32_t)it < per_wg) && idx < g1)   // (workgroup-uniform first half: no second round for small workgroups)
+            raster_preprocess_one((int)idx, (int)idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W,
+                                  H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds, tiles_touched,
+                                  op_mu, &thin, noreg, key[it], bt, rect[it]);
     }
-    const unsigned long long vm = __ballot(vis);
+    R2_TS_AT(geom, 10);
+    __syncthreads();                           // the histogram is clear
+    uint32_t n[NI], incl[NI], nvis = 0u, kmx = 0u, nkmn = 0u;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        const bool vis = key[it] != DEPTH_CULLED_KEY;
+        n[it] = vis ? depth_rect_count(rect[it]) : 0u;
+        if (vis) {
+            const uint32_t x0 = rect[it] & 0xFFu, y0 = (rect[it] >> 8) & 0xFFu, w = ((rect[it] >> 16) & 0xFFu) + 1u, h = (rect[it] >> 24) + 1u;
+            for (uint32_t r = 0; r < h; ++r) {
+                const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
+                for (uint32_t c = 0; c < w; ++c) atomicAdd(&tf_hist[row + c], 1u);
+            }
+            rects[g0 + (uint32_t)it * NT + (uint32_t)tid] = rect[it];
+            kmx = max(kmx, key[it]);
+            nkmn = max(nkmn, ~key[it]);
+        }
+        // exclusive prefix of n inside the workgroup, in (round, thread) order
+        incl[it] = n[it];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl[it], d);
+            if (lane >= d) incl[it] += up;
+        }
+        nvis += (uint32_t)__popcll(__ballot(vis));
+        if (lane == 63) s_wn[it][wave] = incl[it];
+    }
     // key range of the call (the sort kernel's depth histograms are laid over it)
-    uint32_t kmx = vis ? key : 0u, nkmn = vis ? ~key : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         kmx = max(kmx, (uint32_t)__shfl_xor(kmx, d));
         nkmn = max(nkmn, (uint32_t)__shfl_xor(nkmn, d));
     }
-    if (lane == 63) { s_wn[wave] = incl; s_wv[wave] = (uint32_t)__popcll(vm); s_kmx[wave] = kmx; s_nkmn[wave] = nkmn; }
+    if (lane == 63) { s_wv[wave] = nvis; s_kmx[wave] = kmx; s_nkmn[wave] = nkmn; }
     if (__any(thin != 0u) && lane == 0) s_thin = 1u;   // benign race: everybody stores 1
+    R2_TS_AT(geom, 11);
     __syncthreads();                           // the histogram is complete; wave sums are in place
-    uint32_t before = 0, tn = 0, tv = 0;
+    R2_TS_AT(geom, 12);
+    uint32_t before[NI], tn = 0, tv = 0;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) {
-        if (q < wave) before += s_wn[q];
-        tn += s_wn[q];
-        tv += s_wv[q];
+    for (int it = 0; it < NI; ++it) {
+        before[it] = tn;                       // everything of the earlier rounds ...
+        for (int q = 0; q < nw; ++q) {
+            if (q < wave) before[it] += s_wn[it][q];   // ... and the earlier waves of this one
+            tn += s_wn[it][q];
+        }
     }
+    for (int q = 0; q < nw; ++q) tv += s_wv[q];
     unsigned long long base_old = 0ull;
     if (tid == 0) {
         // (its result is consumed at the very end: the round trip of this same-address atomic -- every workgroup bumps it --
         // runs behind the per-tile atomics below)
         base_old = atomicAdd(&ctr->total, ((unsigned long long)tv << 40) | (unsigned long long)tn);
         if (s_thin) __hip_atomic_store(&ctr->thin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // the workgroup's key range: one slot per workgroup, reduced by the last one (atomicMax on ONE word from every
+        // the workgroup's key range: one slot per workgroup, reduced by the next kernel (atomicMax on ONE word from every
         // workgroup was measured: +5 us on the kernel, same-address atomics retire at ~90 per microsecond)
         uint32_t a = 0u, b = 0u;
-#pragma unroll
-        for (int q = 0; q < NW; ++q) { a = max(a, s_kmx[q]); b = max(b, s_nkmn[q]); }
-        __hip_atomic_store(&wgmm[2u * blockIdx.x], a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&wgmm[2u * blockIdx.x + 1u], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = 0; q < nw; ++q) { a = max(a, s_kmx[q]); b = max(b, s_nkmn[q]); }
+        wgmm[2u * blockIdx.x] = a;
+        wgmm[2u * blockIdx.x + 1u] = b;
     }
     // one returning atomic per tile this workgroup touches: where its instances start inside the tile's list
     uint32_t *__restrict__ my_off = wgoff + (size_t)blockIdx.x * T;
-    for (uint32_t t = tid; t < T; t += (uint32_t)TF_WG) {
+    for (uint32_t t = tid; t < T; t += NT) {
         const uint32_t c = tf_hist[t];
         if (c) my_off[t] = atomicAdd(&ctr->tile_count[t], c);
     }
+    R2_TS_AT(geom, 13);
     if (tid == 0) s_base = (uint32_t)base_old;
     __syncthreads();
-    if (vis) first[idx] = s_base + before + incl - n;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+        if (key[it] != DEPTH_CULLED_KEY) first[g0 + (uint32_t)it * NT + (uint32_t)tid] = s_base + before[it] + incl[it] - n[it];
     R2_TS_AT(geom, 1);
-    // ---- the last workgroup to get here posts the totals
-    if (tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this workgroup's atomics have been acknowledged
-        s_last = (atomicAdd(&ctr->done, 1u) == gridDim.x - 1u) ? 1u : 0u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // key range of the call: max over the workgroups' slots (all 1024 threads of this workgroup)
-    uint32_t gkmax = 0u, gnkmin = 0u;
-    for (uint32_t b = tid; b < gridDim.x; b += (uint32_t)TF_WG) {
-        gkmax = max(gkmax, __hip_atomic_load(&wgmm[2u * b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        gnkmin = max(gnkmin, __hip_atomic_load(&wgmm[2u * b + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        gkmax = max(gkmax, (uint32_t)__shfl_xor(gkmax, d));
-        gnkmin = max(gnkmin, (uint32_t)__shfl_xor(gnkmin, d));
-    }
-    __syncthreads();
-    if (lane == 0) { s_kmx[wave] = gkmax; s_nkmn[wave] = gnkmin; }
-    __syncthreads();
-    if (tid != 0) return;
-#pragma unroll
-    for (int q = 0; q < NW; ++q) { gkmax = max(gkmax, s_kmx[q]); gnkmin = max(gnkmin, s_nkmn[q]); }
-    const unsigned long long tot = atomicAdd(&ctr->total, 0ull);
-    // 40 bits of instances (P < 2^24 Gaussians of <= 2^16 tiles each), 24 of visible Gaussians; a total beyond the 31-bit
-    // num_rendered of the API reaches the host as an out-of-range word, which it rejects
-    const unsigned long long inst = tot & ((1ull << 40) - 1ull);
-    const uint32_t R = inst > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)inst, nvis = (uint32_t)(tot >> 40);
-    const uint32_t any_thin = __hip_atomic_load(&ctr->thin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ctr->total, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ctr->done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(&ctr->thin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = any_thin; words[DW_PMAX] = TF_MARK;
-    words[DW_PNMAX] = 0u; words[DW_NMAX] = gkmax; words[DW_NNMAX] = gnkmin; words[DW_NVIS] = nvis;
-    mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = any_thin; mailbox[DW_PMAX] = TF_MARK;
-    mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = gkmax; mailbox[DW_NNMAX] = gnkmin; mailbox[DW_NVIS] = nvis;
-    __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    R2_TS_AT(geom, 2);
 }
 
 // z_view > 0.2 mask (RAS/rasterizer_impl.cu:54-66)
@@ -811,18 +797,18 @@ int launch_raster_preprocess(const RasterGeom &g, int P, int V, const float *mea
     return 0;
 }
 
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
-                                const float *rotations, const float *opacities, const float *cov3D_precomp, const float *view,
-                                const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode, int *radii,
-                                TFCounters *ctr, uint32_t *mailbox, uint32_t seq, hipStream_t s)
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const float *means3D, const float *scales,
+                                float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
+                                const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
+                                int *radii, TFCounters *ctr, hipStream_t s)
 {
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    raster_preprocess_tf_kernel<<<dim3((unsigned)((P + TF_WG - 1) / TF_WG)), dim3(TF_WG), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, focal_x,
-        focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff, g.tf_wgmm,
-        ctr, g.host_words, mailbox, seq);
+    raster_preprocess_tf_kernel<<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * sizeof(uint32_t), s>>>(
+        P, grid.per_wg, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,
+        g.tf_wgmm, ctr);
     return 0;
 }
 

@@ -75,12 +75,28 @@ __device__ __forceinline__ bool block_live(float px, float py, float hx, float h
 // of the (entry, block) pairs -- was built and measured in round 2: parity green, forward 47.5 -> 50.9 us (the test costs more
 // than the dropped entries save), backward unchanged (its rounds are quantised: 118 or 104 items per chunk are both 2 rounds).)
 
-#ifndef R2_EXP_TF_WG
-#define R2_EXP_TF_WG 1024
-#endif
-constexpr int TF_WG = R2_EXP_TF_WG;                 // tile-first: Gaussians per producer workgroup (preprocess and scatter share the mapping);
-                                            // large, so that few workgroups bump the same tile counter (same-address atomics
-                                            // retire at ~90 per microsecond device-wide) and the scatter's per-workgroup scan amortises
+// tile-first: how the Gaussians are dealt to the producer workgroups (the preprocess and the scatter kernel share the mapping:
+// workgroup w owns Gaussians [w * per_wg, (w + 1) * per_wg), thread t of it the Gaussians t, t + threads, ... of that range).
+// Round 4 used 1024 Gaussians = 1024 threads per workgroup whatever P: 300k Gaussians were 294 workgroups on 256 CUs, 38 CUs ran
+// two of them and the kernel ended when THEY did (in-kernel stamps: median workgroup 12.3 us, slowest 19.1 us); 50k Gaussians were
+// 49 workgroups on 256 CUs.  Now the grid is a whole number of workgroups per CU -- one per CU (up to 2048 Gaussians each, two
+// per thread) where that is enough -- and small clouds get more, smaller workgroups.  Few workgroups also means few same-address
+// atomics per tile counter (they retire at ~90 per microsecond device-wide).
+constexpr uint32_t TF_THREADS_MAX = 1024, TF_PER_THREAD_MAX = 2, TF_PER_WG_MIN = 256;
+struct TFGrid { uint32_t wgs, per_wg, threads; };
+inline TFGrid tf_grid(int P, int cus)
+{
+    const unsigned long long cap = (unsigned long long)TF_THREADS_MAX * TF_PER_THREAD_MAX, c = (unsigned long long)(cus > 0 ? cus : 1);
+    const unsigned long long k = ((unsigned long long)P + c * cap - 1) / (c * cap);            // workgroups per CU
+    unsigned long long per = ((unsigned long long)P + k * c - 1) / (k * c);
+    if (per < TF_PER_WG_MIN) per = TF_PER_WG_MIN;
+    TFGrid g;
+    g.per_wg = (uint32_t)per;
+    g.wgs = (uint32_t)(((unsigned long long)P + per - 1) / per);
+    const unsigned long long th = (per + 63) / 64 * 64;
+    g.threads = (uint32_t)(th > TF_THREADS_MAX ? TF_THREADS_MAX : th);
+    return g;
+}
 struct RasterGeom {
     float4 *rec;              // [2P]  {px, py, A2, B2} {C2, L, hx, hy}: A2,B2,C2 = conic * (-log2e/2, -log2e, -log2e/2),
                               //       L = log2(opacity*mu), (hx, hy) = half-extents of the alpha >= 1e-5 bounding box
@@ -103,12 +119,12 @@ struct RasterGeom {
     size_t psort_bytes;
     // tile-first binning (raster_tilefirst.hip) only, carved BEHIND everything else so that the layout the backward and the
     // introspection compute from P alone is unchanged: the Gaussian's tile rectangle (depth_rect_pack) and, per producer
-    // workgroup of TF_WG Gaussians and tile, the offset of that workgroup's instances inside the tile's list
+    // workgroup (tf_grid) and tile, the offset of that workgroup's instances inside the tile's list
     uint32_t *tf_rect;        // [P]
-    uint32_t *tf_wgoff;       // [ceil(P / TF_WG)][T]
-    uint32_t *tf_wgmm;        // [ceil(P / TF_WG)][2] key range {max, ~min} of every producer workgroup
+    uint32_t *tf_wgoff;       // [producer workgroups][T]
+    uint32_t *tf_wgmm;        // [producer workgroups][2] key range {max, ~min} of every producer workgroup
     size_t bytes;
-    static RasterGeom carve(char *chunk, int P, size_t tf_T = 0)
+    static RasterGeom carve(char *chunk, int P, size_t tf_T = 0, size_t tf_wgs = 0)
     {
         RasterGeom g;
         Bump b(chunk);
@@ -130,8 +146,8 @@ struct RasterGeom {
         g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order (kept apart: the control block at
         g.psort_temp = b.take<char>(g.psort_bytes);   // the start of dorder_temp must survive until the backward)
         g.tf_rect = b.take<uint32_t>(tf_T ? (size_t)P : 0);
-        g.tf_wgoff = b.take<uint32_t>(tf_T ? ((size_t)P + TF_WG - 1) / TF_WG * tf_T : 0);
-        g.tf_wgmm = b.take<uint32_t>(tf_T ? ((size_t)P + TF_WG - 1) / TF_WG * 2 : 0);
+        g.tf_wgoff = b.take<uint32_t>(tf_wgs * tf_T);
+        g.tf_wgmm = b.take<uint32_t>(tf_wgs * 2);
         g.bytes = b.total();
         return g;
     }
@@ -187,7 +203,7 @@ constexpr uint32_t TF_MARK = 0x71FEu;       // host word DW_PMAX of a forward th
 // zero-fill launch precedes the forward (a launch boundary costs 3-4 us).  All zero between calls.
 struct TFCounters {
     unsigned long long total;   // (visible Gaussians << 40) | instances handed out so far (a workgroup's base = the low bits)
-    uint32_t done;              // producer workgroups that have finished
+    uint32_t unused;
     uint32_t thin;              // a Gaussian needs the re-anchored row recurrence (row_tier == 1)
     uint32_t pad[12];
     uint32_t tile_count[TF_MAX_TILES];   // instances per tile
@@ -234,12 +250,19 @@ int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, c
                              const float *rotations, const float *opacities, const float *cov3D_precomp,
                              const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy,
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
-// tile-first binning, first kernel: the preprocess + per-tile instance counts + every Gaussian's run of scratch rows; its last
-// workgroup posts {num_rendered, thin flag, visible count} to the state's host words and to the mailbox
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const float *means3D, const float *scales, float scale_modifier,
-                                const float *rotations, const float *opacities, const float *cov3D_precomp, const float *view,
-                                const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode, int *radii,
-                                TFCounters *ctr, uint32_t *mailbox, uint32_t seq, hipStream_t s);
+// tile-first binning, first kernel: the preprocess + per-tile instance counts + every Gaussian's run of scratch rows.  The totals
+// stay in the counters: the scatter kernel's workgroup 0 posts them to the state's host words and to the mailbox
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const float *means3D, const float *scales,
+                                float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
+                                const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
+                                int *radii, TFCounters *ctr, hipStream_t s);
+// 40 bits of instances (P < 2^24 Gaussians of <= 2^16 tiles each), 24 of visible Gaussians; a total beyond the 31-bit num_rendered
+// of the API reaches the host as an out-of-range word, which it rejects
+__host__ __device__ __forceinline__ uint32_t tf_total_instances(unsigned long long tot)
+{
+    const unsigned long long inst = tot & ((1ull << 40) - 1ull);
+    return inst > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)inst;
+}
 int launch_raster_duplicate(const RasterGeom &g, const RasterBinning &b, int P /* per view */, int V, const int *radii, int W, int H,
                             const uint32_t *nvis /* device word: visible prefix of order/offsets, or null = all P */,
                             hipStream_t s);
@@ -269,6 +292,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
                              const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
                              float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s);
 void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin);   // a finished forward's count: the next prediction
+void raster_tilefirst_release();   // the calling thread's counters and predictions (r2_thread_release)
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s);
 

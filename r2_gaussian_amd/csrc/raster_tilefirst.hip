@@ -1,11 +1,12 @@
 // raster_tilefirst.hip -- tile-first binning of the X-ray rasterizer (round 4): the reference's
 // duplicateWithKeys -> SortPairs(tile | depth) -> identifyTileRanges (RAS/rasterizer_impl.cu:70-138,275-316) as
 //     1. raster_preprocess_tf_kernel (raster_geom.hip)   preprocess + per-tile instance counts (LDS histogram per workgroup, one
-//                                                        returning global atomic per (workgroup, tile)) + totals to the host
+//                                                        returning global atomic per (workgroup, tile)); the totals stay in the
+//                                                        counters
 //     2. raster_tf_scatter_kernel                        every instance straight into its TILE's segment of the list, as a
 //                                                        (depth key, Gaussian id) pair, in arbitrary order inside the segment;
-//                                                        workgroup 0 also builds tile ranges, the render work list and the
-//                                                        sort parts
+//                                                        workgroup 0 posts the totals to the host and builds tile ranges, the
+//                                                        render work list and the sort parts
 //     3. raster_tf_sort_kernel                           one workgroup per tile (long lists: several, by depth range) sorts its
 //                                                        segment by (depth key, id) in LDS and writes point_list
 // A stable sort by tile followed by a sort of every tile's entries on (depth bits, id) IS the reference's (tile | depth) order
@@ -36,7 +37,8 @@ namespace r2 {
 
 namespace {
 
-constexpr int TFS_THREADS = TF_WG;      // scatter: the producer's mapping (raster_preprocess_tf_kernel)
+constexpr int TFS_THREADS = (int)TF_THREADS_MAX;   // scatter: always full workgroups (the scan of the tile counts uses all of them);
+                                                   // the producer's mapping (tf_grid) says which threads own Gaussians
 // ---- the sort kernel: 1024-thread workgroups of two kinds
 //   "big"    one tile list of > TFK_SMALL_CAP entries (or one depth range of a list beyond TFK_BIG_CAP) sorted by the whole workgroup;
 //   "group"  TFK_GROUPS lists of <= TFK_SMALL_CAP entries, one per 256-thread part of the workgroup, in lockstep (same code,
@@ -64,28 +66,68 @@ static_assert(TFK_GROUPS * TFK_SMALL_CAP * sizeof(unsigned long long) + TFK_GROU
 static_assert(TFK_SMALL_CAP == TF_SMALL_CAP && TFK_COARSE == TFK_THREADS && TFK_BIG_CAP >= TFK_BIG_TARGET + TFK_BIG_TARGET / 2,
               "parts need slack over their target size");
 
-// ---- 2. scatter.  Workgroup 0 does not scatter: it builds the tile ranges, the render kernel's work list and the sort kernel's
-// work lists from the tile counts while the others run (as block 0's epilogue this serial job was the kernel's tail)
+// ---- 2. scatter.  The first TFS_SERVICE workgroups do not scatter; while the others run they (0) post the call's totals to the
+// host, (1) build the tile ranges and the render kernel's work list, (2) build the sort kernel's work lists from the tile counts --
+// one workgroup each: as ONE workgroup's serial job (round 4, 9 us) they became the kernel's tail once the producers got faster
+constexpr uint32_t TFS_SERVICE = 3;
 __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
-    int P, int gx, uint32_t T, const uint32_t *__restrict__ rects, const uint32_t *__restrict__ depth_key,
-    const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff, const uint32_t *__restrict__ tile_count,
-    const uint32_t *__restrict__ words, uint32_t cap, uint2 *__restrict__ pairs, WorkListOut wo, uint4 *__restrict__ big_parts,
-    uint32_t big_cap, uint4 *__restrict__ small_tiles, uint32_t *__restrict__ nparts /* [2]: big parts, small tiles */)
+    int P, uint32_t per_wg, uint32_t pthreads, int gx, uint32_t T, const uint32_t *__restrict__ rects,
+    const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff,
+    const uint32_t *__restrict__ wgmm, uint32_t producers, const TFCounters *__restrict__ ctr, uint32_t *__restrict__ words,
+    uint32_t *__restrict__ mailbox, uint32_t seq, uint32_t cap, uint2 *__restrict__ pairs, WorkListOut wo,
+    uint4 *__restrict__ big_parts, uint32_t big_cap, uint4 *__restrict__ small_tiles,
+    uint32_t *__restrict__ nparts /* [2]: big parts, small tiles */)
 {
     extern __shared__ uint32_t s_pos[];   // [T] start of the tile's segment + this workgroup's offset in it, bumped per instance
     __shared__ uint32_t s_wsum[3][TFS_THREADS / 64], s_carry[3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *__restrict__ tile_count = ctr->tile_count;
     R2_TS_AT(tilefirst, 0);
-    const uint32_t R = words[DW_TOTAL];
+    // the call's totals are where the preprocess kernel's atomics left them (round 4: its last workgroup copied them to the host
+    // words in an epilogue that every later kernel waited for)
+    const unsigned long long tot = ctr->total;
+    const uint32_t R = tf_total_instances(tot);
+    if (blockIdx.x == 0) {
+        // ---- first of all, what the HOST is waiting for: {num_rendered, thin flag, key range, visible count} to the state's host
+        // words and to the mailbox.  Key range of the call = max over the producers' slots
+        uint32_t gkmax = 0u, gnkmin = 0u;
+        for (uint32_t b = tid; b < producers; b += TFS_THREADS) {
+            gkmax = max(gkmax, wgmm[2u * b]);
+            gnkmin = max(gnkmin, wgmm[2u * b + 1u]);
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            gkmax = max(gkmax, (uint32_t)__shfl_xor(gkmax, d));
+            gnkmin = max(gnkmin, (uint32_t)__shfl_xor(gnkmin, d));
+        }
+        if (lane == 0) { s_wsum[0][wave] = gkmax; s_wsum[1][wave] = gnkmin; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int q = 0; q < TFS_THREADS / 64; ++q) { gkmax = max(gkmax, s_wsum[0][q]); gnkmin = max(gnkmin, s_wsum[1][q]); }
+            const uint32_t nvis = (uint32_t)(tot >> 40), any_thin = ctr->thin;
+            words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = any_thin; words[DW_PMAX] = TF_MARK;
+            words[DW_PNMAX] = 0u; words[DW_NMAX] = gkmax; words[DW_NNMAX] = gnkmin; words[DW_NVIS] = nvis;
+            mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = any_thin; mailbox[DW_PMAX] = TF_MARK;
+            mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = gkmax; mailbox[DW_NNMAX] = gnkmin; mailbox[DW_NVIS] = nvis;
+            __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        R2_TS_AT(tilefirst, 5);
+    }
     if (R > cap) {   // the buffers were sized by a prediction that fell short: do nothing, the host sizes them exactly and re-runs
         if (blockIdx.x == 0 && tid == 0) { wo.chunk_base[T] = 0u; wo.chunk_base[T + 1] = 0u; nparts[0] = 0u; nparts[1] = 0u; }
         return;
     }
-    if (blockIdx.x == 0) {
-        // ---- tile ranges + the render kernel's work list (arrival counters zeroed, empty tiles appended) ...
+    if (blockIdx.x == 0) return;
+    if (blockIdx.x == 1) {
+        // ---- tile ranges + the render kernel's work list (arrival counters zeroed, empty tiles appended)
         ranges_and_work_block<TFS_THREADS>(tile_count, wo);
-        // ... + the sort kernel's two lists
-        __syncthreads();
+        R2_TS_AT(tilefirst, 2);
+        return;
+    }
+    if (blockIdx.x == 2) {
+        // ---- the sort kernel's two lists
         if (tid < 3) s_carry[tid] = 0u;
         __syncthreads();
         for (uint32_t base = 0; base < T; base += TFS_THREADS) {
@@ -115,12 +157,21 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
         R2_TS_AT(tilefirst, 2);
         return;
     }
-    const uint32_t wg = blockIdx.x - 1u;
-    // this thread's Gaussian: requested now, used after the scan (everything here was written by the previous kernel on other
-    // XCDs, i.e. comes from memory: one round trip for all of it instead of one per dependent step)
-    const int idx = (int)wg * TFS_THREADS + tid;
-    const int idc = min(idx, P - 1);
-    const uint32_t g_tt = tiles_touched[idc], g_rect = rects[idc], g_key = depth_key[idc];
+    const uint32_t wg = blockIdx.x - TFS_SERVICE;
+    // this thread's Gaussians (tf_grid: up to TF_PER_THREAD_MAX of the workgroup's range): requested now, used after the scan
+    // (everything here was written by the previous kernel on other XCDs, i.e. comes from memory: one round trip for all of it
+    // instead of one per dependent step)
+    constexpr int NI = (int)TF_PER_THREAD_MAX;
+    const uint32_t g0 = wg * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
+    uint32_t g_idx[NI], g_tt[NI], g_rect[NI], g_key[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        g_idx[it] = g0 + (uint32_t)it * pthreads + (uint32_t)tid;
+        const bool own = (uint32_t)tid < pthreads && g_idx[it] < g1;
+        const uint32_t idc = min(g_idx[it], (uint32_t)P - 1u);
+        g_tt[it] = tiles_touched[idc]; g_rect[it] = rects[idc]; g_key[it] = depth_key[idc];
+        g_tt[it] = own ? g_tt[it] : 0u;
+    }
     // ---- exclusive scan of the tile counts (every workgroup for itself: <= 16 KB, cheaper than a launch boundary)
     const uint32_t *__restrict__ my_off = wgoff + (size_t)wg * T;
     constexpr int MAXT = (int)(TF_MAX_TILES / TFS_THREADS);
@@ -161,17 +212,19 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
     }
     __syncthreads();
     // ---- every instance of this workgroup's Gaussians
-    if (idx < P && g_tt != 0u) {
-        const uint32_t rect = g_rect, key = g_key;
-        const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
-        for (uint32_t r = 0; r < h; ++r) {
-            const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
-            for (uint32_t c = 0; c < w; ++c) {
-                const uint32_t pos = atomicAdd(&s_pos[row + c], 1u);
-                pairs[pos] = make_uint2(key, (uint32_t)idx);
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+        if (g_tt[it] != 0u) {
+            const uint32_t rect = g_rect[it], key = g_key[it];
+            const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
+            for (uint32_t r = 0; r < h; ++r) {
+                const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
+                for (uint32_t c = 0; c < w; ++c) {
+                    const uint32_t pos = atomicAdd(&s_pos[row + c], 1u);
+                    pairs[pos] = make_uint2(key, g_idx[it]);
+                }
             }
         }
-    }
     R2_TS_AT(tilefirst, 1);
 }
 
@@ -269,14 +322,21 @@ __device__ __forceinline__ void tf_sort_group(unsigned long long (&mine)[PER], u
 
 __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
     const uint4 *__restrict__ big_parts, uint32_t big_cap, const uint4 *__restrict__ small_tiles, const uint32_t *__restrict__ nparts,
-    const uint2 *__restrict__ pairs, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tile_count,
-    const uint32_t *__restrict__ words)
+    const uint2 *__restrict__ pairs, uint32_t *__restrict__ point_list, TFCounters *__restrict__ ctr,
+    const uint32_t *__restrict__ words, uint32_t cap)
 {
     extern __shared__ unsigned long long tfk_lds[];
     __shared__ uint32_t s_mm[2][TFK_THREADS / 64], s_wsum[TFK_THREADS / 64], s_cnt, s_off;
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t *__restrict__ tile_count = ctr->tile_count;
     R2_TS_AT(tilefirst, 3);
+    // the scalar counters have been read for the last time by the scatter kernel: ready for the next call -- unless the state was
+    // too small for this one, in which case the scatter kernel will want them again
+    if (p == 0u && tid == 0 && words[DW_TOTAL] <= cap) {
+        __hip_atomic_store(&ctr->total, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ctr->thin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     // the descriptor is requested together with the counts that say whether it exists (one round trip, not two): the big-part
     // list has a slot for every workgroup below its capacity; the short list is indexed behind the big count, so it waits
     const uint4 pd = big_parts[min(p, big_cap - 1u)];
@@ -472,36 +532,88 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
 }
 
 // ---- host side
-struct TFWorkspace { int dev; hipStream_t stream; TFCounters *ctr; uint32_t *nparts; bool dirty; };
-thread_local std::vector<TFWorkspace> g_tf_ws;
+// Counters that several workgroups bump with atomics live in a small persistent allocation per (host thread, device, stream):
+// self-resetting, so no zero-fill launch precedes the forward.  Owned by the thread: freed when it exits (or on
+// r2_thread_release()); a thread that cycles through more streams than the table holds evicts the least recently used entry
+// (round 4: never freed, and the fast path silently switched itself off after 64 streams -- ADVICE r4).
+struct TFWorkspace { int dev; hipStream_t stream; TFCounters *ctr; uint32_t *nparts; bool dirty; unsigned long long used; };
+struct TFWorkspaces {
+    std::vector<TFWorkspace> v;
+    unsigned long long tick = 0;
+    static void free_one(const TFWorkspace &w)
+    {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (cur != w.dev && hipSetDevice(w.dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipFree(w.ctr) != hipSuccess) (void)hipGetLastError();   // (its last forward may still run: hipFree waits for the device)
+        if (cur != w.dev) (void)hipSetDevice(cur);
+    }
+    void release()
+    {
+        for (const TFWorkspace &w : v) free_one(w);
+        v.clear();
+    }
+    ~TFWorkspaces() { release(); }
+};
+thread_local TFWorkspaces g_tf_ws;
+constexpr size_t TF_MAX_WORKSPACES = 16;
 
 TFWorkspace *tf_workspace(int dev, hipStream_t s)
 {
-    for (TFWorkspace &w : g_tf_ws)
-        if (w.dev == dev && w.stream == s) return &w;
-    if (g_tf_ws.size() >= 64) return nullptr;   // a thread cycling through ever new streams: the general path from here on
+    TFWorkspaces &t = g_tf_ws;
+    ++t.tick;
+    for (TFWorkspace &w : t.v)
+        if (w.dev == dev && w.stream == s) { w.used = t.tick; return &w; }
+    if (t.v.size() >= TF_MAX_WORKSPACES) {
+        size_t lru = 0;
+        for (size_t i = 1; i < t.v.size(); ++i)
+            if (t.v[i].used < t.v[lru].used) lru = i;
+        TFWorkspaces::free_one(t.v[lru]);
+        t.v.erase(t.v.begin() + (long)lru);
+    }
     char *p = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&p), sizeof(TFCounters) + 64) != hipSuccess) {
         (void)hipGetLastError();
         return nullptr;
     }
-    g_tf_ws.push_back(TFWorkspace{dev, s, reinterpret_cast<TFCounters *>(p), reinterpret_cast<uint32_t *>(p + sizeof(TFCounters)), true});
-    return &g_tf_ws.back();
+    t.v.push_back(TFWorkspace{dev, s, reinterpret_cast<TFCounters *>(p), reinterpret_cast<uint32_t *>(p + sizeof(TFCounters)), true, t.tick});
+    return &t.v.back();
 }
 
 // the thread's recent instance counts per problem size: what the prediction is made of
-struct TFHint { int P, W, H; uint32_t recent[8]; uint32_t n; bool thin; };
+struct TFHint { int P, W, H; uint32_t recent[8]; uint32_t n; bool thin; unsigned long long used; };
 thread_local std::vector<TFHint> g_tf_hints;
+thread_local unsigned long long g_tf_hint_tick = 0;
 
 TFHint *tf_hint(int P, int W, int H, bool create)
 {
     for (TFHint &h : g_tf_hints)
-        if (h.P == P && h.W == W && h.H == H) return &h;
+        if (h.P == P && h.W == W && h.H == H) { h.used = ++g_tf_hint_tick; return &h; }
     if (!create) return nullptr;
-    if (g_tf_hints.size() >= 16) g_tf_hints.erase(g_tf_hints.begin());
-    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false});
+    if (g_tf_hints.size() >= 16) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_tf_hints.size(); ++i)
+            if (g_tf_hints[i].used < g_tf_hints[lru].used) lru = i;
+        g_tf_hints.erase(g_tf_hints.begin() + (long)lru);
+    }
+    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false, ++g_tf_hint_tick});
     return &g_tf_hints.back();
 }
+
+// no call with this P yet -- every densification changes it (train.py:155-168) --: the thread's most recent call on the same
+// detector, scaled by the ratio of the Gaussian counts
+const TFHint *tf_hint_nearby(int W, int H)
+{
+    const TFHint *best = nullptr;
+    for (const TFHint &h : g_tf_hints)
+        if (h.W == W && h.H == H && h.n != 0u && h.P > 0 && (!best || h.used > best->used)) best = &h;
+    return best;
+}
+
+// what the chain did, process-wide (r2_tile_first_stats): forwards that took it, forwards it declined (no prediction / limits),
+// chains run a second time because the prediction fell short, renders repeated for the thin-Gaussian variant, forwards whose
+// prediction was seeded from another P (the call after a densification)
+std::atomic<long long> g_tf_taken{0}, g_tf_declined{0}, g_tf_rerun{0}, g_tf_rerender{0}, g_tf_seeded{0};
 
 std::atomic<int> g_tf_mode{-1};   // -1: not decided yet (environment), 0: off, 1: on
 
@@ -536,36 +648,54 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
 {
     const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
     const size_t T = (size_t)gx * gy, N = (size_t)width * height;
-    const size_t wgs = ((size_t)P + TF_WG - 1) / TF_WG;
+    const TFGrid grid = tf_grid(P, device_cu_count());
+    const size_t wgs = grid.wgs;
     // rectangles are packed into bytes (<= 256 x 256 tiles), the LDS histogram holds <= 4096 tiles, instance offsets are 32-bit
-    if (T > TF_MAX_TILES || gx > 256 || gy > 256 || wgs * T > ((size_t)1 << 25) || P >= (1 << 24) || !tf_enabled())
+    if (T > TF_MAX_TILES || gx > 256 || gy > 256 || wgs * T > ((size_t)1 << 25) || P >= (1 << 24) || !tf_enabled()) {
+        g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
-    const TFHint *hint = tf_hint(P, width, height, false);
-    if (!hint || hint->n == 0) return TF_NOT_TAKEN;   // no prediction yet: the general path, which leaves one behind
+    }
+    // ---- the prediction: the largest count of the thread's recent calls with this P and detector; for a P it has not rendered
+    // yet (the call after a densification) the most recent call on the same detector, scaled -- same scene, more Gaussians
+    uint32_t rmax = 0;
+    bool thin_guess = false;
+    if (const TFHint *hint = tf_hint(P, width, height, false); hint && hint->n != 0u) {
+        for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
+        thin_guess = hint->thin;
+    } else if (const TFHint *near = tf_hint_nearby(width, height)) {
+        uint32_t r0 = 0;
+        for (uint32_t i = 0; i < std::min(near->n, 8u); ++i) r0 = std::max(r0, near->recent[i]);
+        rmax = (uint32_t)std::min<double>((double)r0 * ((double)P / (double)near->P) * 1.1, 2.0e9);
+        thin_guess = near->thin;
+        g_tf_seeded.fetch_add(1, std::memory_order_relaxed);
+    } else {
+        g_tf_declined.fetch_add(1, std::memory_order_relaxed);
+        return TF_NOT_TAKEN;   // no prediction yet: the general path, which leaves one behind
+    }
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
     TFWorkspace *ws = tf_workspace(dev, s);
-    if (!ws) return TF_NOT_TAKEN;
-    uint32_t rmax = 0;
-    for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
+    if (!ws) {
+        g_tf_declined.fetch_add(1, std::memory_order_relaxed);
+        return TF_NOT_TAKEN;
+    }
     // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes)
     size_t cap = (((size_t)rmax + rmax / 4 + 16384) + 65535) & ~(size_t)65535;
-    bool thin_guess = hint->thin;
 
-    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, T).bytes, geometry_user);
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, T, wgs).bytes, geometry_user);
     if (!gchunk) {
         set_error("%s: state allocation callback returned NULL", what);
         return R2_ERR_ALLOC;
     }
-    const RasterGeom geom = RasterGeom::carve(gchunk, P, T);
+    const RasterGeom geom = RasterGeom::carve(gchunk, P, T, wgs);
     if (ws->dirty) R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));   // first use, or a call that failed half way
     ws->dirty = true;
     uint32_t *mailbox = nullptr, mailbox_seq = 0;
     int rc = host_mailbox_arm(&mailbox, &mailbox_seq);
     if (rc) return rc;
     { StageScope t(ST_RAS_PREPROCESS, s);
-    launch_raster_preprocess_tf(geom, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix, projmatrix,
-                                width, height, tan_fovx, tan_fovy, mode, radii, ws->ctr, mailbox, mailbox_seq, s); }
+    launch_raster_preprocess_tf(geom, P, grid, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
+                                projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, ws->ctr, s); }
     R2_HIP_TRY(hipGetLastError());
 
     RasterBinning bin{};
@@ -583,14 +713,16 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
             uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // backward scratch (32 bytes per instance), free until then
             { StageScope t(ST_RAS_DUPLICATE, s);
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW};
-            raster_tf_scatter_kernel<<<dim3((unsigned)wgs + 1u), dim3(TFS_THREADS), T * sizeof(uint32_t), s>>>(
-                P, gx, (uint32_t)T, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, ws->ctr->tile_count,
-                geom.host_words, (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP,
-                img.tf_parts + img.NP, ws->nparts); }
+            raster_tf_scatter_kernel<<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), T * sizeof(uint32_t), s>>>(
+                P, grid.per_wg, grid.threads, gx, (uint32_t)T, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff,
+                geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,
+                (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,
+                ws->nparts); }
             R2_HIP_TRY(hipGetLastError());
             { StageScope t(ST_RAS_SORT, s);
             raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (T + TFK_GROUPS - 1) / TFK_GROUPS)), dim3(TFK_THREADS), TFK_LDS, s>>>(
-                img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr->tile_count, geom.host_words); }
+                img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr, geom.host_words,
+                (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu)); }
             R2_HIP_TRY(hipGetLastError());
         } else {
             R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, T * sizeof(uint32_t), s));   // the first render left its arrivals behind
@@ -613,18 +745,32 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         return R2_ERR_INVALID;
     }
     if ((size_t)num_rendered > cap) {
+        g_tf_rerun.fetch_add(1, std::memory_order_relaxed);
         rc = enqueue(num_rendered, thin, false);      // the prediction fell short: exact sizes, same kernels
         if (rc) return rc;
     } else if (thin && !thin_guess) {
+        g_tf_rerender.fetch_add(1, std::memory_order_relaxed);
         rc = enqueue(cap, true, true);                // the scene holds thin Gaussians after all: render again with that variant
         if (rc) return rc;
     }
     ws->dirty = false;
+    g_tf_taken.fetch_add(1, std::memory_order_relaxed);
     raster_tilefirst_note(P, width, height, num_rendered, thin);
     return (int)num_rendered;
 }
 
+void raster_tilefirst_release() { g_tf_ws.release(); g_tf_hints.clear(); }
+
 }  // namespace r2
+
+extern "C" void r2_tile_first_stats(long long *out, int reset)
+{
+    std::atomic<long long> *c[5] = {&r2::g_tf_taken, &r2::g_tf_declined, &r2::g_tf_rerun, &r2::g_tf_rerender, &r2::g_tf_seeded};
+    for (int i = 0; i < 5; ++i) {
+        if (out) out[i] = c[i]->load(std::memory_order_relaxed);
+        if (reset) c[i]->store(0, std::memory_order_relaxed);
+    }
+}
 
 extern "C" void r2_tile_first_control(int mode)
 {

@@ -241,14 +241,44 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
 // The two persistent counters of the path ({done | survivors | rows} of the preprocess, `arrivals` of the lists kernel) are
 // self-resetting, so they must not be shared by two calls in flight: one 64-byte block per (host thread, device, stream), kept
 // for the life of the thread (a thread that alternates devices or streams finds its block again instead of allocating).
-struct SmallCounter { int dev; hipStream_t stream; unsigned long long *ptr; };
-thread_local std::vector<SmallCounter> g_small_counters;
+// one 64-byte counter block per (host thread, device, stream), owned by the thread: freed when it exits or on
+// r2_thread_release(); a thread that cycles through more streams than the table holds evicts the least recently used entry
+// (round 4: never freed, and the path switched itself off for the thread after 256 streams -- ADVICE r4)
+struct SmallCounter { int dev; hipStream_t stream; unsigned long long *ptr; unsigned long long used; };
+struct SmallCounters {
+    std::vector<SmallCounter> v;
+    unsigned long long tick = 0;
+    static void free_one(const SmallCounter &c)
+    {
+        int cur = 0;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (cur != c.dev && hipSetDevice(c.dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        if (hipFree(c.ptr) != hipSuccess) (void)hipGetLastError();   // (waits for the device: its last call may still run)
+        if (cur != c.dev) (void)hipSetDevice(cur);
+    }
+    void release()
+    {
+        for (const SmallCounter &c : v) free_one(c);
+        v.clear();
+    }
+    ~SmallCounters() { release(); }
+};
+thread_local SmallCounters g_small_counters;
+constexpr size_t SMALL_MAX_COUNTERS = 16;
 
 unsigned long long *small_counter_for(int dev, hipStream_t s)
 {
-    for (const SmallCounter &c : g_small_counters)
-        if (c.dev == dev && c.stream == s) return c.ptr;
-    if (g_small_counters.size() >= 256) return nullptr;   // a thread cycling through ever new streams: general path from here on
+    SmallCounters &t = g_small_counters;
+    ++t.tick;
+    for (SmallCounter &c : t.v)
+        if (c.dev == dev && c.stream == s) { c.used = t.tick; return c.ptr; }
+    if (t.v.size() >= SMALL_MAX_COUNTERS) {
+        size_t lru = 0;
+        for (size_t i = 1; i < t.v.size(); ++i)
+            if (t.v[i].used < t.v[lru].used) lru = i;
+        SmallCounters::free_one(t.v[lru]);
+        t.v.erase(t.v.begin() + (long)lru);
+    }
     unsigned long long *p = nullptr;
     if (hipMalloc(reinterpret_cast<void **>(&p), 64) != hipSuccess) {
         (void)hipGetLastError();
@@ -259,7 +289,7 @@ unsigned long long *small_counter_for(int dev, hipStream_t s)
         (void)hipFree(p);
         return nullptr;
     }
-    g_small_counters.push_back(SmallCounter{dev, s, p});
+    t.v.push_back(SmallCounter{dev, s, p, t.tick});
     return p;
 }
 
@@ -339,5 +369,7 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
     R2_HIP_TRY(hipGetLastError());
     return (int)num_rendered;
 }
+
+void voxel_small_release() { g_small_counters.release(); }
 
 }  // namespace r2

@@ -177,6 +177,7 @@ constexpr uint32_t VOX_SMALL_MAX_SURVIVORS = 8192;  // a tile's list (<= all sur
 // -> num_rendered (>= 0), a negative R2_ERR_* code, or VOX_SMALL_NOT_TAKEN: the caller runs the general pipeline
 constexpr int VOX_SMALL_NOT_TAKEN = -1000;
 constexpr uint32_t VOX_SMALL_MARK = 0x5A11u;      // DW_USER word of a state produced by the small-grid path (introspection / tests)
+void voxel_small_release();   // the calling thread's counter blocks of the small-grid path (r2_thread_release)
 int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                         const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                         const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,

@@ -232,11 +232,21 @@ int main(int argc, char **argv)
                 tabs.push_back(ts);
                 names.push_back(u);
             }
+            // only the stamps of the step just run: the tables also hold what kernels of earlier calls (other chains, larger
+            // grids) left in slots this step did not overwrite.  A step is < 1 ms; the newest stamp ends it.
+            unsigned long long tmax = 0;
+            for (const auto &tb : tabs)
+                for (unsigned long long v : tb) tmax = std::max(tmax, v);
+            const unsigned long long tlo = tmax > 100000ull ? tmax - 100000ull : 0ull;   // 1 ms at 100 MHz
+            t0 = ~0ull;
+            for (const auto &tb : tabs)
+                for (unsigned long long v : tb)
+                    if (v >= tlo && v < t0) t0 = v;
             for (size_t k = 0; k < tabs.size(); ++k)
                 for (int ph = 0; ph < 16; ++ph) {
                     std::vector<double> v;
                     for (int b = 0; b < 2048; ++b)
-                        if (tabs[k][ph * 2048 + b]) v.push_back((double)(tabs[k][ph * 2048 + b] - t0) * 0.01);   // 100 MHz -> us
+                        if (tabs[k][ph * 2048 + b] >= tlo && tabs[k][ph * 2048 + b]) v.push_back((double)(tabs[k][ph * 2048 + b] - t0) * 0.01);   // 100 MHz -> us
                     if (v.empty()) continue;
                     std::sort(v.begin(), v.end());
                     printf("  TS %-6s %2d: n %4zu  min %7.2f  med %7.2f  max %7.2f us\n", names[k].c_str(), ph, v.size(), v.front(),
