@@ -79,6 +79,7 @@ def _sum_check(name, got, ref64, tol, stats, flagged):
 
 
 MAX_PAIRS_PER_ROW = 8   # rows with more borderline pairs keep the budget check only (2^m subsets are enumerated)
+MAX_SKIPPED_FRACTION, MAX_SKIPPED_ROWS_ABS = 0.05, 4   # ... and there may only be a few of them
 
 
 def _after_flips(stats, pairs, flagged, raw_err, raw_tol, chained, rtol):
@@ -97,7 +98,14 @@ def _after_flips(stats, pairs, flagged, raw_err, raw_tol, chained, rtol):
            "pairs_listed": int(len(ids)), "pair_list_truncated": bool(pairs["truncated"]), "max_err_over_tol_after_flips": 0.0,
            "rows_needing_a_flip": 0}
     stats["after_flips"] = out
-    if pairs["truncated"] or not len(ids):
+    if pairs["truncated"]:
+        # the audit listed only part of the borderline pairs: the stricter check cannot be made -- that is a FAILED check, not a
+        # passed one (it used to return silently, and the test stayed green on the budget check alone)
+        stats.setdefault("_errors", []).append(
+            "the borderline-pair list overflowed (%d pairs listed): the after-flips check of %d flagged rows could not be made; "
+            "raise the pair capacity of the audit or shrink the case" % (len(ids), int(flagged.sum())))
+        return
+    if not len(ids):
         return
     order = np.argsort(ids, kind="stable")
     ids_s, vals_s = ids[order], vals[order]
@@ -131,6 +139,11 @@ def _after_flips(stats, pairs, flagged, raw_err, raw_tol, chained, rtol):
             worst, worst_row = float(r[k]), i
     out["max_err_over_tol_after_flips"] = worst
     out["worst_row"] = worst_row
+    # rows with more pairs than are enumerated keep the budget check only: visible loss of coverage, bounded
+    if out["rows_skipped_many_pairs"] > MAX_SKIPPED_FRACTION * max(out["rows_flagged"], 1) + MAX_SKIPPED_ROWS_ABS:
+        stats.setdefault("_errors", []).append(
+            "%d of %d flagged rows hold more than %d borderline pairs and were not given the after-flips check (allowed: %.0f %% + %d)" % (
+                out["rows_skipped_many_pairs"], out["rows_flagged"], MAX_PAIRS_PER_ROW, 100 * MAX_SKIPPED_FRACTION, MAX_SKIPPED_ROWS_ABS))
     if worst > 1.0:
         stats.setdefault("_errors", []).append(
             "after taking out the best-matching subset of its borderline pairs, Gaussian %d is still %.3f x the pure %.0e*sum|terms| "

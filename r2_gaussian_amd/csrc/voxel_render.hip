@@ -250,8 +250,13 @@ __device__ __forceinline__ void vfwd_item_body(
                 mk[sl] = __ballot(live && !exact);
                 mx[sl] = __ballot(live && exact);
             }
+            // (nq is not needed by the tests above: it waits in this thread's own slot of s3 -- which only the short-list path
+            // uses otherwise -- instead of in four registers across the barrier.  With it in registers the kernel needed 131 of
+            // the 128 VGPRs that four waves per SIMD allow and spilled three of them around this barrier: 12 bytes written
+            // and read back per staged entry, 96 MB of scratch writes per 256^3 query in the round-4 counters.)
+            s3[tid] = nq;
             __syncthreads();   // the previous batch has been consumed
-            s0[tid] = np; s1[tid] = nq; s2[tid] = nr;
+            s0[tid] = np; s1[tid] = s3[tid]; s2[tid] = nr;
             if (lane == 0) {
 #pragma unroll
                 for (int sl = 0; sl < 4; ++sl) { sKeep[sl][wave] = mk[sl]; sExact[sl][wave] = mx[sl]; }

@@ -178,6 +178,20 @@ def test_bench_gpus_n_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["config"]["ranks_in_process_group"] == 2
     assert line["steps"] == 4 and line["timing"]["regions"] == 3 and line["overlapped"]["regions"] == 3
     assert line["value"] > 0 and line["overlapped"]["value"] > 0
+    # round 5: what north_star asks of an N > 1 line -- the synchronous modes side by side with their views per step and which
+    # of them `value` is; one whole data-parallel TRAINING iteration (exchange behind the TV branch); the full-volume query
+    # sharded by x-slab with and without the all-gather (the stand-in voxelizer lets bench.py check the gathered slab order);
+    # the exchange path in `config`
+    assert line["config"]["comm_zero_copy"] in (True, False) and "parallelism" in line["config"]
+    sm = line["sync_modes"]
+    assert sm["value_is"] == "sync" and sm["sync"]["value"] == line["value"]
+    assert sm["sync"]["views_per_rank_and_step"] == 1 and sm["sync2"]["views_per_rank_and_step"] == sm["accum2"]["views_per_rank_and_step"] == 2
+    ti = line["train_iteration"]
+    assert ti["unit"] == "iterations/s" and ti["value"] > 0 and ti["views_per_iteration"] == 2
+    assert abs(ti["views_per_s"] - 2 * ti["value"]) < 0.02
+    sh = line["voxelizer"]["sharded"]
+    assert sh["gvoxel_per_s"] > 0 and sh["with_all_gather"]["gvoxel_per_s"] > 0 and sh["gather_checked"] is True
+    assert sh["slab_of_rank0"] == [0, 32] and sh["volume"] == [64, 64, 64]
     # a launcher that started a different number of ranks than --gpus says: refuse
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],

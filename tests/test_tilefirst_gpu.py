@@ -208,3 +208,37 @@ def test_two_host_threads(L, oracle, gpu):
         th.join()
     assert not errs, errs
     assert took == [True, True]
+
+
+def test_a_new_gaussian_count_is_seeded_from_the_previous_one(L, oracle, gpu):
+    """Round 5.  Every densification changes P (train.py:155-168); round 4 sent the first call of every new P
+    through the general chain.  Now its prediction is seeded from the thread's last call on the same detector (instances per
+    Gaussian x the new count), so the call after a densification takes the tile-first chain as well -- and a seed that falls short
+    (the new Gaussians are much larger) costs a second pass, never a wrong result."""
+    import ctypes
+    v = S.make_views(8, (256, 256))[2]
+    full = S.make_cloud(60000, seed=17)
+    stats = (ctypes.c_longlong * 5)()
+
+    def prefix(n, mult=1.0):
+        return S.Cloud(full.xyz[:n].contiguous(), (full.scales[:n] * mult).contiguous(), full.rotations[:n].contiguous(),
+                       full.density[:n].contiguous())
+    Hh.hip_raster(prefix(20000), v, gpu)                       # first call on this detector: general chain, leaves a prediction
+    L.r2_tile_first_stats(stats, 1)
+    for n in (22000, 26000, 31000, 40000, 60000):              # five "densifications"
+        c = prefix(n)
+        t = Hh.hip_raster(c, v, gpu)
+        assert Hh.took_tile_first(t), "the first call at P = %d did not take the tile-first chain" % n
+        Hh.check_binning(t, Hh.oracle_raster(oracle, c, v, render=False))
+    L.r2_tile_first_stats(stats, 0)
+    assert stats[0] == 5 and stats[1] == 0 and stats[4] == 5, list(stats)
+    # a seed that is far too small: the same count of Gaussians three times the size
+    L.r2_tile_first_stats(stats, 1)
+    big = prefix(61000, mult=3.0)
+    t = Hh.hip_raster(big, v, gpu)
+    L.r2_tile_first_stats(stats, 0)
+    assert Hh.took_tile_first(t) and stats[2] == 1, list(stats)
+    o = Hh.oracle_raster(oracle, big, v)
+    Hh.check_binning(t, o)
+    Hh.parity_image(oracle, o, t["color"], "tile-first, seeded prediction that fell short")
+
