@@ -196,6 +196,11 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 // critical path of everything (stamps: profiles/experiments/r05_round4_chain_stamps.txt).  The totals now simply stay in the
 // counters and workgroup 0 of the NEXT kernel -- which starts when this one has drained anyway -- posts them.  (2) the Gaussians
 // are dealt evenly to one workgroup per CU (tf_grid): a thread owns up to TF_PER_THREAD_MAX of them.
+// (Measured and left out, round 5, same box, alternating runs against this kernel at 22.8 us of stage time: requesting the inputs of
+// BOTH of a thread's Gaussians before computing the first one: the arithmetic phase 5.3 -> 6.8 us by the stamps -- eleven more live
+// registers through 150 lines of double-precision culling arithmetic -- kernel 25.0 us; walking rectangles of more than 8 tiles with
+// the whole wave, 64 tiles per step, here and in the scatter kernel: histogram phase 3.9 -> 4.6 us, scatter 13.5 -> 14.2 us: a wave
+// holds only a handful of such rectangles and each costs three v_readlane + a division-free index computation per step.)
 __global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
     int P, uint32_t per_wg, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
@@ -545,6 +550,10 @@ __global__ void __launch_bounds__(EMIT_THREADS) raster_emit_hist_kernel(
 //   3. computeCov2DCUDA (RAS/backward.cu:145-330) + preprocessCUDA backward (RAS/backward.cu:402-444).
 // Outputs are ASSIGNED; the caller's zero-initialisation covers the rows of culled Gaussians.
 constexpr int GB_ROWS = 256;   // moment rows a wave streams per pass (4 per lane)
+// (Measured and left out, round 5: __launch_bounds__(256, 4) makes hipcc allocate 94 instead of 98 VGPRs, i.e. five waves per SIMD by
+// registers -- the grid of 1172 workgroups is 1.14 rounds of the 1024 slots that four allow, and the stamps show the second round
+// starting 12 us after the first.  26.2 us against 25.2: the LDS (32 KB per workgroup) still stops at four per CU, and with 192 or 128
+// rows per pass -- 24 / 16 KB, six or more per CU -- the kernel takes 27.7 us: the row passes get shorter, the round trips do not.)
 template <bool MV>
 __global__ void __launch_bounds__(256) raster_geom_backward_kernel(
     int P, int Vn, const float *__restrict__ means3D, const int *__restrict__ radii, const float *__restrict__ cov3Ds,
