@@ -192,7 +192,8 @@ static int raster_forward_impl(
     launch_raster_render_forward(geom, bin, img, width, height, V, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
                                  /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s); }
     R2_STAGE_CHECK(debug, s, "render");
-    if (V == 1) raster_tilefirst_note(P, width, height, num_rendered, hw[DW_USER] != 0);   // the next call's prediction
+    // the next call's prediction (visible keys are positive floats: their range is the P class of the host words)
+    if (V == 1) raster_tilefirst_note(P, width, height, num_rendered, hw[DW_USER] != 0, hw[DW_PMAX], ~hw[DW_PNMAX]);
     host_mark_forward_end();
     return (int)num_rendered;
 }

@@ -201,8 +201,9 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 // registers through 150 lines of double-precision culling arithmetic -- kernel 25.0 us; walking rectangles of more than 8 tiles with
 // the whole wave, 64 tiles per step, here and in the scatter kernel: histogram phase 3.9 -> 4.6 us, scatter 13.5 -> 14.2 us: a wave
 // holds only a handful of such rectangles and each costs three v_readlane + a division-free index computation per step.)
+template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */>
 __global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
-    int P, uint32_t per_wg, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    int P, uint32_t per_wg, const TFSlabs slabs, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
@@ -211,13 +212,14 @@ __global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
     uint32_t *__restrict__ first, uint32_t *__restrict__ rects, uint32_t *__restrict__ wgoff, uint32_t *__restrict__ wgmm,
     TFCounters *__restrict__ ctr)
 {
-    extern __shared__ uint32_t tf_hist[];   // [T]
+    extern __shared__ uint32_t tf_hist[];   // [lists = T x slabs]
     constexpr int MAXW = (int)(TF_THREADS_MAX / 64), NI = (int)TF_PER_THREAD_MAX;
     __shared__ uint32_t s_wn[NI][MAXW], s_wv[MAXW], s_kmx[MAXW], s_nkmn[MAXW], s_thin, s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t NT = blockDim.x;
     const int nw = (int)(NT >> 6);
-    const uint32_t T = (uint32_t)(gx * gy);
+    const uint32_t nsl = SL ? slabs.n : 1u;
+    const uint32_t T = (uint32_t)(gx * gy) * nsl;   // lists
     const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);   // this workgroup's Gaussians
     R2_TS_AT(geom, 0);
     for (uint32_t t = tid; t < T; t += NT) tf_hist[t] = 0u;
@@ -243,9 +245,10 @@ __global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
         n[it] = vis ? depth_rect_count(rect[it]) : 0u;
         if (vis) {
             const uint32_t x0 = rect[it] & 0xFFu, y0 = (rect[it] >> 8) & 0xFFu, w = ((rect[it] >> 16) & 0xFFu) + 1u, h = (rect[it] >> 24) + 1u;
+            const uint32_t sl = SL ? tf_slab_of(key[it], slabs) : 0u;
             for (uint32_t r = 0; r < h; ++r) {
-                const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
-                for (uint32_t c = 0; c < w; ++c) atomicAdd(&tf_hist[row + c], 1u);
+                const uint32_t row = ((y0 + r) * (uint32_t)gx + x0) * nsl + sl;
+                for (uint32_t c = 0; c < w; ++c) atomicAdd(&tf_hist[row + c * nsl], 1u);
             }
             rects[g0 + (uint32_t)it * NT + (uint32_t)tid] = rect[it];
             kmx = max(kmx, key[it]);
@@ -806,7 +809,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P, int V, const float *mea
     return 0;
 }
 
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const float *means3D, const float *scales,
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
                                 const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
                                 int *radii, TFCounters *ctr, hipStream_t s)
@@ -814,10 +817,14 @@ int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, 
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    raster_preprocess_tf_kernel<<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * sizeof(uint32_t), s>>>(
-        P, grid.per_wg, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy,
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,
-        g.tf_wgmm, ctr);
+#define R2_TF_PRE(SLB)                                                                                                            \
+    raster_preprocess_tf_kernel<SLB><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>(          \
+        P, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, \
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,  \
+        g.tf_wgmm, ctr)
+    if (slabs.n > 1u) R2_TF_PRE(true);
+    else R2_TF_PRE(false);
+#undef R2_TF_PRE
     return 0;
 }
 

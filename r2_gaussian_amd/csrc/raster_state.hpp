@@ -83,6 +83,22 @@ __device__ __forceinline__ bool block_live(float px, float py, float hx, float h
 // per thread) where that is enough -- and small clouds get more, smaller workgroups.  Few workgroups also means few same-address
 // atomics per tile counter (they retire at ~90 per microsecond device-wide).
 constexpr uint32_t TF_THREADS_MAX = 1024, TF_PER_THREAD_MAX = 2, TF_PER_WG_MIN = 256;
+// Depth slabs (round 5).  A tile list longer than one sort workgroup holds (8192 entries) is sorted by several workgroups that each
+// read the WHOLE list to pick out their depth range -- on trained, densified clouds (lists of 23 k entries) that is most of the sort
+// kernel's time.  When the previous call on this detector saw such lists, the chain bins by LIST = tile * slabs + slab instead of by
+// tile: slab = a monotone function of the depth key laid over the previous call's key range (keys outside it clamp into the end
+// slabs), slabs in {1, 2, 4}.  Monotone => a tile's slabs, one after the other, each sorted on (key, id), ARE the tile's list in
+// (depth, id) order, whatever the range and the count: the choice affects speed only.
+constexpr uint32_t TF_MAX_SLABS = 4;
+constexpr uint32_t TF_SLAB_SPLIT_ABOVE = 12288;  // longest tile list beyond which the lists are cut into slabs (8192 = what one sort
+                                                 // workgroup holds; up to ~two parts the several-workgroups-per-list path is cheaper)
+struct TFSlabs { uint32_t n, lo; float scale; };
+__host__ __device__ __forceinline__ uint32_t tf_slab_of(uint32_t key, const TFSlabs &sl)
+{
+    const uint32_t k = key > sl.lo ? key - sl.lo : 0u;
+    const uint32_t v = (uint32_t)((float)k * sl.scale);
+    return v < sl.n - 1u ? v : sl.n - 1u;
+}
 struct TFGrid { uint32_t wgs, per_wg, threads; };
 inline TFGrid tf_grid(int P, int cus)
 {
@@ -121,7 +137,7 @@ struct RasterGeom {
     // introspection compute from P alone is unchanged: the Gaussian's tile rectangle (depth_rect_pack) and, per producer
     // workgroup (tf_grid) and tile, the offset of that workgroup's instances inside the tile's list
     uint32_t *tf_rect;        // [P]
-    uint32_t *tf_wgoff;       // [producer workgroups][T]
+    uint32_t *tf_wgoff;       // [producer workgroups][lists = T x slabs]
     uint32_t *tf_wgmm;        // [producer workgroups][2] key range {max, ~min} of every producer workgroup
     size_t bytes;
     static RasterGeom carve(char *chunk, int P, size_t tf_T = 0, size_t tf_wgs = 0)
@@ -219,13 +235,13 @@ struct RasterImage {
     uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
     uint32_t *n_contrib;   // [N]  last contributing list position per pixel; only written in debug mode
     char *work_temp;       // scratch of the parallel work-list construction (only for > 4096 tiles)
-    uint4 *tf_parts;       // [NP + T] tile-first only (forward scratch): the sort kernel's work lists -- NP "big" parts {tile,
+    uint4 *tf_parts;       // [NP + lists] tile-first only (forward scratch): the sort kernel's work lists -- NP "big" parts {tile,
                            //      part | parts << 16, first instance, instances}, then up to T short lists {tile, 0, first, instances}
     size_t NP;             // upper bound on big parts: every one stands for > TF_SMALL_CAP instances
     size_t NW;             // upper bound on work items: R/FWD_CHUNK + T
     size_t bytes;
     // everything the backward or the introspection reads (ranges, chunk_base) sits at offsets that depend on T only
-    static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug, bool tile_first = false)
+    static RasterImage carve(char *chunk, size_t T, size_t N, size_t R, bool debug, size_t tf_lists = 0)
     {
         RasterImage s;
         Bump b(chunk);
@@ -238,8 +254,8 @@ struct RasterImage {
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
         s.n_contrib = b.take<uint32_t>(debug ? N : 0);
         s.work_temp = b.take<char>(build_work_temp_bytes(T));
-        s.NP = tile_first ? R / TF_SMALL_CAP + 1 : 0;
-        s.tf_parts = b.take<uint4>(tile_first ? s.NP + T : 0);
+        s.NP = tf_lists ? R / TF_SMALL_CAP + 1 : 0;
+        s.tf_parts = b.take<uint4>(tf_lists ? s.NP + tf_lists : 0);
         s.bytes = b.total();
         return s;
     }
@@ -252,7 +268,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, c
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
 // tile-first binning, first kernel: the preprocess + per-tile instance counts + every Gaussian's run of scratch rows.  The totals
 // stay in the counters: the scatter kernel's workgroup 0 posts them to the state's host words and to the mailbox
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const float *means3D, const float *scales,
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
                                 const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
                                 int *radii, TFCounters *ctr, hipStream_t s);
@@ -291,7 +307,8 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
                              const float *means3D, const float *opacities, const float *scales, float scale_modifier,
                              const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
                              float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s);
-void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin);   // a finished forward's count: the next prediction
+// a finished forward's instance count and depth-key range: the next call's prediction
+void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin);
 void raster_tilefirst_release();   // the calling thread's counters and predictions (r2_thread_release)
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s);

@@ -70,8 +70,10 @@ static_assert(TFK_SMALL_CAP == TF_SMALL_CAP && TFK_COARSE == TFK_THREADS && TFK_
 // host, (1) build the tile ranges and the render kernel's work list, (2) build the sort kernel's work lists from the tile counts --
 // one workgroup each: as ONE workgroup's serial job (round 4, 9 us) they became the kernel's tail once the producers got faster
 constexpr uint32_t TFS_SERVICE = 3;
+template <bool SL /* depth slabs in use */>
 __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
-    int P, uint32_t per_wg, uint32_t pthreads, int gx, uint32_t T, const uint32_t *__restrict__ rects,
+    int P, uint32_t per_wg, uint32_t pthreads, int gx, uint32_t T /* LISTS = tiles x slabs */, const TFSlabs slabs,
+    const uint32_t *__restrict__ rects,
     const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff,
     const uint32_t *__restrict__ wgmm, uint32_t producers, const TFCounters *__restrict__ ctr, uint32_t *__restrict__ words,
     uint32_t *__restrict__ mailbox, uint32_t seq, uint32_t cap, uint2 *__restrict__ pairs, WorkListOut wo,
@@ -116,13 +118,22 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
         R2_TS_AT(tilefirst, 5);
     }
     if (R > cap) {   // the buffers were sized by a prediction that fell short: do nothing, the host sizes them exactly and re-runs
-        if (blockIdx.x == 0 && tid == 0) { wo.chunk_base[T] = 0u; wo.chunk_base[T + 1] = 0u; nparts[0] = 0u; nparts[1] = 0u; }
+        if (blockIdx.x == 0 && tid == 0) { wo.chunk_base[wo.T] = 0u; wo.chunk_base[wo.T + 1] = 0u; nparts[0] = 0u; nparts[1] = 0u; }
         return;
     }
     if (blockIdx.x == 0) return;
     if (blockIdx.x == 1) {
-        // ---- tile ranges + the render kernel's work list (arrival counters zeroed, empty tiles appended)
-        ranges_and_work_block<TFS_THREADS>(tile_count, wo);
+        // ---- tile ranges + the render kernel's work list (arrival counters zeroed, empty tiles appended); a tile's list is its
+        // slabs' lists, one after the other
+        if (SL) {
+            for (uint32_t t = tid; t < wo.T; t += TFS_THREADS) {
+                uint32_t c = 0u;
+                for (uint32_t d = 0; d < slabs.n; ++d) c += tile_count[t * slabs.n + d];
+                s_pos[t] = c;
+            }
+            __syncthreads();
+        }
+        ranges_and_work_block<TFS_THREADS>(SL ? s_pos : tile_count, wo);
         R2_TS_AT(tilefirst, 2);
         return;
     }
@@ -217,10 +228,11 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
         if (g_tt[it] != 0u) {
             const uint32_t rect = g_rect[it], key = g_key[it];
             const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
+            const uint32_t nsl = SL ? slabs.n : 1u, sl = SL ? tf_slab_of(key, slabs) : 0u;
             for (uint32_t r = 0; r < h; ++r) {
-                const uint32_t row = (y0 + r) * (uint32_t)gx + x0;
+                const uint32_t row = ((y0 + r) * (uint32_t)gx + x0) * nsl + sl;
                 for (uint32_t c = 0; c < w; ++c) {
-                    const uint32_t pos = atomicAdd(&s_pos[row + c], 1u);
+                    const uint32_t pos = atomicAdd(&s_pos[row + c * nsl], 1u);
                     pairs[pos] = make_uint2(key, g_idx[it]);
                 }
             }
@@ -581,7 +593,13 @@ TFWorkspace *tf_workspace(int dev, hipStream_t s)
 }
 
 // the thread's recent instance counts per problem size: what the prediction is made of
-struct TFHint { int P, W, H; uint32_t recent[8]; uint32_t n; bool thin; unsigned long long used; };
+struct TFHint {
+    int P, W, H;
+    uint32_t recent[8], n;
+    bool thin;
+    uint32_t kmax, kmin;    // depth-key range of the last call (the next call's slabs are laid over it)
+    unsigned long long used;
+};
 thread_local std::vector<TFHint> g_tf_hints;
 thread_local unsigned long long g_tf_hint_tick = 0;
 
@@ -596,7 +614,7 @@ TFHint *tf_hint(int P, int W, int H, bool create)
             if (g_tf_hints[i].used < g_tf_hints[lru].used) lru = i;
         g_tf_hints.erase(g_tf_hints.begin() + (long)lru);
     }
-    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false, ++g_tf_hint_tick});
+    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false, 0u, 0u, ++g_tf_hint_tick});
     return &g_tf_hints.back();
 }
 
@@ -630,13 +648,21 @@ bool tf_enabled()
            allow_dynamic_lds(reinterpret_cast<const void *>(raster_tf_sort_kernel), (int)TFK_LDS, lds_state);
 }
 
+int tf_forced_slabs()
+{
+    static const int v = [] { const char *e = getenv("R2_TF_SLABS"); return e ? atoi(e) : 0; }();
+    return (v == 1 || v == 2 || v == 4) ? v : 0;
+}
+
 }  // namespace
 
-void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin)
+void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin)
 {
     TFHint *h = tf_hint(P, W, H, true);
     h->recent[h->n++ & 7u] = num_rendered;
     h->thin = thin;
+    h->kmax = kmax;
+    h->kmin = kmin;
 }
 
 // -> num_rendered (>= 0), a negative error code, or TF_NOT_TAKEN: nothing was launched, run the general path
@@ -657,16 +683,19 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     }
     // ---- the prediction: the largest count of the thread's recent calls with this P and detector; for a P it has not rendered
     // yet (the call after a densification) the most recent call on the same detector, scaled -- same scene, more Gaussians
-    uint32_t rmax = 0;
+    uint32_t rmax = 0, kmax = 0, kmin = 0;
     bool thin_guess = false;
     if (const TFHint *hint = tf_hint(P, width, height, false); hint && hint->n != 0u) {
         for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
         thin_guess = hint->thin;
+        kmax = hint->kmax; kmin = hint->kmin;
     } else if (const TFHint *near = tf_hint_nearby(width, height)) {
         uint32_t r0 = 0;
         for (uint32_t i = 0; i < std::min(near->n, 8u); ++i) r0 = std::max(r0, near->recent[i]);
-        rmax = (uint32_t)std::min<double>((double)r0 * ((double)P / (double)near->P) * 1.1, 2.0e9);
+        const double f = (double)P / (double)near->P;
+        rmax = (uint32_t)std::min<double>((double)r0 * f * 1.1, 2.0e9);
         thin_guess = near->thin;
+        kmax = near->kmax; kmin = near->kmin;
         g_tf_seeded.fetch_add(1, std::memory_order_relaxed);
     } else {
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
@@ -682,19 +711,37 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes)
     size_t cap = (((size_t)rmax + rmax / 4 + 16384) + 65535) & ~(size_t)65535;
 
-    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, T, wgs).bytes, geometry_user);
+    // depth slabs per tile, from an ESTIMATE of the longest tile list: a dense tile holds ~8x the mean on every scene seen so far
+    // (synthetic 300k cloud: mean 1128, longest 8776; 92k trained cloud: 825 / 5856; 331k trained cloud: 3015 / 22388).  A wrong estimate costs
+    // speed only.  (The exact length reported back by the scatter kernel through the mailbox was built and measured: +0.7 us on
+    // that kernel for a decision the estimate gets right.)
+    TFSlabs slabs{1u, kmin, 0.f};
+    {
+        const double ml = 8.0 * (double)rmax / (double)T;
+        uint32_t d = 1u;
+        if (ml > (double)TF_SLAB_SPLIT_ABOVE)
+            while (d < TF_MAX_SLABS && T * d * 2u <= TF_MAX_TILES) d *= 2u;
+        if (const int f = tf_forced_slabs())
+            if (T * (size_t)f <= TF_MAX_TILES) d = (uint32_t)f;
+        if (kmax <= kmin) d = 1u;   // no key range to lay the slabs over
+        slabs.n = d;
+        slabs.scale = d > 1u ? (float)d / ((float)(kmax - kmin) + 1.0f) : 0.f;
+    }
+    const size_t TL = T * slabs.n;   // lists
+
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, TL, wgs).bytes, geometry_user);
     if (!gchunk) {
         set_error("%s: state allocation callback returned NULL", what);
         return R2_ERR_ALLOC;
     }
-    const RasterGeom geom = RasterGeom::carve(gchunk, P, T, wgs);
+    const RasterGeom geom = RasterGeom::carve(gchunk, P, TL, wgs);
     if (ws->dirty) R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));   // first use, or a call that failed half way
     ws->dirty = true;
     uint32_t *mailbox = nullptr, mailbox_seq = 0;
     int rc = host_mailbox_arm(&mailbox, &mailbox_seq);
     if (rc) return rc;
     { StageScope t(ST_RAS_PREPROCESS, s);
-    launch_raster_preprocess_tf(geom, P, grid, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
+    launch_raster_preprocess_tf(geom, P, grid, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
                                 projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, ws->ctr, s); }
     R2_HIP_TRY(hipGetLastError());
 
@@ -703,24 +750,29 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     auto enqueue = [&](size_t capacity, bool any_thin, bool render_only) -> int {
         if (!render_only) {
             char *bchunk = binningBuffer(RasterBinning::carve(nullptr, capacity).bytes, binning_user);
-            char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, capacity, false, true).bytes, image_user);
+            char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, capacity, false, TL).bytes, image_user);
             if (!bchunk || !ichunk) {
                 set_error("%s: binning/image allocation callback returned NULL", what);
                 return R2_ERR_ALLOC;
             }
             bin = RasterBinning::carve(bchunk, capacity);
-            img = RasterImage::carve(ichunk, T, N, capacity, false, true);
+            img = RasterImage::carve(ichunk, T, N, capacity, false, TL);
             uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // backward scratch (32 bytes per instance), free until then
             { StageScope t(ST_RAS_DUPLICATE, s);
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW};
-            raster_tf_scatter_kernel<<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), T * sizeof(uint32_t), s>>>(
-                P, grid.per_wg, grid.threads, gx, (uint32_t)T, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff,
-                geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,
-                (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,
-                ws->nparts); }
+#define R2_TF_SCATTER(SLB)                                                                                                        \
+            raster_tf_scatter_kernel<SLB><<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), TL * sizeof(uint32_t), s>>>(         \
+                P, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
+                geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,                                            \
+                (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,   \
+                ws->nparts)
+            if (slabs.n > 1u) R2_TF_SCATTER(true);
+            else R2_TF_SCATTER(false);
+#undef R2_TF_SCATTER
+            }
             R2_HIP_TRY(hipGetLastError());
             { StageScope t(ST_RAS_SORT, s);
-            raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (T + TFK_GROUPS - 1) / TFK_GROUPS)), dim3(TFK_THREADS), TFK_LDS, s>>>(
+            raster_tf_sort_kernel<<<dim3((unsigned)(img.NP + (TL + TFK_GROUPS - 1) / TFK_GROUPS)), dim3(TFK_THREADS), TFK_LDS, s>>>(
                 img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP, ws->nparts, pairs, bin.point_list, ws->ctr, geom.host_words,
                 (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu)); }
             R2_HIP_TRY(hipGetLastError());
@@ -755,7 +807,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     }
     ws->dirty = false;
     g_tf_taken.fetch_add(1, std::memory_order_relaxed);
-    raster_tilefirst_note(P, width, height, num_rendered, thin);
+    raster_tilefirst_note(P, width, height, num_rendered, thin, hw[DW_NMAX], ~hw[DW_NNMAX]);
     return (int)num_rendered;
 }
 

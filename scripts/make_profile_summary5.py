@@ -1,7 +1,7 @@
-"""profiles/<tag>_* from what scripts/gpu_profile4.sh left under gpurun_out/ (round 4: rocprofv3 passes over
+"""profiles/<tag>_* from what scripts/gpu_profile5.sh left under gpurun_out/ (rounds 4-5: rocprofv3 passes over
 `bench.py --headline-only`, so every kernel row is the single-view forward + backward step, + the same for the 256^3 voxel
 query alone, + the bench lines of the trained clouds and of the one-rank collective path):
-    python scripts/make_profile_summary4.py r04e "title"
+    python scripts/make_profile_summary5.py r05f "title"
 """
 import csv, json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -50,14 +50,20 @@ if os.path.exists(os.path.join(P, "%s_kernel_stats.csv" % tag)):   # (a voxel-on
                 "pmc_latest.json, which bench.py reads for `roofline.traffic` when its source hash matches); KB in the json, MB here.  "
                 "Bench lines of the same build: %s_bench.json (default run), %s_bench_driver.json (--steps 20 --warmup 5), "
                 "%s_bench_{B,C,E}.json (BASELINE configs B 50k/512^2, C 300k/560^2, E 1M/1024^2/360 views).\n\n" % (tag, tag, tag, tag, tag))
-        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) |\n|---|---|---|---|---|---|---|\n")
+        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) | VALU issue |\n|---|---|---|---|---|---|---|---|\n")
         for r in rows[:30]:
             k = short(r['Name']); p = pmc.get(k, {})
-            f.write("| `%s` | %s | %.1f | %s | %s | %s | %s |\n" % (
-                k, r['Calls'], float(r['AverageNs']) / 1e3, r['Percentage'],
+            us = float(r['AverageNs']) / 1e3
+            # share of the VALU issue slots: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles at the nominal 2.4 GHz)
+            issue = (p['SQ_INSTS_VALU'] * 2.0 / (1024.0 * us * 2400.0)) if ('SQ_INSTS_VALU' in p and us > 0) else None
+            f.write("| `%s` | %s | %.1f | %s | %s | %s | %s | %s |\n" % (
+                k, r['Calls'], us, r['Percentage'],
                 ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
                 ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
-                ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else ""))
+                ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else "",
+                ("%.2f" % issue) if issue is not None else ""))
+        f.write("\nVALU issue = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel time x 2.4 GHz): the share of the vector issue slots the "
+                "kernel uses (DESIGN.md section 4: a wave issues one VALU instruction per ~5 cycles whatever its ILP, a SIMD one per 2).\n")
         f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
                 "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  Kernels named "
                 "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
