@@ -30,7 +30,7 @@ timeout 300 python bench.py --gaussians 50000 --no-voxel --no-streams --no-batch
 timeout 300 python bench.py --detector 560 --no-voxel --no-streams --no-batched > gpurun_out/bench_${TAG}_C.json 2>/dev/null; cut -c1-160 gpurun_out/bench_${TAG}_C.json
 timeout 600 python bench.py --gaussians 1000000 --detector 1024 --views 360 --steps 300 --warmup 30 --no-voxel --no-streams --no-batched > gpurun_out/bench_${TAG}_E.json 2>/dev/null; cut -c1-160 gpurun_out/bench_${TAG}_E.json
 # one rank through the collective path (RCCL initialised, the [11 P] block all-reduced with nobody to talk to)
-R2_BENCH_FORCE_COMM=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 200 --warmup 20 --no-voxel --no-batched --no-streams --no-forward-only --no-cpu-baseline > gpurun_out/bench_${TAG}_forcecomm.json 2> gpurun_out/bench_${TAG}_forcecomm.err; cut -c1-160 gpurun_out/bench_${TAG}_forcecomm.json
+R2_BENCH_FORCE_COMM=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 1 --steps 200 --warmup 20 --no-batched --no-streams --no-forward-only --no-cpu-baseline --no-densify-pattern > gpurun_out/bench_${TAG}_forcecomm.json 2> gpurun_out/bench_${TAG}_forcecomm.err; cut -c1-160 gpurun_out/bench_${TAG}_forcecomm.json
 # C host for the ABI: A/B of the two binning chains, then the stamped build's timeline
 for E in 0 1; do R2_TILE_FIRST=$E timeout 300 scripts/cbench 300 r2_gaussian_amd/libr2hip.so > gpurun_out/cbench_${TAG}_tf$E.txt 2>&1; grep -E "BEST|STREAMS|BATCH V=4:|^voxel|raster\.|tv " gpurun_out/cbench_${TAG}_tf$E.txt; done
 [ -f r2_gaussian_amd/libr2hip_ts.so ] && timeout 100 scripts/cbench 100 r2_gaussian_amd/libr2hip_ts.so single 2>&1 | grep -E "BEST|TS " > gpurun_out/timeline_${TAG}.txt
