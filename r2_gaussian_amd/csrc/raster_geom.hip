@@ -201,8 +201,10 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 // registers through 150 lines of double-precision culling arithmetic -- kernel 25.0 us; walking rectangles of more than 8 tiles with
 // the whole wave, 64 tiles per step, here and in the scatter kernel: histogram phase 3.9 -> 4.6 us, scatter 13.5 -> 14.2 us: a wave
 // holds only a handful of such rectangles and each costs three v_readlane + a division-free index computation per step.)
-template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */>
-__global__ void __launch_bounds__(TF_THREADS_MAX) raster_preprocess_tf_kernel(
+// SHARE: more producer workgroups than CUs (clouds beyond 524k Gaussians): compiled for <= 64 VGPRs (four spilled), so that two
+// 1024-thread workgroups run side by side on a CU instead of one after the other; the plain instantiation (68 VGPRs) has its CU to itself.
+template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */, bool SHARE>
+__global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preprocess_tf_kernel(
     int P, uint32_t per_wg, const TFSlabs slabs, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
@@ -817,8 +819,15 @@ int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, 
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
+    const bool share = (int)grid.wgs > device_cu_count() && grid.threads > TF_THREADS_MAX / 2;
 #define R2_TF_PRE(SLB)                                                                                                            \
-    raster_preprocess_tf_kernel<SLB><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>(          \
+    if (share)                                                                                                                        \
+        raster_preprocess_tf_kernel<SLB, true><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>( \
+            P, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,    \
+            tan_fovy, focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect,  \
+            g.tf_wgoff, g.tf_wgmm, ctr);                                                                                                \
+    else                                                                                                                              \
+    raster_preprocess_tf_kernel<SLB, false><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>(   \
         P, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, \
         focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,  \
         g.tf_wgmm, ctr)

@@ -106,6 +106,10 @@ inline TFGrid tf_grid(int P, int cus)
     const unsigned long long k = ((unsigned long long)P + c * cap - 1) / (c * cap);            // workgroups per CU
     unsigned long long per = ((unsigned long long)P + k * c - 1) / (k * c);
     if (per < TF_PER_WG_MIN) per = TF_PER_WG_MIN;
+    // beyond one workgroup per CU (> 524k Gaussians) the kernels run in rounds anyway, and rounds of plain one-Gaussian-per-thread
+    // workgroups overlap their phases better than half as many doing everything twice (1M Gaussians / 1024^2: scatter 50.6 us with
+    // 977 workgroups of 1024, 62 us with 512 of 1954; the preprocess 51 vs 47 -- measured, round 5)
+    if (k > 1) per = TF_THREADS_MAX;
     TFGrid g;
     g.per_wg = (uint32_t)per;
     g.wgs = (uint32_t)(((unsigned long long)P + per - 1) / per);
