@@ -1,28 +1,36 @@
-// raster_tilefirst.hip -- tile-first binning of the X-ray rasterizer (round 4): the reference's
+// raster_tilefirst.hip -- tile-first binning of the X-ray rasterizer (rounds 4-5): the reference's
 // duplicateWithKeys -> SortPairs(tile | depth) -> identifyTileRanges (RAS/rasterizer_impl.cu:70-138,275-316) as
-//     1. raster_preprocess_tf_kernel (raster_geom.hip)   preprocess + per-tile instance counts (LDS histogram per workgroup, one
-//                                                        returning global atomic per (workgroup, tile)); the totals stay in the
-//                                                        counters
-//     2. raster_tf_scatter_kernel                        every instance straight into its TILE's segment of the list, as a
-//                                                        (depth key, Gaussian id) pair, in arbitrary order inside the segment;
-//                                                        workgroup 0 posts the totals to the host and builds tile ranges, the
-//                                                        render work list and the sort parts
-//     3. raster_tf_sort_kernel                           one workgroup per tile (long lists: several, by depth range) sorts its
-//                                                        segment by (depth key, id) in LDS and writes point_list
+//     1. raster_preprocess_tf_kernel (raster_geom.hip)   preprocess + per-list instance counts (LDS histogram per workgroup, one
+//                                                        returning global atomic per (workgroup, list)); the totals stay in the
+//                                                        counters.  One workgroup per CU, up to two Gaussians per thread (tf_grid)
+//     2. raster_tf_scatter_kernel                        every instance straight into its LIST's segment, as a (depth key,
+//                                                        Gaussian id) pair, in arbitrary order inside the segment; three service
+//                                                        workgroups meanwhile post the totals to the host and build tile ranges,
+//                                                        the render work list and the sort parts
+//     3. raster_tf_sort_kernel                           one 256-thread group per short list, one workgroup per long one (very
+//                                                        long ones: several, by depth range) sorts its segment by (depth key, id)
+//                                                        in LDS and writes point_list
+// list = tile, or tile x depth slab when the lists are long (TFSlabs, raster_state.hpp).
 // A stable sort by tile followed by a sort of every tile's entries on (depth bits, id) IS the reference's (tile | depth) order
 // with its tie rule: point_list and ranges are bit-identical to the global-depth-order chain (raster_api.hip), which stays as
-// the general path (first call of a size, batched views, debug mode, grids of more than 4096 tiles).
+// the general path (first call on a detector size, batched views, debug mode, grids of more than 4096 tiles).
 //
 // Why (profiles/r03e_step_timeline.md): the global depth order costs the forward six launches -- zero-fill,
 // preprocess with one 64-bit bucket atomic per Gaussian, dual scan x 2, place, rank -- before a single instance is emitted, and
 // every launch boundary on this part is 3-5 us.  Here the forward is preprocess -> scatter -> sort -> render: no zero-fill (the
-// counters are self-resetting), no scan kernel (every scatter workgroup scans the <= 4096 tile counts itself), no radix pass.
+// counters are self-resetting), no scan kernel (every scatter workgroup scans the <= 4096 list counts itself), no radix pass.
+// Round 5 (DESIGN.md section 4 has the stamps): these kernels are ONE round of workgroups each, so their time is the life of the
+// slowest workgroup plus whatever follows it -- hence one producer workgroup per CU, no epilogue in the preprocess (the scatter's
+// workgroup 0 posts the totals), the scatter's serial jobs on workgroups of their own.  The two-kernel form of this chain (no
+// scatter: producers write their own instances grouped by list, the sort gathers a list from ~300 runs) was built and measured
+// slower: profiles/experiments/r05_tilefirst_two_kernel_chain.patch.
 //
 // The host round trip.  num_rendered sizes the binning / image state (the reference's D2H, RAS/rasterizer_impl.cu:279).  The old
 // chain hides it behind place + rank; here nothing is left to hide it behind, so the two buffers are sized by a PREDICTION (the
-// largest count of the thread's recent calls with this P, + 25 %) and kernels 2-4 are enqueued at once; they read the true count
-// on the device and do nothing when it exceeds the prediction, in which case the host -- which reads the count from the mailbox
-// as before -- sizes the buffers exactly and enqueues them again.  Results never depend on the prediction.
+// largest count of the thread's recent calls with this P, + 25 %; a P it has not rendered yet -- every densification -- is seeded
+// from its last call on the same detector) and kernels 2-4 are enqueued at once; they read the true count on the device and do
+// nothing when it exceeds the prediction, in which case the host -- which reads the count from the mailbox as before -- sizes the
+// buffers exactly and enqueues them again.  Results never depend on the prediction.
 // What must survive from forward to backward sits at prediction-independent offsets (RasterBinning::carve).
 #include "raster_state.hpp"
 
