@@ -36,6 +36,7 @@ SOURCES = {
     "voxel_render.hip": FAST,
     "voxel_api.hip": FAST,
     "voxel_small.hip": FAST,
+    "voxel_sticks.hip": FAST,
     "knn.hip": EXACT,
     "loss_ops.hip": FAST,
     "densify_ops.hip": EXACT,

@@ -336,5 +336,6 @@ extern "C" void r2_thread_release(void)
 {
     r2::raster_tilefirst_release();
     r2::voxel_small_release();
+    r2::voxel_sticks_release();
     r2::host_words_release();
 }

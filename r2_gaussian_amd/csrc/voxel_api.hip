@@ -62,19 +62,34 @@ extern "C" int r2_voxel_forward(
         }
     }
 
+    // large grids (> 4096 tiles, e.g. the 256^3 query): stick-first binning, no global sort (voxel_sticks.hip)
+    bool preprocessed = false;   // that chain left after its scan (a list too long for it): the preprocess has run, un-hinted
+    if (!debug) {
+        const int st = voxel_forward_sticks(binningBuffer, binning_user, imageBuffer, image_user, geom, v, P, means3D, opacities, scales,
+                                            scale_modifier, rotations, cov3D_precomp, out_volume, radii_x, radii_y, radii_z, s);
+        if (st == VOX_STICKS_FALLBACK) {
+            preprocessed = true;
+        } else if (st != VOX_STICKS_NOT_TAKEN) {
+            host_mark_forward_end();
+            return st;
+        }
+    }
+
     // binning, first half (see raster_api.hip): order of the Gaussians by the bits of world z (the reference's low sort
     // word, Q10) + instance offsets in that order; hinted / un-hinted bucket sort, radix fallback
     int rc = depth_order_prepare(geom.dorder_temp, geom.dorder_bytes, (size_t)P, s);
     if (rc) return rc;
     uint32_t *host_words = geom.host_words;
     DepthHint hint;
-    const bool hinted = depth_hint_lookup(1, (size_t)P, &hint);
+    const bool hinted = !preprocessed && depth_hint_lookup(1, (size_t)P, &hint);
     const uint32_t pre_wgs = (uint32_t)((P + 255) / 256);
     DepthReg reg{};
     if (hinted) reg = depth_order_reg(geom.dorder_temp, (size_t)P, hint);
-    { StageScope t(ST_VOX_PREPROCESS, s);
-    launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
-                            radii_y, radii_z, reg, true, s); }
+    if (!preprocessed) {
+        StageScope t(ST_VOX_PREPROCESS, s);
+        launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x,
+                                radii_y, radii_z, reg, true, s);
+    }
     R2_STAGE_CHECK(debug, s, "preprocess");
     uint32_t hw[DW_COUNT] = { 0 };
     if (hinted) {

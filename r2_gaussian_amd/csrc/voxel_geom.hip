@@ -156,9 +156,11 @@ __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg, uint4 *__restrict__ cube)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg, uint4 *__restrict__ cube,
+    uint32_t *__restrict__ zero16)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (zero16 != nullptr && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;   // the stick chain's counters (voxel_sticks.hip)
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P)
@@ -519,12 +521,12 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            bool store_cov3D, hipStream_t s)
+                            bool store_cov3D, hipStream_t s, uint32_t *zero16)
 {
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
                                                                         radii_z, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr,
-                                                                        g.tiles_touched, g.ext, reg, g.cube);
+                                                                        g.tiles_touched, g.ext, reg, g.cube, zero16);
     return 0;
 }
 

@@ -45,6 +45,33 @@ __device__ __forceinline__ bool needs_exact_slab3(float D2, float F2, float L, f
     return !(smax > 0.f && need <= smax) || !(hx < 3.0e38f);
 }
 
+// Workspace of the stick-first binning chain (voxel_sticks.hip), part of the geometry state: 16 bytes per Gaussian + 150 KB.
+constexpr uint32_t VS_MAX_LISTS = 4096;     // lists (sticks of 2^shift consecutive tiles) per call: one LDS histogram
+constexpr uint32_t VS_PRODUCER = 1024;      // Gaussians per producer workgroup
+struct VoxelSticks {
+    uint32_t *ctr;       // [16]  {total (64 bit: visible << 40 | instances), longest list, scan workgroups done, big lists, short lists}
+    uint32_t *totals;    // [VS_MAX_LISTS] instances per list
+    uint32_t *wgtot;     // [NW]  instances per producer workgroup
+    uint4 *big, *small;  // [VS_MAX_LISTS] each: the sort kernel's work lists {list, 0, first instance, instances}
+    uint32_t *H;         // [NW][stride] instances per (producer workgroup, list) -> after the scan: exclusive prefix over the workgroups
+    size_t NW;
+    size_t bytes;
+    static VoxelSticks carve(char *chunk, int P)
+    {
+        VoxelSticks t;
+        Bump b(chunk);
+        t.NW = ((size_t)(P > 0 ? P : 1) + VS_PRODUCER - 1) / VS_PRODUCER;
+        t.ctr = b.take<uint32_t>(16);
+        t.totals = b.take<uint32_t>(VS_MAX_LISTS);
+        t.wgtot = b.take<uint32_t>(t.NW);
+        t.big = b.take<uint4>(VS_MAX_LISTS);
+        t.small = b.take<uint4>(VS_MAX_LISTS);
+        t.H = b.take<uint32_t>(t.NW * VS_MAX_LISTS);
+        t.bytes = b.total();
+        return t;
+    }
+};
+
 struct VoxelGeom {
     float4 *rec;              // [3P] {x,y,z (voxel units), opacity} {a2,b2,c2,d2} {e2,f2,L,kz}: inverse covariance
                               //      (xx,xy,xz,yy,yz,zz) pre-scaled by -log2e/2 (diagonal) or -log2e (off-diagonal),
@@ -68,6 +95,8 @@ struct VoxelGeom {
     size_t dorder_bytes;
     char *psort_temp;
     size_t psort_bytes;
+    char *stick_temp;         // VoxelSticks
+    size_t stick_bytes;
     size_t bytes;
     static VoxelGeom carve(char *chunk, int P)
     {
@@ -91,6 +120,8 @@ struct VoxelGeom {
         g.host_words = chunk ? depth_order_words(g.dorder_temp, (size_t)P) : nullptr;
         g.psort_bytes = sort_temp_bytes((size_t)P);   // radix fallback of the depth order
         g.psort_temp = b.take<char>(g.psort_bytes);
+        g.stick_bytes = VoxelSticks::carve(nullptr, P).bytes;
+        g.stick_temp = b.take<char>(g.stick_bytes);
         g.bytes = b.total();
         return g;
     }
@@ -162,7 +193,7 @@ struct VoxelGrid {
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            bool store_cov3D, hipStream_t s);
+                            bool store_cov3D, hipStream_t s, uint32_t *zero16 = nullptr /* 16 words zeroed on the way */);
 // small grids (<= 64 tiles): preprocess + survivor list (voxel_geom.hip), per-tile lists from it (voxel_small.hip)
 int launch_voxel_preprocess_small(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                                   float scale_modifier, const float *rotations, const float *opacities,
@@ -182,6 +213,16 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
                         const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                         const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
+// large grids (more than 4096 tiles, e.g. the 256^3 query): stick-first binning (voxel_sticks.hip).
+// -> num_rendered (>= 0), a negative R2_ERR_* code, VOX_STICKS_NOT_TAKEN (nothing was launched: run the general pipeline) or
+// VOX_STICKS_FALLBACK (the preprocess has run, without depth registration: continue with the general pipeline's un-hinted branch)
+constexpr int VOX_STICKS_NOT_TAKEN = -1001, VOX_STICKS_FALLBACK = -1002;
+constexpr uint32_t VOX_STICKS_MARK = 0x571Cu;   // DW_USER word of a state produced by that chain (introspection / tests)
+void voxel_sticks_release();   // the calling thread's notes about that chain (r2_thread_release)
+int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
+                         const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
+                         const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s, uint2 *zero_ranges = nullptr, size_t zero_T = 0);
 // the seven gradient arrays of the voxelizer backward, for a kernel that zero-fills them

@@ -1,0 +1,663 @@
+// voxel_sticks.hip -- stick-first binning of the voxelizer's LARGE grids (round 5): the reference's duplicateWithKeys ->
+// SortPairs(tile | z bits) -> identifyTileRanges (VOX/voxelizer_impl.cu:54-128,244-287) for grids of more than 4096 tiles (the 256^3
+// query of test.py:105-112 has 32 768) without a global sort.
+//
+// Why.  The general chain (voxel_api.hip) orders the Gaussians by their z bits (five launches), emits the instances in that order
+// and sorts them by their 15-bit tile id with two 8-bit radix passes (six launches) before the ranges and the work list (three):
+// seventeen launches and ~185 us around a 343 us render at 300k Gaussians / 256^3 (profiles/r05f_voxel256_summary.md).  The
+// rasterizer's tile-first chain (raster_tilefirst.hip) does not carry over as it is: 32 768 tile counters do not fit one LDS
+// histogram, and one returning global atomic per (workgroup, tile) is 10^6 atomics here (the Gaussians of a workgroup are spread
+// over the whole volume).  So:
+//   * a LIST is a STICK of 2^shift consecutive tile ids (8 tiles along x at 256^3): <= 4096 lists, one LDS histogram;
+//   * the per-(workgroup, list) counts go to memory with plain stores (16 KB per workgroup of 1024 Gaussians) and a column scan
+//     turns them into offsets -- no global atomics except one per workgroup for the call's totals;
+//   * every instance is then written straight into its list's segment as (z bits, id | tile-in-stick << 29), in arbitrary order;
+//   * one workgroup (or a 256-thread quarter of one) per list sorts its segment in LDS by (tile-in-stick, z bits, id) -- the
+//     bucket sort of raster_tilefirst.hip with the buckets divided among the stick's tiles -- and writes point_list, the
+//     per-instance tile ids and the ranges of its tiles.
+// Sorting every list by (tile, z bits, id) IS the reference's (tile | z bits) order with its tie rule (emission order = id
+// order): point_list and ranges are bit-identical to the general chain's, which stays as the path of debug mode, of grids of up
+// to 4096 tiles, and of scenes with a stick list longer than one workgroup sorts (trained clouds with Gaussians of many voxels:
+// the chain notices after its scan, continues on the general chain's un-hinted branch -- the preprocess is not repeated -- and
+// the thread remembers the (P, grid) for which that happened).
+//
+//     1. voxel_preprocess_kernel (voxel_geom.hip)   unchanged, no depth registration; zeroes the chain's counters on the way
+//     2. vox_stick_count_kernel                      LDS histogram of the workgroup's instances over the lists -> H[wg][list]
+//     3. vox_stick_scan_kernel                       exclusive prefix of every column of H, list totals, longest list; the last
+//                                                    workgroup posts {num_rendered, longest list} to the host mailbox
+//        (the host sizes the binning / image state: the reference's D2H, VOX/voxelizer_impl.cu:248)
+//     4. vox_stick_scatter_kernel                    instances -> list segments; first instance of every Gaussian (the backward's
+//                                                    moment rows); workgroup 0 builds the sort kernel's lists
+//     5. vox_stick_sort_kernel                       per-list sort, point_list, tiles, ranges
+//     6. launch_build_work (binning.hip)             the render kernel's work list from the ranges, as in the general chain
+#include "voxel_state.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <vector>
+
+namespace r2 {
+
+namespace {
+
+constexpr int VS_THREADS = (int)VS_PRODUCER;
+constexpr uint32_t VS_MAX_SHIFT = 3;       // tiles per stick = 2^shift <= 8: three bits above the 29-bit id
+constexpr uint32_t VS_ID_BITS = 29;
+constexpr uint32_t VS_ID_MASK = (1u << VS_ID_BITS) - 1u;
+
+// the sort kernel: 1024-thread workgroups of two kinds, as in raster_tilefirst.hip ("big": one list of up to VSK_BIG_CAP
+// entries; "group": four lists of up to VSK_SMALL_CAP entries, one per 256 threads, in lockstep)
+constexpr int VSK_THREADS = 1024;
+constexpr int VSK_GROUPS = VSK_THREADS / 256;
+constexpr uint32_t VSK_SMALL_CAP = 1536, VSK_SMALL_PER = 6, VSK_SMALL_BINS = 1024;
+constexpr uint32_t VSK_BIG_CAP = 8192, VSK_BIG_PER = 8, VSK_BIG_BINS = 2048;
+constexpr size_t VSK_LDS = VSK_BIG_CAP * sizeof(unsigned long long) + (VSK_BIG_BINS + 1) * sizeof(uint32_t);
+static_assert(VSK_GROUPS * VSK_SMALL_CAP * sizeof(unsigned long long) + VSK_GROUPS * (VSK_SMALL_BINS + 1) * sizeof(uint32_t) <= VSK_LDS,
+              "the groups fit the big layout");
+static_assert(VSK_SMALL_PER * 256 == VSK_SMALL_CAP && VSK_BIG_PER * VSK_THREADS == VSK_BIG_CAP, "entries per thread");
+static_assert((VSK_SMALL_BINS >> VS_MAX_SHIFT) >= 64, "enough buckets per tile of a stick");
+
+struct VSCounters {
+    unsigned long long total;   // visible Gaussians << 40 | instances
+    uint32_t maxlist;           // longest list
+    uint32_t scan_done;         // scan workgroups that have finished
+    uint32_t nparts[2];         // big lists, short lists
+    uint32_t pad[10];
+};
+static_assert(sizeof(VSCounters) == 64, "the preprocess kernel zeroes sixteen words");
+
+struct Cube { uint32_t lx, ly, lz, rw, rh, rd; };
+__device__ __forceinline__ Cube cube_of(const uint4 c, uint32_t tt)
+{
+    Cube q;
+    q.lx = c.y & 0xFFFFu; q.ly = c.y >> 16; q.lz = c.z & 0xFFFFu; q.rw = c.z >> 16; q.rh = c.w;
+    q.rd = tt / (q.rw * q.rh);   // tiles_touched = rw * rh * rd
+    return q;
+}
+
+// ---- 2. per-(workgroup, list) instance counts
+__global__ void __launch_bounds__(VS_THREADS) vox_stick_count_kernel(
+    int P, uint32_t gx, uint32_t gy, uint32_t sh, uint32_t stride, const uint32_t *__restrict__ tiles_touched,
+    const uint4 *__restrict__ cube, uint32_t *__restrict__ H, uint32_t *__restrict__ wgtot, VSCounters *__restrict__ ctr)
+{
+    extern __shared__ uint32_t s_hist[];   // [stride]
+    __shared__ uint32_t s_w[2][VS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < stride; i += VS_THREADS) s_hist[i] = 0u;
+    __syncthreads();
+    const uint32_t g = blockIdx.x * (uint32_t)VS_THREADS + (uint32_t)tid;
+    const uint32_t tt = g < (uint32_t)P ? tiles_touched[g] : 0u;
+    if (tt != 0u) {
+        const Cube q = cube_of(cube[g], tt);
+        const uint32_t nsub = 1u << sh;
+        for (uint32_t z = 0; z < q.rd; ++z)
+            for (uint32_t y = 0; y < q.rh; ++y) {
+                const uint32_t t0 = ((q.lz + z) * gy + q.ly + y) * gx + q.lx, t1 = t0 + q.rw - 1u;
+                for (uint32_t l = t0 >> sh; l <= (t1 >> sh); ++l) {   // the row's tiles, stick by stick
+                    const uint32_t a = max(t0, l << sh), b = min(t1, (l << sh) + nsub - 1u);
+                    atomicAdd(&s_hist[l], b - a + 1u);
+                }
+            }
+    }
+    // the workgroup's totals: one 64-bit atomic for the call's, one plain word for the scatter kernel's row offsets
+    uint32_t sum = tt, vis = tt != 0u ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += (uint32_t)__shfl_xor(sum, d);
+        vis += (uint32_t)__shfl_xor(vis, d);
+    }
+    if (lane == 0) { s_w[0][wave] = sum; s_w[1][wave] = vis; }
+    __syncthreads();   // (also: the histogram is complete)
+    if (tid == 0) {
+        uint32_t S = 0, V = 0;
+#pragma unroll
+        for (int w = 0; w < VS_THREADS / 64; ++w) { S += s_w[0][w]; V += s_w[1][w]; }
+        wgtot[blockIdx.x] = S;
+        atomicAdd(&ctr->total, ((unsigned long long)V << 40) | (unsigned long long)S);
+    }
+    uint32_t *__restrict__ row = H + (size_t)blockIdx.x * stride;
+    for (uint32_t i = tid; i < stride; i += VS_THREADS) row[i] = s_hist[i];
+}
+
+// ---- 3. column scan (the layout of rs_scan_kernel, radix_sort.hip: a workgroup owns 32 consecutive lists, its 32 thread rows
+// split the producer workgroups, every access is a full 128-byte row segment) + the call's totals for the host
+constexpr int VSS_THREADS = 1024, VSS_LISTS = 32, VSS_ROWS = VSS_THREADS / VSS_LISTS, VSS_BATCH = 16;
+__global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
+    uint32_t *__restrict__ H, uint32_t rows, uint32_t stride, uint32_t *__restrict__ totals, VSCounters *__restrict__ ctr,
+    uint32_t *__restrict__ words, uint32_t *__restrict__ mailbox, uint32_t seq)
+{
+    __shared__ uint32_t part[VSS_ROWS][VSS_LISTS];
+    const uint32_t dl = threadIdx.x % VSS_LISTS, row = threadIdx.x / VSS_LISTS;
+    const uint32_t d = blockIdx.x * VSS_LISTS + dl;   // < stride (a multiple of 32)
+    const uint32_t per = (rows + VSS_ROWS - 1) / VSS_ROWS;
+    const uint32_t t0 = min(rows, row * per), t1 = min(rows, t0 + per);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
+        uint32_t v[VSS_BATCH];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u) sum += (t + (uint32_t)u < t1) ? v[u] : 0u;
+    }
+    part[row][dl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int r = 0; r < VSS_ROWS; ++r) {
+        const uint32_t v = part[r][dl];
+        if ((uint32_t)r < row) run += v;
+        total += v;
+    }
+    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
+        uint32_t v[VSS_BATCH];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u)
+            if (t + (uint32_t)u < t1) {
+                H[(size_t)(t + (uint32_t)u) * stride + d] = run;
+                run += v[u];
+            }
+    }
+    if (row == 0) totals[d] = total;
+    // the longest list of the call; the last workgroup to get here tells the host
+    if (threadIdx.x < 64) {
+        uint32_t m = row == 0 ? total : 0u;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor(m, s));
+        if (threadIdx.x == 0) {
+            atomicMax(&ctr->maxlist, m);
+            __threadfence();
+            const uint32_t done = atomicAdd(&ctr->scan_done, 1u);
+            if (done == gridDim.x - 1u) {
+                __threadfence();
+                const uint32_t ml = atomicMax(&ctr->maxlist, 0u);
+                const unsigned long long tot = atomicAdd(&ctr->total, 0ull);
+                const unsigned long long r40 = tot & ((1ull << 40) - 1ull);
+                const uint32_t R = r40 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r40;
+                // DW_NVIS = 0: `order` will hold all P ids (the geometry backward walks all of it)
+                words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = VOX_STICKS_MARK; words[DW_PMAX] = ml;
+                words[DW_PNMAX] = 0u; words[DW_NMAX] = 0u; words[DW_NNMAX] = 0u; words[DW_NVIS] = 0u;
+                mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = VOX_STICKS_MARK; mailbox[DW_PMAX] = ml;
+                mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = 0u; mailbox[DW_NNMAX] = 0u; mailbox[DW_NVIS] = (uint32_t)(tot >> 40);
+                __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
+// ---- 4. scatter.  Workgroup 0 does not scatter: it builds the sort kernel's two lists from the list totals and gives the
+// tiles of empty lists their (0, 0) ranges (the reference's memset).
+__global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
+    int P, uint32_t gx, uint32_t gy, uint32_t T, uint32_t sh, uint32_t NL, uint32_t stride,
+    const uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ cube, const uint32_t *__restrict__ depth_key,
+    uint32_t *__restrict__ first, uint32_t *__restrict__ order, const uint32_t *__restrict__ H,
+    const uint32_t *__restrict__ totals, const uint32_t *__restrict__ wgtot, uint2 *__restrict__ pairs,
+    uint2 *__restrict__ ranges, uint4 *__restrict__ big, uint4 *__restrict__ small, uint32_t *__restrict__ nparts)
+{
+    extern __shared__ uint32_t s_pos[];   // [stride] start of the list's segment + this workgroup's offset in it, bumped per instance
+    __shared__ uint32_t s_wsum[3][VS_THREADS / 64], s_carry[3], s_base;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0) {
+        if (tid < 3) s_carry[tid] = 0u;
+        __syncthreads();
+        for (uint32_t base = 0; base < NL; base += VS_THREADS) {
+            const uint32_t l = base + (uint32_t)tid;
+            const uint32_t c = l < NL ? totals[l] : 0u;
+            const uint32_t nb = c > VSK_SMALL_CAP ? 1u : 0u;
+            const uint32_t ns = (c != 0u && nb == 0u) ? 1u : 0u;
+            uint32_t i0 = c, i1 = nb, i2 = ns;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t u0 = __shfl_up(i0, d), u1 = __shfl_up(i1, d), u2 = __shfl_up(i2, d);
+                if (lane >= d) { i0 += u0; i1 += u1; i2 += u2; }
+            }
+            if (lane == 63) { s_wsum[0][wave] = i0; s_wsum[1][wave] = i1; s_wsum[2][wave] = i2; }
+            __syncthreads();
+            uint32_t o0 = 0, o1 = 0, o2 = 0;
+            for (int w = 0; w < wave; ++w) { o0 += s_wsum[0][w]; o1 += s_wsum[1][w]; o2 += s_wsum[2][w]; }
+            const uint32_t start = s_carry[0] + o0 + i0 - c, bstart = s_carry[1] + o1 + i1 - nb, sstart = s_carry[2] + o2 + i2 - ns;
+            if (nb) big[bstart] = make_uint4(l, 0u, start, c);
+            if (ns) small[sstart] = make_uint4(l, 0u, start, c);
+            if (l < NL && c == 0u)
+                for (uint32_t sub = 0; sub < (1u << sh); ++sub)
+                    if ((l << sh) + sub < T) ranges[(l << sh) + sub] = make_uint2(0u, 0u);
+            __syncthreads();
+            if (tid == VS_THREADS - 1) { s_carry[0] = start + c; s_carry[1] = bstart + nb; s_carry[2] = sstart + ns; }
+            __syncthreads();
+        }
+        if (tid == 0) { nparts[0] = s_carry[1]; nparts[1] = s_carry[2]; }
+        return;
+    }
+    const uint32_t wg = blockIdx.x - 1u;
+    // this thread's Gaussian: requested now, used after the scans (everything here was written by earlier kernels on other XCDs)
+    const uint32_t g = wg * (uint32_t)VS_THREADS + (uint32_t)tid;
+    const bool own = g < (uint32_t)P;
+    const uint32_t gc = min(g, (uint32_t)P - 1u);
+    uint32_t tt = tiles_touched[gc];
+    const uint4 cb = cube[gc];
+    const uint32_t key = depth_key[gc];
+    tt = own ? tt : 0u;
+    // rows of producer workgroups before this one (the first instance of its first Gaussian)
+    uint32_t pre = 0;
+    for (uint32_t w = tid; w < wg; w += VS_THREADS) pre += wgtot[w];
+    // ---- exclusive scan of the list totals (every workgroup for itself: <= 16 KB, cheaper than a launch boundary)
+    const uint32_t *__restrict__ my_off = H + (size_t)wg * stride;
+    constexpr int MAXQ = (int)(VS_MAX_LISTS / VS_THREADS);
+    uint32_t offs[MAXQ];
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const uint32_t t = min((uint32_t)(q * VS_THREADS + tid), stride - 1u);
+        offs[q] = my_off[t];
+        s_pos[t] = totals[t];   // (clamped duplicates store the same value)
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += (uint32_t)__shfl_xor(pre, d);
+    if (lane == 0) s_wsum[1][wave] = pre;
+    __syncthreads();
+    const uint32_t ipt = (stride + VS_THREADS - 1) / VS_THREADS;
+    const uint32_t t0 = min(stride, (uint32_t)tid * ipt), t1 = min(t0 + ipt, stride);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; ++t) sum += s_pos[t];
+    uint32_t incl = sum, itt = tt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d), ut = __shfl_up(itt, d);
+        if (lane >= d) { incl += up; itt += ut; }
+    }
+    if (lane == 63) { s_wsum[0][wave] = incl; s_wsum[2][wave] = itt; }
+    if (tid == 0) {
+        uint32_t b = 0;
+#pragma unroll
+        for (int w = 0; w < VS_THREADS / 64; ++w) b += s_wsum[1][w];
+        s_base = b;
+    }
+    __syncthreads();
+    uint32_t run = incl - sum, frun = itt - tt;
+    for (int w = 0; w < wave; ++w) { run += s_wsum[0][w]; frun += s_wsum[2][w]; }
+    for (uint32_t t = t0; t < t1; ++t) {
+        const uint32_t c = s_pos[t];
+        s_pos[t] = run;
+        run += c;
+    }
+    const uint32_t firstv = s_base + frun;
+    __syncthreads();
+    // ... + where this workgroup's instances start inside each segment
+#pragma unroll
+    for (int q = 0; q < MAXQ; ++q) {
+        const uint32_t t = (uint32_t)(q * VS_THREADS + tid);
+        if (t < stride) s_pos[t] += offs[q];
+    }
+    __syncthreads();
+    // what the backward needs per Gaussian: its run of moment rows (any disjoint assignment serves: here id order) and a list of
+    // the ids to walk (all of them: DW_NVIS = 0)
+    if (own) order[g] = g;
+    if (tt != 0u) {
+        first[g] = firstv;
+        reinterpret_cast<uint32_t *>(cube + g)[0] = firstv;
+        // ---- every instance of this Gaussian
+        const Cube q = cube_of(cb, tt);
+        const uint32_t smask = (1u << sh) - 1u;
+        for (uint32_t z = 0; z < q.rd; ++z)
+            for (uint32_t y = 0; y < q.rh; ++y) {
+                const uint32_t t0r = ((q.lz + z) * gy + q.ly + y) * gx + q.lx;
+                for (uint32_t x = 0; x < q.rw; ++x) {
+                    const uint32_t tile = t0r + x;
+                    const uint32_t pos = atomicAdd(&s_pos[tile >> sh], 1u);
+                    pairs[pos] = make_uint2(key, g | ((tile & smask) << VS_ID_BITS));
+                }
+            }
+    }
+}
+
+// ---- 5. per-list sort
+__device__ __forceinline__ unsigned long long vs_pack(const uint2 e)
+{
+    return ((unsigned long long)(e.y >> VS_ID_BITS) << 61) | ((unsigned long long)e.x << VS_ID_BITS) | (unsigned long long)(e.y & VS_ID_MASK);
+}
+
+// key range of a group's entries -> every thread of the group: (kmin, kmax) over all keys, pmax = largest key with a clear sign
+// bit, nmin = smallest key with the sign bit set; two workgroup barriers
+template <int NT>
+__device__ __forceinline__ void vs_group_range(uint32_t &kmin, uint32_t &kmax, uint32_t &pmax, uint32_t &nmin,
+                                               uint32_t (*s_mm)[VSK_THREADS / 64], int lane, int wave, int w0)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, (uint32_t)__shfl_xor(kmin, d));
+        kmax = max(kmax, (uint32_t)__shfl_xor(kmax, d));
+        pmax = max(pmax, (uint32_t)__shfl_xor(pmax, d));
+        nmin = min(nmin, (uint32_t)__shfl_xor(nmin, d));
+    }
+    __syncthreads();
+    if (lane == 0) { s_mm[0][wave] = kmin; s_mm[1][wave] = kmax; s_mm[2][wave] = pmax; s_mm[3][wave] = nmin; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        kmin = min(kmin, s_mm[0][w0 + w]); kmax = max(kmax, s_mm[1][w0 + w]);
+        pmax = max(pmax, s_mm[2][w0 + w]); nmin = min(nmin, s_mm[3][w0 + w]);
+    }
+    // (the same in every lane of a wave: scalar registers -- the sort below runs at the 64-VGPR limit)
+    kmin = __builtin_amdgcn_readfirstlane(kmin); kmax = __builtin_amdgcn_readfirstlane(kmax);
+    pmax = __builtin_amdgcn_readfirstlane(pmax); nmin = __builtin_amdgcn_readfirstlane(nmin);
+}
+
+// mine[u] (entry u * NT + gtid of the list's cnt entries, in registers) -> its sorted position by (tile in stick, z bits, id).
+// One-level bucket sort as in raster_tilefirst.hip (tf_sort_group): the BINS buckets are divided among the stick's 2^sh tiles,
+// and inside a tile laid linearly over the list's key range.  The keys are raw float bits of world z, compared as unsigned
+// (quirk Q10: negative z after positive): a list that straddles z = 0 holds two clusters 2^31 apart, so the sign-bit class is
+// first moved down to sit right behind the other one (monotone: the order of the buckets is the order of the keys, whatever the
+// distribution; position = bucket base + rank inside the bucket by the whole 64-bit entry, exact).
+// The barriers are the WORKGROUP's: every group of the workgroup calls this together.
+template <int NT, uint32_t PER, uint32_t BINS>
+__device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], unsigned long long *s_a, uint32_t *s_bin,
+                                              uint32_t *s_wsum, int gtid, int lane, int wave, int w0, uint32_t cnt, uint32_t kmin,
+                                              uint32_t kmax, uint32_t pmax, uint32_t nmin, uint32_t sh, uint32_t list, uint32_t T,
+                                              uint32_t start, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
+                                              uint2 *__restrict__ ranges)
+{
+    const uint32_t BPS = BINS >> sh;   // buckets per tile of the stick
+    const bool both = kmin < 0x80000000u && kmax >= 0x80000000u;
+    const uint32_t shift = both ? nmin - pmax : 0u;
+    const uint32_t umin = kmin, umax = kmax >= 0x80000000u ? kmax - shift : kmax;
+    const float scale = umax > umin ? (float)(BPS - 1u) / (float)(umax - umin) : 0.f;
+    for (uint32_t i = gtid; i <= BINS; i += NT) s_bin[i] = 0u;
+    __syncthreads();
+    // (64 VGPRs keep two of these workgroups on a CU: bucket and ticket share a word, and so do a bucket's base and length)
+    static_assert(BINS <= (1u << 16) && PER * NT <= (1u << 16), "two 16-bit halves");
+    uint32_t bin_ticket[PER];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        bin_ticket[u] = 0u;
+        if (i < cnt) {
+            const uint32_t key = (uint32_t)(mine[u] >> VS_ID_BITS), sub = (uint32_t)(mine[u] >> 61);
+            const uint32_t uk = key >= 0x80000000u ? key - shift : key;
+            const uint32_t bin = sub * BPS + min((uint32_t)((float)(uk - umin) * scale), BPS - 1u);
+            bin_ticket[u] = bin | (atomicAdd(&s_bin[bin], 1u) << 16);
+        }
+    }
+    __syncthreads();
+    {
+        constexpr uint32_t BPT = BINS / NT;
+        static_assert(BINS % NT == 0, "whole buckets per thread");
+        uint32_t c[BPT], tsum = 0;
+#pragma unroll
+        for (uint32_t q = 0; q < BPT; ++q) { c[q] = s_bin[gtid * BPT + q]; tsum += c[q]; }
+        uint32_t incl = tsum;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - tsum;
+        for (int w = w0; w < wave; ++w) run += s_wsum[w];
+#pragma unroll
+        for (uint32_t q = 0; q < BPT; ++q) { s_bin[gtid * BPT + q] = run; run += c[q]; }
+        if (gtid == NT - 1) s_bin[BINS] = run;
+    }
+    __syncthreads();
+    // the ranges of the stick's tiles: their buckets' first and one-past-last positions (identifyTileRanges; empty tiles keep (0, 0))
+    if (cnt != 0u && (uint32_t)gtid < (1u << sh)) {
+        const uint32_t tile = (list << sh) + (uint32_t)gtid;
+        if (tile < T) {
+            const uint32_t a = s_bin[(uint32_t)gtid * BPS], b = s_bin[((uint32_t)gtid + 1u) * BPS];
+            ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
+        }
+    }
+    uint32_t base_len[PER];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        base_len[u] = 0u;
+        if (i < cnt) {
+            const uint32_t bin = bin_ticket[u] & 0xFFFFu;
+            const uint32_t b0 = s_bin[bin], b1 = s_bin[bin + 1u];
+            base_len[u] = b0 | ((b1 - b0) << 16);
+            if (b1 - b0 > 1u) s_a[b0 + (bin_ticket[u] >> 16)] = mine[u];   // a bucket of one needs neither the store nor a rank
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        if (i < cnt) {
+            const uint32_t b0 = base_len[u] & 0xFFFFu, len = base_len[u] >> 16;
+            uint32_t r = 0;
+            if (len > 1u)
+                for (uint32_t q = b0; q < b0 + len; ++q) r += s_a[q] < mine[u] ? 1u : 0u;
+            const uint32_t pos = start + b0 + r;
+            point_list[pos] = (uint32_t)mine[u] & VS_ID_MASK;
+            tiles_out[pos] = (list << sh) + (uint32_t)(mine[u] >> 61);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
+    const uint4 *__restrict__ big, const uint4 *__restrict__ small, const uint32_t *__restrict__ nparts,
+    const uint2 *__restrict__ pairs, uint32_t sh, uint32_t T, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
+    uint2 *__restrict__ ranges)
+{
+    extern __shared__ unsigned long long vsk_lds[];
+    __shared__ uint32_t s_mm[4][VSK_THREADS / 64], s_wsum[VSK_THREADS / 64];
+    const uint32_t p = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // the descriptor is requested together with the counts that say whether it exists (one round trip, not two)
+    const uint4 pd = big[min(p, VS_MAX_LISTS - 1u)];
+    const uint32_t nbig = nparts[0], nsmall = nparts[1];
+    if (p >= nbig) {
+        // ---- group: VSK_GROUPS short lists, one per 256 threads of the workgroup
+        const uint32_t q0 = (p - nbig) * (uint32_t)VSK_GROUPS;
+        if (q0 >= nsmall) return;
+        const int g = tid >> 8, gtid = tid & 255, w0 = g * 4;
+        unsigned long long *s_a = vsk_lds + (size_t)g * VSK_SMALL_CAP;
+        uint32_t *s_bin = reinterpret_cast<uint32_t *>(vsk_lds + VSK_GROUPS * VSK_SMALL_CAP) + (size_t)g * (VSK_SMALL_BINS + 1);
+        uint32_t n = 0, start = 0, list = 0;
+        if (q0 + (uint32_t)g < nsmall) {
+            const uint4 sd = small[q0 + g];
+            list = sd.x; start = sd.z; n = sd.w;
+        }
+        list = __builtin_amdgcn_readfirstlane(list); start = __builtin_amdgcn_readfirstlane(start); n = __builtin_amdgcn_readfirstlane(n);
+        uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, pmax = 0u, nmin = 0xFFFFFFFFu;
+        unsigned long long mine[VSK_SMALL_PER];
+        {
+            // all loads in flight before the first use, branch-free (clamped addresses)
+            uint2 e[VSK_SMALL_PER];
+            const uint32_t last = start + (n ? n - 1u : 0u);
+#pragma unroll
+            for (uint32_t u = 0; u < VSK_SMALL_PER; ++u) e[u] = pairs[min(start + u * 256u + (uint32_t)gtid, last)];
+#pragma unroll
+            for (uint32_t u = 0; u < VSK_SMALL_PER; ++u) {
+                const bool in = u * 256u + (uint32_t)gtid < n;
+                const bool neg = (e[u].x >> 31) != 0u;
+                mine[u] = in ? vs_pack(e[u]) : ~0ull;
+                kmin = in ? min(kmin, e[u].x) : kmin;
+                kmax = in ? max(kmax, e[u].x) : kmax;
+                pmax = (in && !neg) ? max(pmax, e[u].x) : pmax;
+                nmin = (in && neg) ? min(nmin, e[u].x) : nmin;
+            }
+        }
+        vs_group_range<256>(kmin, kmax, pmax, nmin, s_mm, lane, wave, w0);
+        vs_sort_group<256, VSK_SMALL_PER, VSK_SMALL_BINS>(mine, s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, pmax, nmin, sh,
+                                                          list, T, start, point_list, tiles_out, ranges);
+        return;
+    }
+    // ---- big: one list for the whole workgroup
+    unsigned long long *s_a = vsk_lds;                                             // [VSK_BIG_CAP]
+    uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_a + VSK_BIG_CAP);             // [VSK_BIG_BINS + 1]
+    const uint32_t list = __builtin_amdgcn_readfirstlane(pd.x), start = __builtin_amdgcn_readfirstlane(pd.z),
+                   n = min(__builtin_amdgcn_readfirstlane(pd.w), VSK_BIG_CAP);   // (the host does not launch this kernel for longer lists)
+    const uint2 *__restrict__ src = pairs + start;
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, pmax = 0u, nmin = 0xFFFFFFFFu;
+    unsigned long long mine[VSK_BIG_PER];
+    {
+        uint2 e[VSK_BIG_PER];
+#pragma unroll
+        for (uint32_t u = 0; u < VSK_BIG_PER; ++u) e[u] = src[min(u * VSK_THREADS + (uint32_t)tid, n - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < VSK_BIG_PER; ++u) {
+            const bool in = u * VSK_THREADS + (uint32_t)tid < n;
+            const bool neg = (e[u].x >> 31) != 0u;
+            mine[u] = in ? vs_pack(e[u]) : ~0ull;
+            kmin = in ? min(kmin, e[u].x) : kmin;
+            kmax = in ? max(kmax, e[u].x) : kmax;
+            pmax = (in && !neg) ? max(pmax, e[u].x) : pmax;
+            nmin = (in && neg) ? min(nmin, e[u].x) : nmin;
+        }
+    }
+    vs_group_range<VSK_THREADS>(kmin, kmax, pmax, nmin, s_mm, lane, wave, 0);
+    vs_sort_group<VSK_THREADS, VSK_BIG_PER, VSK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, n, kmin, kmax, pmax, nmin, sh, list,
+                                                          T, start, point_list, tiles_out, ranges);
+}
+
+// ---- host side
+// what the thread has learnt about a (P, grid): a stick list too long for the sort kernel -> the general chain from then on
+struct VSNote { int P, nx, ny, nz; bool bad; unsigned long long used; };
+thread_local std::vector<VSNote> g_vs_notes;
+thread_local unsigned long long g_vs_tick = 0;
+
+VSNote *vs_note(int P, const VoxelGrid &v, bool create)
+{
+    for (VSNote &n : g_vs_notes)
+        if (n.P == P && n.nx == v.nx && n.ny == v.ny && n.nz == v.nz) { n.used = ++g_vs_tick; return &n; }
+    if (!create) return nullptr;
+    if (g_vs_notes.size() >= 32) {
+        size_t lru = 0;
+        for (size_t i = 1; i < g_vs_notes.size(); ++i)
+            if (g_vs_notes[i].used < g_vs_notes[lru].used) lru = i;
+        g_vs_notes.erase(g_vs_notes.begin() + (long)lru);
+    }
+    g_vs_notes.push_back(VSNote{P, v.nx, v.ny, v.nz, false, ++g_vs_tick});
+    return &g_vs_notes.back();
+}
+
+// forwards that took the chain, forwards that left it after the scan (a list too long), forwards it declined
+std::atomic<long long> g_vs_taken{0}, g_vs_fallback{0}, g_vs_declined{0};
+std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1: grids of more than 4096 tiles, 2: every grid it can serve
+
+int vs_mode()
+{
+    int m = g_vs_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char *e = getenv("R2_VOXEL_STICKS");
+        m = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+        g_vs_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
+bool vs_lds_ok()
+{
+    static signed char lds_state[R2_MAX_DEVICES] = {};
+    return VSK_LDS <= device_lds_optin_bytes() &&
+           allow_dynamic_lds(reinterpret_cast<const void *>(vox_stick_sort_kernel), (int)VSK_LDS, lds_state);
+}
+
+}  // namespace
+
+int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
+                         const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
+                         const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
+                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s)
+{
+    const size_t T = (size_t)v.gx * v.gy * v.gz;
+    const size_t V = (size_t)v.nx * v.ny * v.nz;
+    const int mode = vs_mode();
+    uint32_t sh = 0;
+    while (sh <= VS_MAX_SHIFT && ((T + ((size_t)1 << sh) - 1) >> sh) > VS_MAX_LISTS) ++sh;
+    // ids share a word with the tile-in-stick bits; the cube packs tile coordinates into 16 bits; 32-bit instance offsets
+    if (mode == 0 || (mode == 1 && T <= 4096) || T <= VOX_SMALL_MAX_TILES || sh > VS_MAX_SHIFT || P >= (1 << VS_ID_BITS) ||
+        v.gx > 65535 || v.gy > 65535 || v.gz > 65535 || !vs_lds_ok()) {
+        g_vs_declined.fetch_add(1, std::memory_order_relaxed);
+        return VOX_STICKS_NOT_TAKEN;
+    }
+    if (const VSNote *n = vs_note(P, v, false); n && n->bad) {
+        g_vs_declined.fetch_add(1, std::memory_order_relaxed);
+        return VOX_STICKS_NOT_TAKEN;
+    }
+    const uint32_t NL = (uint32_t)((T + ((size_t)1 << sh) - 1) >> sh);
+    uint32_t stride = 32;
+    while (stride < NL) stride <<= 1;
+    const VoxelSticks st = VoxelSticks::carve(geom.stick_temp, P);
+    VSCounters *ctr = reinterpret_cast<VSCounters *>(st.ctr);
+    const uint32_t NW = (uint32_t)st.NW;
+
+    uint32_t *mailbox = nullptr, seq = 0;
+    int rc = host_mailbox_arm(&mailbox, &seq);
+    if (rc) return rc;
+    { StageScope t(ST_VOX_PREPROCESS, s);
+    launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x, radii_y,
+                            radii_z, DepthReg{}, true, s, st.ctr); }
+    R2_HIP_TRY(hipGetLastError());
+    { StageScope t(ST_VOX_SCAN, s);
+    vox_stick_count_kernel<<<dim3(NW), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
+        P, (uint32_t)v.gx, (uint32_t)v.gy, sh, stride, geom.tiles_touched, geom.cube, st.H, st.wgtot, ctr);
+    vox_stick_scan_kernel<<<dim3(stride / VSS_LISTS), dim3(VSS_THREADS), 0, s>>>(st.H, NW, stride, st.totals, ctr, geom.host_words,
+                                                                                mailbox, seq); }
+    R2_HIP_TRY(hipGetLastError());
+    uint32_t hw[DW_COUNT] = { 0 };
+    rc = host_mailbox_wait(seq, hw, DW_COUNT, s);
+    if (rc) return rc;
+    const uint32_t num_rendered = hw[DW_TOTAL], longest = hw[DW_PMAX];
+    if (num_rendered > 0x7FFFFFFFu) {
+        set_error("r2_voxel_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
+        return R2_ERR_INVALID;
+    }
+    if (longest > VSK_BIG_CAP) {   // a stick's list is longer than one workgroup sorts: the general chain, from here and from now on
+        vs_note(P, v, true)->bad = true;
+        g_vs_fallback.fetch_add(1, std::memory_order_relaxed);
+        return VOX_STICKS_FALLBACK;
+    }
+    const size_t R = num_rendered;
+    char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false).bytes, image_user);
+    if (!bchunk || !ichunk) {
+        set_error("r2_voxel_forward: binning/image allocation callback returned NULL");
+        return R2_ERR_ALLOC;
+    }
+    const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false);
+    uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // the backward's moment scratch (48 bytes per instance), free until then
+    { StageScope t(ST_VOX_DUPLICATE, s);
+    vox_stick_scatter_kernel<<<dim3(NW + 1u), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
+        P, (uint32_t)v.gx, (uint32_t)v.gy, (uint32_t)T, sh, NL, stride, geom.tiles_touched, geom.cube, geom.depth_key, geom.first,
+        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, ctr->nparts); }
+    R2_HIP_TRY(hipGetLastError());
+    if (R > 0) {
+        StageScope t(ST_VOX_SORT, s);
+        vox_stick_sort_kernel<<<dim3(NL + (NL + VSK_GROUPS - 1) / VSK_GROUPS), dim3(VSK_THREADS), VSK_LDS, s>>>(
+            st.big, st.small, ctr->nparts, pairs, sh, (uint32_t)T, bin.point_list, bin.tiles, img.ranges);
+    }
+    R2_HIP_TRY(hipGetLastError());
+    { StageScope t(ST_VOX_RANGES, s);
+    launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(R), img.chunk_base, img.work_tile, img.work_temp, s,
+                      voxel_short_list_min(false)); }
+    R2_HIP_TRY(hipGetLastError());
+    { StageScope t(ST_VOX_RENDER_FWD, s);
+    launch_voxel_render_forward(geom, bin, img, v, out_volume, false, s); }
+    R2_HIP_TRY(hipGetLastError());
+    g_vs_taken.fetch_add(1, std::memory_order_relaxed);
+    return (int)num_rendered;
+}
+
+void voxel_sticks_release() { g_vs_notes.clear(); }
+
+}  // namespace r2
+
+extern "C" void r2_voxel_sticks_stats(long long *out, int reset)
+{
+    std::atomic<long long> *c[3] = {&r2::g_vs_taken, &r2::g_vs_fallback, &r2::g_vs_declined};
+    for (int i = 0; i < 3; ++i) {
+        if (out) out[i] = c[i]->load(std::memory_order_relaxed);
+        if (reset) c[i]->store(0, std::memory_order_relaxed);
+    }
+}
+
+extern "C" void r2_voxel_sticks_control(int mode)
+{
+    if (mode >= 0 && mode <= 2) r2::g_vs_mode.store(mode, std::memory_order_relaxed);
+    if (mode == 3) r2::g_vs_notes.clear();   // the calling thread's notes
+}

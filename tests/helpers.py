@@ -207,6 +207,13 @@ def ellipsoid_cloud(P, seed=0, scale_mult=1.0):
 TF_MARK = 0x71FE   # host word DW_PMAX of a rasterizer forward that took the tile-first path
 
 
+VOX_STICKS_MARK = 0x571C
+
+
+def took_sticks(h):
+    return int(h["host_words"][2]) == VOX_STICKS_MARK
+
+
 def took_tile_first(h):
     return int(h["host_words"][3]) == TF_MARK
 
@@ -221,14 +228,18 @@ def check_binning(h, o):
     R = o["num_rendered"]
     assert np.array_equal(h["tiles_touched"], o["tiles_touched"])
     tt = o["tiles_touched"].astype(np.int64)
-    if int(h["host_words"][2]) == 0x5A11 or int(h["host_words"][3]) == TF_MARK:
+    sticks = int(h["host_words"][2]) == VOX_STICKS_MARK
+    if int(h["host_words"][2]) == 0x5A11 or int(h["host_words"][3]) == TF_MARK or sticks:
         # rasterizer, tile-first binning (csrc/raster_tilefirst.hip, marker in host word 3), or
         # voxelizer, small-grid path (csrc/voxel_small.hip): no global depth order and no emission list exist -- the per-tile
         # lists are built straight from the survivors.  What the reference defines must still match bit for bit: the sorted
         # (tile | depth) keys, point_list, ranges; and every visible Gaussian owns a run of tiles_touched scratch rows, the runs
         # disjoint and covering [0, R) (the backward's contract).
         nvis = int((tt > 0).sum())
-        assert int(h["host_words"][7]) == nvis
+        if sticks:   # voxelizer, stick-first binning (csrc/voxel_sticks.hip): `order` lists every id, the visible count is cleared
+            assert int(h["host_words"][7]) == 0 and np.array_equal(h["order"], np.arange(P, dtype=np.uint32))
+        else:
+            assert int(h["host_words"][7]) == nvis
         vis = np.nonzero(tt > 0)[0]
         start = h["first"].astype(np.int64)[vis]
         srt = np.argsort(start, kind="stable")
