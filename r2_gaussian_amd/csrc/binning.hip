@@ -524,6 +524,16 @@ __global__ void __launch_bounds__(SC_THREADS) work_apply_fill_kernel(const uint2
     }
 }
 
+// the second half of the two-launch construction alone, for a caller whose own kernels have left the per-block work item counts
+// (partial[b] = work items of tiles [b * build_work_block_tiles(), ...)) -- voxel_sticks.hip: its sort kernel knows every tile's length
+uint32_t build_work_block_tiles() { return (uint32_t)SC_TILE; }
+void launch_build_work_from_partials(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
+                                     const uint32_t *partial, hipStream_t s, uint32_t min_len)
+{
+    const uint32_t tiles = (T + SC_TILE - 1) / SC_TILE;
+    work_apply_fill_kernel<<<dim3(tiles), dim3(SC_THREADS), 0, s>>>(ranges, T, chunk, min_len, partial, chunk_base, work_tile);
+}
+
 size_t build_work_temp_bytes(size_t T) { return T > 4096 ? sizeof(uint32_t) * 2 * T + scan_temp_bytes((int)T) + 256 : 0; }
 
 void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,

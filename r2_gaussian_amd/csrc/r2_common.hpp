@@ -268,6 +268,11 @@ size_t build_work_temp_bytes(size_t T);
 void launch_build_work(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
                        void *temp /* build_work_temp_bytes(T) bytes, may be null for T <= 4096 */, hipStream_t s,
                        uint32_t min_len = 0 /* tiles with fewer instances get no work item */);
+// many tiles (> 4096), for a caller whose kernels have summed the work items per block of build_work_block_tiles() consecutive tiles
+// themselves (partial[], in the temp storage): one launch instead of two
+uint32_t build_work_block_tiles();
+void launch_build_work_from_partials(const uint2 *ranges, uint32_t T, uint32_t chunk, uint32_t *chunk_base, uint4 *work_tile,
+                                     const uint32_t *partial, hipStream_t s, uint32_t min_len = 0);
 // same, but the tile ranges themselves are derived from the per-tile instance counts of a single-pass tile sort
 void launch_ranges_and_work(const uint32_t *tile_counts, uint32_t T, uint32_t chunk, uint2 *ranges, uint32_t *chunk_base,
                             uint4 *work_tile, hipStream_t s, uint32_t min_len = 0);

@@ -29,20 +29,45 @@ __device__ __forceinline__ void voxel_cov(const float *cov3D, float dvx, float d
     h[3] = cov.m[1][1]; h[4] = cov.m[1][2]; h[5] = cov.m[2][2];
 }
 
-// n_out = the Gaussian's number of tiles (0: it emits nothing)
+// Inverse of the voxel-space covariance (VOX/forward.cu:110-135), upper triangle; false: singular (the reference then returns
+// with radii = 0).
+__device__ __forceinline__ bool voxel_inverse(const float *cov3D, float dvx, float dvy, float dvz, float *inv)
+{
+    M3 M;
+    float h[6];
+    voxel_cov(cov3D, dvx, dvy, dvz, M, h);
+    const float a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
+    const float det = a * d * f + 2 * b * c * e - a * e * e - f * b * b - d * c * c;
+    if (det == 0.0f) return false;
+    const float det_inv = 1.f / det;
+    inv[0] = (d * f - e * e) * det_inv;
+    inv[1] = (c * e - b * f) * det_inv;
+    inv[2] = (b * e - c * d) * det_inv;
+    inv[3] = (a * f - c * c) * det_inv;
+    inv[4] = (b * c - a * e) * det_inv;
+    inv[5] = (a * d - b * b) * det_inv;
+    return true;
+}
+__device__ __forceinline__ float3 voxel_position(float3 p, const VoxelGrid &v, float dvx, float dvy, float dvz)
+{
+    return make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy, (p.z - v.cz + v.sz / 2) / dvz);
+}
+
+// The preprocess in two parts (one after the other in voxel_preprocess_kernel; as two kernels in the stick-first chain,
+// voxel_sticks.hip, where the second one runs while the host sizes the binning state).
+// Part 1, everything the BINNING needs: radii, tiles_touched, the depth key, the tile cube (and the 3D covariance).
+// -> the Gaussian's number of tiles (0: it emits nothing); pv / inv: voxel-space position and inverse covariance for part 2.
 // EARLY_CULL (small grids, where ~98 % of the Gaussians miss the volume): the volume / tile-cube tests come first, so a culled
 // Gaussian costs two loads and never computes or stores its covariance.  Same outcome: the reference returns with radii = 0 on
 // whichever test fails first (VOX/forward.cu:120-160) and nothing of a culled Gaussian's state is read again.
 template <bool EARLY_CULL = false>
-__device__ __forceinline__ void voxel_preprocess_one(
+__device__ __forceinline__ uint32_t voxel_cull_one(
     int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
-    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
-    const VoxelGrid &v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
-    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out,
-    uint4 *__restrict__ cube = nullptr)
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, const VoxelGrid &v,
+    int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z, uint32_t *__restrict__ depth_key,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ cube, float3 &pv_out, float *inv,
+    int3 &lo, int3 &hi)
 {
-    key_out = DEPTH_CULLED_KEY;
     radii_x[idx] = 0;
     radii_y[idx] = 0;
     radii_z[idx] = 0;
@@ -56,13 +81,13 @@ __device__ __forceinline__ void voxel_preprocess_one(
     if (EARLY_CULL) {
         const float ms = fmaxf(fmaxf(scales[3 * idx], scales[3 * idx + 1]), scales[3 * idx + 2]);
         const float3 rd = make_float3(ceilf((3.f * ms) / dvx), ceilf((3.f * ms) / dvy), ceilf((3.f * ms) / dvz));
-        const float3 q = make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy, (p.z - v.cz + v.sz / 2) / dvz);
+        const float3 q = voxel_position(p, v, dvx, dvy, dvz);
         if (q.x + rd.x < 0 || q.y + rd.y < 0 || q.z + rd.z < 0 || q.x - rd.x > (float)v.nx || q.y - rd.y > (float)v.ny ||
             q.z - rd.z > (float)v.nz)
-            return;
+            return 0u;
         int3 l0, h0;
         tile_cube(q, rd, v.gx, v.gy, v.gz, l0, h0);
-        if ((h0.x - l0.x) * (h0.y - l0.y) * (h0.z - l0.z) == 0) return;
+        if ((h0.x - l0.x) * (h0.y - l0.y) * (h0.z - l0.z) == 0) return 0u;
     }
 
     float cov3D[6];
@@ -76,33 +101,19 @@ __device__ __forceinline__ void voxel_preprocess_one(
 #pragma unroll
             for (int k = 0; k < 6; ++k) cov3Ds[6 * idx + k] = cov3D[k];
     }
-    M3 M;
-    float h[6];
-    voxel_cov(cov3D, dvx, dvy, dvz, M, h);
-    const float a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5];
-    const float det = a * d * f + 2 * b * c * e - a * e * e - f * b * b - d * c * c;
-    if (det == 0.0f) return;
-    const float det_inv = 1.f / det;
-    const float inv_a = (d * f - e * e) * det_inv;
-    const float inv_b = (c * e - b * f) * det_inv;
-    const float inv_c = (b * e - c * d) * det_inv;
-    const float inv_d = (a * f - c * c) * det_inv;
-    const float inv_e = (b * c - a * e) * det_inv;
-    const float inv_f = (a * d - b * b) * det_inv;
+    if (!voxel_inverse(cov3D, dvx, dvy, dvz, inv)) return 0u;
 
     // radius from the RAW scales, no scale_modifier (reference quirk Q5, VOX/forward.cu:137-143)
     const float max_scale = fmaxf(fmaxf(scales[3 * idx], scales[3 * idx + 1]), scales[3 * idx + 2]);
     const float3 rad = make_float3(ceilf((3.f * max_scale) / dvx), ceilf((3.f * max_scale) / dvy),
                                    ceilf((3.f * max_scale) / dvz));
-    const float3 pv = make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy,
-                                  (p.z - v.cz + v.sz / 2) / dvz);
+    const float3 pv = voxel_position(p, v, dvx, dvy, dvz);
     if (pv.x + rad.x < 0 || pv.y + rad.y < 0 || pv.z + rad.z < 0 || pv.x - rad.x > (float)v.nx ||
         pv.y - rad.y > (float)v.ny || pv.z - rad.z > (float)v.nz)
-        return;
-    int3 lo, hi;
+        return 0u;
     tile_cube(pv, rad, v.gx, v.gy, v.gz, lo, hi);
     const uint32_t n = (uint32_t)(hi.x - lo.x) * (uint32_t)(hi.y - lo.y) * (uint32_t)(hi.z - lo.z);
-    if (n == 0) return;
+    if (n == 0) return 0u;
 
     radii_x[idx] = (int)rad.x;
     radii_y[idx] = (int)rad.y;
@@ -114,8 +125,16 @@ __device__ __forceinline__ void voxel_preprocess_one(
     if (cube)
         cube[idx] = make_uint4(0u, (uint32_t)lo.x | ((uint32_t)lo.y << 16), (uint32_t)lo.z | ((uint32_t)(hi.x - lo.x) << 16),
                                (uint32_t)(hi.y - lo.y));
-    key_out = __float_as_uint(p.z);   // visible: hinted depth order, the key goes straight into its bucket
-    bt_out = depth_register_key(reg, key_out, n);
+    pv_out = pv;
+    return n;
+}
+
+// Part 2, what the RENDER kernels read: the record {position, opacity, scaled inverse covariance, log2 opacity} and the culling
+// extents of a visible Gaussian.
+__device__ __forceinline__ void voxel_record_one(int idx, const float3 pv, const float *inv, const float *__restrict__ opacities,
+                                                 float4 *__restrict__ rec, float4 *__restrict__ ext)
+{
+    const float inv_a = inv[0], inv_b = inv[1], inv_c = inv[2], inv_d = inv[3], inv_e = inv[4], inv_f = inv[5];
     const float op = opacities[idx];
     const float L = op > 0.0f ? log2f(op) : -INFINITY;
     // bounding box of {alpha >= 1e-6} (VOX/forward.cu:293): q = d^T C d <= 2 ln2 (L - log2(1e-6)), half-widths
@@ -151,22 +170,132 @@ __device__ __forceinline__ void voxel_preprocess_one(
     ext[idx] = make_float4(hx, hyc, hzc, ky);
 }
 
+template <bool EARLY_CULL = false>
+__device__ __forceinline__ void voxel_preprocess_one(
+    int idx, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
+    const VoxelGrid &v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
+    float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, const DepthReg &reg, uint32_t &key_out, uint2 &bt_out,
+    uint4 *__restrict__ cube = nullptr)
+{
+    key_out = DEPTH_CULLED_KEY;
+    float3 pv;
+    float inv[6];
+    int3 lo, hi;
+    const uint32_t n = voxel_cull_one<EARLY_CULL>(idx, means3D, scales, scale_modifier, rotations, cov3D_precomp, v, radii_x, radii_y,
+                                                  radii_z, depth_key, cov3Ds, tiles_touched, cube, pv, inv, lo, hi);
+    if (n == 0u) return;
+    key_out = __float_as_uint(means3D[3 * idx + 2]);   // visible: hinted depth order, the key goes straight into its bucket
+    bt_out = depth_register_key(reg, key_out, n);
+    voxel_record_one(idx, pv, inv, opacities, rec, ext);
+}
+
 __global__ void __launch_bounds__(256) voxel_preprocess_kernel(
     int P, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     VoxelGrid v, int *__restrict__ radii_x, int *__restrict__ radii_y, int *__restrict__ radii_z,
     float4 *__restrict__ rec, uint32_t *__restrict__ depth_key,
-    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg, uint4 *__restrict__ cube,
-    uint32_t *__restrict__ zero16)
+    float *__restrict__ cov3Ds, uint32_t *__restrict__ tiles_touched, float4 *__restrict__ ext, DepthReg reg, uint4 *__restrict__ cube)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (zero16 != nullptr && blockIdx.x == 0 && threadIdx.x < 16) zero16[threadIdx.x] = 0u;   // the stick chain's counters (voxel_sticks.hip)
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
     if (idx < P)
         voxel_preprocess_one(idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, v, radii_x, radii_y, radii_z,
                              rec, depth_key, cov3Ds, tiles_touched, ext, reg, key, bt, cube);
     depth_register_end(reg, (uint32_t)idx, key, bt);
+}
+
+// ---- stick-first chain (voxel_sticks.hip): part 1 of the preprocess for VS_PRODUCER Gaussians per workgroup + the workgroup's
+// instance counts per LIST (stick of 2^sh consecutive tile ids) in an LDS histogram, stored as one row of H; the workgroup's
+// totals: one plain word (the scatter kernel's row offsets) and ONE 64-bit atomic (the call's num_rendered).
+__global__ void __launch_bounds__(VS_PRODUCER) voxel_cull_count_kernel(
+    int P, uint32_t per_wg, uint32_t ni, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp, VoxelGrid v, int *__restrict__ radii_x,
+    int *__restrict__ radii_y, int *__restrict__ radii_z, uint32_t *__restrict__ depth_key, float *__restrict__ cov3Ds,
+    uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ cube, uint32_t sh, uint32_t stride, uint32_t *__restrict__ H,
+    uint32_t *__restrict__ wgtot, VSCounters *__restrict__ ctr)
+{
+    extern __shared__ uint32_t s_hist[];   // [stride]
+    __shared__ uint32_t s_w[2][VS_PRODUCER / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t i = tid; i < stride; i += VS_PRODUCER) s_hist[i] = 0u;
+    __syncthreads();
+    const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
+    uint32_t sum = 0u, vis = 0u;
+    for (uint32_t it = 0; it < ni; ++it) {
+        const uint32_t idx = g0 + it * VS_PRODUCER + (uint32_t)tid;
+        if (idx >= g1) continue;
+        float3 pv;
+        float inv[6];
+        int3 lo, hi;
+        const uint32_t tt = voxel_cull_one((int)idx, means3D, scales, scale_modifier, rotations, cov3D_precomp, v, radii_x, radii_y,
+                                           radii_z, depth_key, cov3Ds, tiles_touched, cube, pv, inv, lo, hi);
+        if (tt == 0u) continue;
+        sum += tt;
+        vis += 1u;
+        const uint32_t nsub = 1u << sh, rw = (uint32_t)(hi.x - lo.x);
+        for (int z = lo.z; z < hi.z; ++z)
+            for (int y = lo.y; y < hi.y; ++y) {
+                const uint32_t t0 = ((uint32_t)z * (uint32_t)v.gy + (uint32_t)y) * (uint32_t)v.gx + (uint32_t)lo.x, t1 = t0 + rw - 1u;
+                for (uint32_t l = t0 >> sh; l <= (t1 >> sh); ++l) {   // the row's tiles, stick by stick
+                    const uint32_t a = max(t0, l << sh), b = min(t1, (l << sh) + nsub - 1u);
+                    atomicAdd(&s_hist[l], b - a + 1u);
+                }
+            }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += (uint32_t)__shfl_xor(sum, d);
+        vis += (uint32_t)__shfl_xor(vis, d);
+    }
+    if (lane == 0) { s_w[0][wave] = sum; s_w[1][wave] = vis; }
+    __syncthreads();   // (also: the histogram is complete)
+    if (tid == 0) {
+        uint32_t S = 0, V = 0;
+#pragma unroll
+        for (int w = 0; w < (int)VS_PRODUCER / 64; ++w) { S += s_w[0][w]; V += s_w[1][w]; }
+        wgtot[blockIdx.x] = S;
+        atomicAdd(&ctr->total, ((unsigned long long)V << 40) | (unsigned long long)S);
+    }
+    uint32_t *__restrict__ row = H + (size_t)blockIdx.x * stride;
+    for (uint32_t i = tid; i < stride; i += VS_PRODUCER) row[i] = s_hist[i];
+}
+
+// ... and part 2 for the visible ones: the inverse covariance is recomputed from the stored 3D covariance (the same operations on
+// the same values: the same bits)
+__global__ void __launch_bounds__(256) voxel_record_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ opacities,
+                                                           const float *__restrict__ cov3Ds, const uint32_t *__restrict__ tiles_touched,
+                                                           VoxelGrid v, float4 *__restrict__ rec, float4 *__restrict__ ext)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= P || tiles_touched[idx] == 0u) return;
+    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+    float cov3D[6], inv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
+    if (!voxel_inverse(cov3D, dvx, dvy, dvz, inv)) return;   // (cannot happen: part 1 gave it tiles)
+    voxel_record_one(idx, voxel_position(p, v, dvx, dvy, dvz), inv, opacities, rec, ext);
+}
+
+int launch_voxel_cull_count(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D, const float *scales,
+                            float scale_modifier, const float *rotations, const float *cov3D_precomp, int *radii_x, int *radii_y,
+                            int *radii_z, uint32_t shift, uint32_t stride, uint32_t *H, uint32_t *wgtot, VSCounters *ctr, hipStream_t s)
+{
+    voxel_cull_count_kernel<<<dim3(grid.wgs), dim3(VS_PRODUCER), stride * sizeof(uint32_t), s>>>(
+        P, grid.per_wg, grid.ni, means3D, scales, scale_modifier, rotations, cov3D_precomp, v, radii_x, radii_y, radii_z, g.depth_key,
+        g.cov3D, g.tiles_touched, g.cube, shift, stride, H, wgtot, ctr);
+    return 0;
+}
+
+int launch_voxel_records(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
+                         const float *cov3D_precomp, hipStream_t s)
+{
+    voxel_record_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, opacities, cov3D_precomp ? cov3D_precomp : g.cov3D,
+                                                                    g.tiles_touched, v, g.rec, g.ext);
+    return 0;
 }
 
 // ---- small grids (the training loop's 32^3 TV patch: 64 tiles; train.py:128-142).  Only ~2 % of the Gaussians reach such a
@@ -521,12 +650,12 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            bool store_cov3D, hipStream_t s, uint32_t *zero16)
+                            bool store_cov3D, hipStream_t s)
 {
     voxel_preprocess_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, scales, scale_modifier, rotations,
                                                                         opacities, cov3D_precomp, v, radii_x, radii_y,
                                                                         radii_z, g.rec, g.depth_key, store_cov3D ? g.cov3D : nullptr,
-                                                                        g.tiles_touched, g.ext, reg, g.cube, zero16);
+                                                                        g.tiles_touched, g.ext, reg, g.cube);
     return 0;
 }
 

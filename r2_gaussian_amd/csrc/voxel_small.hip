@@ -372,4 +372,6 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
 
 void voxel_small_release() { g_small_counters.release(); }
 
+unsigned long long *voxel_small_counter_block(int dev, hipStream_t s) { return small_counter_for(dev, s); }
+
 }  // namespace r2

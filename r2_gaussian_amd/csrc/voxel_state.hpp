@@ -47,9 +47,34 @@ __device__ __forceinline__ bool needs_exact_slab3(float D2, float F2, float L, f
 
 // Workspace of the stick-first binning chain (voxel_sticks.hip), part of the geometry state: 16 bytes per Gaussian + 150 KB.
 constexpr uint32_t VS_MAX_LISTS = 4096;     // lists (sticks of 2^shift consecutive tiles) per call: one LDS histogram
-constexpr uint32_t VS_PRODUCER = 1024;      // Gaussians per producer workgroup
+constexpr uint32_t VS_PRODUCER = 1024;      // Gaussians per producer workgroup (512: the same scatter time, twice the rows to scan: +6 us)
+// Producer workgroups of the chain (cull + count, scatter): VS_PRODUCER threads, ONE workgroup per CU as long as a thread then
+// owns at most VS_PER_THREAD_MAX Gaussians (293 workgroups of 1024 Gaussians on 256 CUs: the 37 CUs with two of them finished
+// 17 us after the others); thread t of workgroup w owns Gaussians w * per_wg + it * VS_PRODUCER + t, it < ni, below (w + 1) * per_wg
+constexpr uint32_t VS_PER_THREAD_MAX = 2;
+struct VSGrid { uint32_t wgs, per_wg, ni; };
+inline VSGrid vs_grid(int P, int cus)
+{
+    VSGrid g;
+    const uint32_t n = (uint32_t)(P > 0 ? P : 1), c = (uint32_t)(cus > 0 ? cus : 1);
+    const uint32_t one = (n + VS_PRODUCER - 1) / VS_PRODUCER;   // workgroups at one Gaussian per thread
+    if (one <= c) { g.wgs = one; g.per_wg = VS_PRODUCER; g.ni = 1; return g; }
+    g.per_wg = (n + c - 1) / c;
+    if (g.per_wg > VS_PRODUCER * VS_PER_THREAD_MAX) g.per_wg = VS_PRODUCER * VS_PER_THREAD_MAX;
+    g.ni = (g.per_wg + VS_PRODUCER - 1) / VS_PRODUCER;
+    g.wgs = (n + g.per_wg - 1) / g.per_wg;   // <= ceil(P / VS_PRODUCER): the rows VoxelSticks reserves
+    return g;
+}
+
+// the chain's device counters, bumped by many workgroups: a persistent block per (host thread, device, stream), zero between
+// calls (the scan kernel's last workgroup resets them); shared with the small-grid path's counters (voxel_small_counter_block)
+struct VSCounters {
+    unsigned long long total;   // visible Gaussians << 40 | instances
+    uint32_t maxlist;           // longest list
+    uint32_t scan_done;         // scan workgroups that have finished
+};
 struct VoxelSticks {
-    uint32_t *ctr;       // [16]  {total (64 bit: visible << 40 | instances), longest list, scan workgroups done, big lists, short lists}
+    uint32_t *ctr;       // [16]  {big lists, short lists} for the sort kernel
     uint32_t *totals;    // [VS_MAX_LISTS] instances per list
     uint32_t *wgtot;     // [NW]  instances per producer workgroup
     uint4 *big, *small;  // [VS_MAX_LISTS] each: the sort kernel's work lists {list, 0, first instance, instances}
@@ -193,7 +218,7 @@ struct VoxelGrid {
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *opacities,
                             const float *cov3D_precomp, int *radii_x, int *radii_y, int *radii_z, const DepthReg &reg,
-                            bool store_cov3D, hipStream_t s, uint32_t *zero16 = nullptr /* 16 words zeroed on the way */);
+                            bool store_cov3D, hipStream_t s);
 // small grids (<= 64 tiles): preprocess + survivor list (voxel_geom.hip), per-tile lists from it (voxel_small.hip)
 int launch_voxel_preprocess_small(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,
                                   float scale_modifier, const float *rotations, const float *opacities,
@@ -219,6 +244,15 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
 constexpr int VOX_STICKS_NOT_TAKEN = -1001, VOX_STICKS_FALLBACK = -1002;
 constexpr uint32_t VOX_STICKS_MARK = 0x571Cu;   // DW_USER word of a state produced by that chain (introspection / tests)
 void voxel_sticks_release();   // the calling thread's notes about that chain (r2_thread_release)
+// 64 bytes of device memory, zero between calls, owned by the calling thread for (current device, stream); nullptr: none to be had
+unsigned long long *voxel_small_counter_block(int dev, hipStream_t s);
+// the preprocess as two kernels: (1) everything the binning needs + the per-(workgroup, list) instance counts of the stick-first
+// chain (lists = tile id >> shift; H[workgroup][stride], wgtot[workgroup], the call's totals into ctr), (2) the render records
+int launch_voxel_cull_count(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D, const float *scales,
+                            float scale_modifier, const float *rotations, const float *cov3D_precomp, int *radii_x, int *radii_y,
+                            int *radii_z, uint32_t shift, uint32_t stride, uint32_t *H, uint32_t *wgtot, VSCounters *ctr, hipStream_t s);
+int launch_voxel_records(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
+                         const float *cov3D_precomp, hipStream_t s);
 int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                          const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                          const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,

@@ -21,11 +21,13 @@
 // the chain notices after its scan, continues on the general chain's un-hinted branch -- the preprocess is not repeated -- and
 // the thread remembers the (P, grid) for which that happened).
 //
-//     1. voxel_preprocess_kernel (voxel_geom.hip)   unchanged, no depth registration; zeroes the chain's counters on the way
-//     2. vox_stick_count_kernel                      LDS histogram of the workgroup's instances over the lists -> H[wg][list]
-//     3. vox_stick_scan_kernel                       exclusive prefix of every column of H, list totals, longest list; the last
+//     1. voxel_cull_count_kernel (voxel_geom.hip)    the part of the preprocess the binning needs (radii, tile cube, z bits) + an LDS
+//                                                    histogram of the workgroup's instances over the lists -> H[wg][list]
+//     2. vox_stick_scan_kernel                       exclusive prefix of every column of H, list totals, longest list; the last
 //                                                    workgroup posts {num_rendered, longest list} to the host mailbox
-//        (the host sizes the binning / image state: the reference's D2H, VOX/voxelizer_impl.cu:248)
+//     3. voxel_record_kernel (voxel_geom.hip)        the rest of the preprocess (the render kernels' records), enqueued at once:
+//                                                    it runs while the host waits for the totals and sizes the binning / image
+//                                                    state (the reference's D2H, VOX/voxelizer_impl.cu:248)
 //     4. vox_stick_scatter_kernel                    instances -> list segments; first instance of every Gaussian (the backward's
 //                                                    moment rows); workgroup 0 builds the sort kernel's lists
 //     5. vox_stick_sort_kernel                       per-list sort, point_list, tiles, ranges
@@ -36,6 +38,9 @@
 #include <atomic>
 #include <cstdlib>
 #include <vector>
+
+R2_TS_DEFINE(sticks)
+#define VS_TS(ph) R2_TS_AT(sticks, ph)
 
 namespace r2 {
 
@@ -58,15 +63,7 @@ static_assert(VSK_GROUPS * VSK_SMALL_CAP * sizeof(unsigned long long) + VSK_GROU
 static_assert(VSK_SMALL_PER * 256 == VSK_SMALL_CAP && VSK_BIG_PER * VSK_THREADS == VSK_BIG_CAP, "entries per thread");
 static_assert((VSK_SMALL_BINS >> VS_MAX_SHIFT) >= 64, "enough buckets per tile of a stick");
 
-struct VSCounters {
-    unsigned long long total;   // visible Gaussians << 40 | instances
-    uint32_t maxlist;           // longest list
-    uint32_t scan_done;         // scan workgroups that have finished
-    uint32_t nparts[2];         // big lists, short lists
-    uint32_t pad[10];
-};
-static_assert(sizeof(VSCounters) == 64, "the preprocess kernel zeroes sixteen words");
-
+struct __attribute__((aligned(8))) Pair2 { uint2 a, b; };   // two list entries, stored at once wherever the first one lies
 struct Cube { uint32_t lx, ly, lz, rw, rh, rd; };
 __device__ __forceinline__ Cube cube_of(const uint4 c, uint32_t tt)
 {
@@ -74,50 +71,6 @@ __device__ __forceinline__ Cube cube_of(const uint4 c, uint32_t tt)
     q.lx = c.y & 0xFFFFu; q.ly = c.y >> 16; q.lz = c.z & 0xFFFFu; q.rw = c.z >> 16; q.rh = c.w;
     q.rd = tt / (q.rw * q.rh);   // tiles_touched = rw * rh * rd
     return q;
-}
-
-// ---- 2. per-(workgroup, list) instance counts
-__global__ void __launch_bounds__(VS_THREADS) vox_stick_count_kernel(
-    int P, uint32_t gx, uint32_t gy, uint32_t sh, uint32_t stride, const uint32_t *__restrict__ tiles_touched,
-    const uint4 *__restrict__ cube, uint32_t *__restrict__ H, uint32_t *__restrict__ wgtot, VSCounters *__restrict__ ctr)
-{
-    extern __shared__ uint32_t s_hist[];   // [stride]
-    __shared__ uint32_t s_w[2][VS_THREADS / 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t i = tid; i < stride; i += VS_THREADS) s_hist[i] = 0u;
-    __syncthreads();
-    const uint32_t g = blockIdx.x * (uint32_t)VS_THREADS + (uint32_t)tid;
-    const uint32_t tt = g < (uint32_t)P ? tiles_touched[g] : 0u;
-    if (tt != 0u) {
-        const Cube q = cube_of(cube[g], tt);
-        const uint32_t nsub = 1u << sh;
-        for (uint32_t z = 0; z < q.rd; ++z)
-            for (uint32_t y = 0; y < q.rh; ++y) {
-                const uint32_t t0 = ((q.lz + z) * gy + q.ly + y) * gx + q.lx, t1 = t0 + q.rw - 1u;
-                for (uint32_t l = t0 >> sh; l <= (t1 >> sh); ++l) {   // the row's tiles, stick by stick
-                    const uint32_t a = max(t0, l << sh), b = min(t1, (l << sh) + nsub - 1u);
-                    atomicAdd(&s_hist[l], b - a + 1u);
-                }
-            }
-    }
-    // the workgroup's totals: one 64-bit atomic for the call's, one plain word for the scatter kernel's row offsets
-    uint32_t sum = tt, vis = tt != 0u ? 1u : 0u;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        sum += (uint32_t)__shfl_xor(sum, d);
-        vis += (uint32_t)__shfl_xor(vis, d);
-    }
-    if (lane == 0) { s_w[0][wave] = sum; s_w[1][wave] = vis; }
-    __syncthreads();   // (also: the histogram is complete)
-    if (tid == 0) {
-        uint32_t S = 0, V = 0;
-#pragma unroll
-        for (int w = 0; w < VS_THREADS / 64; ++w) { S += s_w[0][w]; V += s_w[1][w]; }
-        wgtot[blockIdx.x] = S;
-        atomicAdd(&ctr->total, ((unsigned long long)V << 40) | (unsigned long long)S);
-    }
-    uint32_t *__restrict__ row = H + (size_t)blockIdx.x * stride;
-    for (uint32_t i = tid; i < stride; i += VS_THREADS) row[i] = s_hist[i];
 }
 
 // ---- 3. column scan (the layout of rs_scan_kernel, radix_sort.hip: a workgroup owns 32 consecutive lists, its 32 thread rows
@@ -128,6 +81,7 @@ __global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
     uint32_t *__restrict__ words, uint32_t *__restrict__ mailbox, uint32_t seq)
 {
     __shared__ uint32_t part[VSS_ROWS][VSS_LISTS];
+    VS_TS(2);
     const uint32_t dl = threadIdx.x % VSS_LISTS, row = threadIdx.x / VSS_LISTS;
     const uint32_t d = blockIdx.x * VSS_LISTS + dl;   // < stride (a multiple of 32)
     const uint32_t per = (rows + VSS_ROWS - 1) / VSS_ROWS;
@@ -161,6 +115,7 @@ __global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
             }
     }
     if (row == 0) totals[d] = total;
+    VS_TS(3);
     // the longest list of the call; the last workgroup to get here tells the host
     if (threadIdx.x < 64) {
         uint32_t m = row == 0 ? total : 0u;
@@ -182,6 +137,10 @@ __global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
                 mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = VOX_STICKS_MARK; mailbox[DW_PMAX] = ml;
                 mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = 0u; mailbox[DW_NNMAX] = 0u; mailbox[DW_NVIS] = (uint32_t)(tot >> 40);
                 __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // every other workgroup is through with the counters: ready for the thread's next call on this stream
+                __hip_atomic_store(&ctr->total, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr->maxlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr->scan_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -190,17 +149,20 @@ __global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
 // ---- 4. scatter.  Workgroup 0 does not scatter: it builds the sort kernel's two lists from the list totals and gives the
 // tiles of empty lists their (0, 0) ranges (the reference's memset).
 __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
-    int P, uint32_t gx, uint32_t gy, uint32_t T, uint32_t sh, uint32_t NL, uint32_t stride,
+    int P, uint32_t per_wg, uint32_t ni, uint32_t gx, uint32_t gy, uint32_t T, uint32_t sh, uint32_t NL, uint32_t stride,
     const uint32_t *__restrict__ tiles_touched, uint4 *__restrict__ cube, const uint32_t *__restrict__ depth_key,
     uint32_t *__restrict__ first, uint32_t *__restrict__ order, const uint32_t *__restrict__ H,
     const uint32_t *__restrict__ totals, const uint32_t *__restrict__ wgtot, uint2 *__restrict__ pairs,
-    uint2 *__restrict__ ranges, uint4 *__restrict__ big, uint4 *__restrict__ small, uint32_t *__restrict__ nparts)
+    uint2 *__restrict__ ranges, uint4 *__restrict__ big, uint4 *__restrict__ small, uint32_t *__restrict__ nparts,
+    uint32_t *__restrict__ work_partial, uint32_t n_partial)
 {
     extern __shared__ uint32_t s_pos[];   // [stride] start of the list's segment + this workgroup's offset in it, bumped per instance
-    __shared__ uint32_t s_wsum[3][VS_THREADS / 64], s_carry[3], s_base;
+    __shared__ uint32_t s_wsum[2 + VS_PER_THREAD_MAX][VS_THREADS / 64], s_carry[3], s_base;
+    static_assert(VS_PER_THREAD_MAX >= 1, "the service workgroup uses three rows");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (blockIdx.x == 0) {
         if (tid < 3) s_carry[tid] = 0u;
+        for (uint32_t i = tid; i < n_partial; i += VS_THREADS) work_partial[i] = 0u;   // the sort kernel adds to them
         __syncthreads();
         for (uint32_t base = 0; base < NL; base += VS_THREADS) {
             const uint32_t l = base + (uint32_t)tid;
@@ -231,14 +193,22 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
         return;
     }
     const uint32_t wg = blockIdx.x - 1u;
-    // this thread's Gaussian: requested now, used after the scans (everything here was written by earlier kernels on other XCDs)
-    const uint32_t g = wg * (uint32_t)VS_THREADS + (uint32_t)tid;
-    const bool own = g < (uint32_t)P;
-    const uint32_t gc = min(g, (uint32_t)P - 1u);
-    uint32_t tt = tiles_touched[gc];
-    const uint4 cb = cube[gc];
-    const uint32_t key = depth_key[gc];
-    tt = own ? tt : 0u;
+    VS_TS(4);
+    // this thread's Gaussians (vs_grid): requested now, used after the scans (everything here was written by earlier kernels on
+    // other XCDs)
+    constexpr int NI = (int)VS_PER_THREAD_MAX;
+    const uint32_t g0 = wg * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
+    uint32_t g_idx[NI], g_tt[NI], g_key[NI];
+    uint4 g_cb[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        g_idx[it] = g0 + (uint32_t)it * (uint32_t)VS_THREADS + (uint32_t)tid;
+        const bool own = (uint32_t)it < ni && g_idx[it] < g1;
+        const uint32_t gc = min(g_idx[it], (uint32_t)P - 1u);
+        g_tt[it] = tiles_touched[gc]; g_cb[it] = cube[gc]; g_key[it] = depth_key[gc];
+        g_tt[it] = own ? g_tt[it] : 0u;
+        if (own) order[g_idx[it]] = g_idx[it];   // the ids the geometry backward walks: all of them (DW_NVIS = 0)
+    }
     // rows of producer workgroups before this one (the first instance of its first Gaussian)
     uint32_t pre = 0;
     for (uint32_t w = tid; w < wg; w += VS_THREADS) pre += wgtot[w];
@@ -260,13 +230,24 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
     const uint32_t t0 = min(stride, (uint32_t)tid * ipt), t1 = min(t0 + ipt, stride);
     uint32_t sum = 0;
     for (uint32_t t = t0; t < t1; ++t) sum += s_pos[t];
-    uint32_t incl = sum, itt = tt;
+    uint32_t incl = sum, itt[NI];
+#pragma unroll
+    for (int it = 0; it < NI; ++it) itt[it] = g_tt[it];
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t up = __shfl_up(incl, d), ut = __shfl_up(itt, d);
-        if (lane >= d) { incl += up; itt += ut; }
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const uint32_t ut = __shfl_up(itt[it], d);
+            if (lane >= d) itt[it] += ut;
+        }
     }
-    if (lane == 63) { s_wsum[0][wave] = incl; s_wsum[2][wave] = itt; }
+    if (lane == 63) {
+        s_wsum[0][wave] = incl;
+#pragma unroll
+        for (int it = 0; it < NI; ++it) s_wsum[2 + it][wave] = itt[it];
+    }
     if (tid == 0) {
         uint32_t b = 0;
 #pragma unroll
@@ -274,14 +255,27 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
         s_base = b;
     }
     __syncthreads();
-    uint32_t run = incl - sum, frun = itt - tt;
-    for (int w = 0; w < wave; ++w) { run += s_wsum[0][w]; frun += s_wsum[2][w]; }
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wave; ++w) run += s_wsum[0][w];
     for (uint32_t t = t0; t < t1; ++t) {
         const uint32_t c = s_pos[t];
         s_pos[t] = run;
         run += c;
     }
-    const uint32_t firstv = s_base + frun;
+    // first moment row of each of this thread's Gaussians: the workgroup's Gaussians in id order (it = 0 first)
+    uint32_t firstv[NI], before = s_base;
+#pragma unroll
+    for (int it = 0; it < NI; ++it) {
+        uint32_t f = before + itt[it] - g_tt[it], all = 0;
+#pragma unroll
+        for (int w = 0; w < VS_THREADS / 64; ++w) {
+            const uint32_t x = s_wsum[2 + it][w];
+            f += w < wave ? x : 0u;
+            all += x;
+        }
+        firstv[it] = f;
+        before += all;
+    }
     __syncthreads();
     // ... + where this workgroup's instances start inside each segment
 #pragma unroll
@@ -290,25 +284,40 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
         if (t < stride) s_pos[t] += offs[q];
     }
     __syncthreads();
-    // what the backward needs per Gaussian: its run of moment rows (any disjoint assignment serves: here id order) and a list of
-    // the ids to walk (all of them: DW_NVIS = 0)
-    if (own) order[g] = g;
-    if (tt != 0u) {
-        first[g] = firstv;
-        reinterpret_cast<uint32_t *>(cube + g)[0] = firstv;
-        // ---- every instance of this Gaussian
-        const Cube q = cube_of(cb, tt);
-        const uint32_t smask = (1u << sh) - 1u;
-        for (uint32_t z = 0; z < q.rd; ++z)
-            for (uint32_t y = 0; y < q.rh; ++y) {
-                const uint32_t t0r = ((q.lz + z) * gy + q.ly + y) * gx + q.lx;
-                for (uint32_t x = 0; x < q.rw; ++x) {
-                    const uint32_t tile = t0r + x;
-                    const uint32_t pos = atomicAdd(&s_pos[tile >> sh], 1u);
-                    pairs[pos] = make_uint2(key, g | ((tile & smask) << VS_ID_BITS));
+    VS_TS(5);
+    const uint32_t smask = (1u << sh) - 1u;
+#pragma unroll
+    for (int it = 0; it < NI; ++it)
+        if (g_tt[it] != 0u) {
+            const uint32_t g = g_idx[it], key = g_key[it];
+            // what the backward needs per Gaussian: its run of moment rows (any disjoint assignment serves: here id order)
+            first[g] = firstv[it];
+            reinterpret_cast<uint32_t *>(cube + g)[0] = firstv[it];
+            // ---- every instance of this Gaussian (a row of the cube lies in one stick, sometimes two: one LDS atomic per (row,
+            // stick), and its instances leave two to a 16-byte store).  The loop is bound by scattered store transactions:
+            // ~19 us for a workgroup's 19 k instances whatever the number of workgroups per CU.  Non-temporal stores (the dirty
+            // lines then do not wait in the L2s for the end of the kernel): 38 -> 123 us -- the L2's write combining is what
+            // makes this loop affordable)
+            const Cube q = cube_of(g_cb[it], g_tt[it]);
+            for (uint32_t z = 0; z < q.rd; ++z)
+                for (uint32_t y = 0; y < q.rh; ++y) {
+                    const uint32_t t0r = ((q.lz + z) * gy + q.ly + y) * gx + q.lx, t1r = t0r + q.rw - 1u;
+                    for (uint32_t l = t0r >> sh; l <= (t1r >> sh); ++l) {
+                        const uint32_t a = max(t0r, l << sh), b = min(t1r, (l << sh) + smask);
+                        const uint32_t cnt = b - a + 1u;
+                        const uint32_t pos = atomicAdd(&s_pos[l], cnt);
+                        uint32_t k = 0;
+                        for (; k + 1u < cnt; k += 2u) {
+                            Pair2 w;
+                            w.a = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
+                            w.b = make_uint2(key, g | (((a + k + 1u) & smask) << VS_ID_BITS));
+                            *reinterpret_cast<Pair2 *>(pairs + pos + k) = w;
+                        }
+                        if (k < cnt) pairs[pos + k] = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
+                    }
                 }
-            }
-    }
+        }
+    VS_TS(6);
 }
 
 // ---- 5. per-list sort
@@ -343,11 +352,13 @@ __device__ __forceinline__ void vs_group_range(uint32_t &kmin, uint32_t &kmax, u
     pmax = __builtin_amdgcn_readfirstlane(pmax); nmin = __builtin_amdgcn_readfirstlane(nmin);
 }
 
+struct VSWork { uint32_t *partial; uint32_t block_tiles, chunk, min_len; };   // partial == nullptr: the caller counts the work items itself
+
 // mine[u] (entry u * NT + gtid of the list's cnt entries, in registers) -> its sorted position by (tile in stick, z bits, id).
 // One-level bucket sort as in raster_tilefirst.hip (tf_sort_group): the BINS buckets are divided among the stick's 2^sh tiles,
-// and inside a tile laid linearly over the list's key range.  The keys are raw float bits of world z, compared as unsigned
-// (quirk Q10: negative z after positive): a list that straddles z = 0 holds two clusters 2^31 apart, so the sign-bit class is
-// first moved down to sit right behind the other one (monotone: the order of the buckets is the order of the keys, whatever the
+// and inside a tile laid over the list's key range.  The keys are raw float bits of world z, compared as unsigned (quirk Q10:
+// negative z after positive): a list that straddles z = 0 holds two clusters 2^31 apart, so the buckets of the sign-bit class
+// follow those of the other class directly (monotone: the order of the buckets is the order of the keys, whatever the
 // distribution; position = bucket base + rank inside the bucket by the whole 64-bit entry, exact).
 // The barriers are the WORKGROUP's: every group of the workgroup calls this together.
 template <int NT, uint32_t PER, uint32_t BINS>
@@ -355,13 +366,19 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
                                               uint32_t *s_wsum, int gtid, int lane, int wave, int w0, uint32_t cnt, uint32_t kmin,
                                               uint32_t kmax, uint32_t pmax, uint32_t nmin, uint32_t sh, uint32_t list, uint32_t T,
                                               uint32_t start, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
-                                              uint2 *__restrict__ ranges)
+                                              uint2 *__restrict__ ranges, const VSWork wk)
 {
     const uint32_t BPS = BINS >> sh;   // buckets per tile of the stick
+    // position of a key on the list's axis: its VALUE (the centres of a list's Gaussians are spread evenly in z: linear in the
+    // bit pattern crowded the lists around z = 0, whose keys span several binades, into a tenth of their buckets -- the rank loop
+    // of such a workgroup ran 17 us against a median of 2), magnitudes capped at FLT_MAX (inf / NaN patterns are the largest of
+    // their class: still monotone); the sign-bit class continues where the other one ends
+    auto fv = [](uint32_t k) { return __uint_as_float(min(k & 0x7FFFFFFFu, 0x7F7FFFFFu)); };
     const bool both = kmin < 0x80000000u && kmax >= 0x80000000u;
-    const uint32_t shift = both ? nmin - pmax : 0u;
-    const uint32_t umin = kmin, umax = kmax >= 0x80000000u ? kmax - shift : kmax;
-    const float scale = umax > umin ? (float)(BPS - 1u) / (float)(umax - umin) : 0.f;
+    const float f0 = fv(kmin), fn0 = fv(nmin), noff = both ? fv(pmax) - f0 : 0.f;
+    const float tmax = both ? noff + (fv(kmax) - fn0) : fv(kmax) - f0;
+    const float scale = tmax > 0.f ? (float)(BPS - 1u) / tmax : 0.f;
+    VS_TS(8);
     for (uint32_t i = gtid; i <= BINS; i += NT) s_bin[i] = 0u;
     __syncthreads();
     // (64 VGPRs keep two of these workgroups on a CU: bucket and ticket share a word, and so do a bucket's base and length)
@@ -373,12 +390,13 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
         bin_ticket[u] = 0u;
         if (i < cnt) {
             const uint32_t key = (uint32_t)(mine[u] >> VS_ID_BITS), sub = (uint32_t)(mine[u] >> 61);
-            const uint32_t uk = key >= 0x80000000u ? key - shift : key;
-            const uint32_t bin = sub * BPS + min((uint32_t)((float)(uk - umin) * scale), BPS - 1u);
+            const float t = (both && key >= 0x80000000u) ? noff + (fv(key) - fn0) : fv(key) - f0;
+            const uint32_t bin = sub * BPS + min((uint32_t)(t * scale), BPS - 1u);
             bin_ticket[u] = bin | (atomicAdd(&s_bin[bin], 1u) << 16);
         }
     }
     __syncthreads();
+    VS_TS(9);
     {
         constexpr uint32_t BPT = BINS / NT;
         static_assert(BINS % NT == 0, "whole buckets per thread");
@@ -400,12 +418,21 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
         if (gtid == NT - 1) s_bin[BINS] = run;
     }
     __syncthreads();
+    VS_TS(10);
     // the ranges of the stick's tiles: their buckets' first and one-past-last positions (identifyTileRanges; empty tiles keep (0, 0))
+    // ... and, for the render kernel's work list (launch_build_work_from_partials), the stick's work items added to the count of
+    // its block of tiles (a stick never straddles two blocks; the scatter kernel zeroed the counts)
     if (cnt != 0u && (uint32_t)gtid < (1u << sh)) {
         const uint32_t tile = (list << sh) + (uint32_t)gtid;
+        uint32_t items = 0u;
         if (tile < T) {
             const uint32_t a = s_bin[(uint32_t)gtid * BPS], b = s_bin[((uint32_t)gtid + 1u) * BPS];
             ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
+            items = (b - a) < wk.min_len ? 0u : (b - a + wk.chunk - 1u) / wk.chunk;
+        }
+        if (wk.partial != nullptr) {
+            for (uint32_t d = 1; d < (1u << sh); d <<= 1) items += (uint32_t)__shfl_xor(items, (int)d);   // lanes 0 .. 2^sh - 1: all here
+            if (gtid == 0 && items != 0u) atomicAdd(&wk.partial[(list << sh) / wk.block_tiles], items);
         }
     }
     uint32_t base_len[PER];
@@ -421,6 +448,7 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
         }
     }
     __syncthreads();
+    VS_TS(11);
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t i = u * NT + (uint32_t)gtid;
@@ -429,23 +457,50 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
             uint32_t r = 0;
             if (len > 1u)
                 for (uint32_t q = b0; q < b0 + len; ++q) r += s_a[q] < mine[u] ? 1u : 0u;
-            const uint32_t pos = start + b0 + r;
-            point_list[pos] = (uint32_t)mine[u] & VS_ID_MASK;
-            tiles_out[pos] = (list << sh) + (uint32_t)(mine[u] >> 61);
+            base_len[u] = b0 + r;   // the entry's position in the sorted list
         }
     }
+    // The ids go to their positions in LDS first and leave in list order with unit-stride stores: written straight from the
+    // lanes that hold them, every store instruction of a wave touched 64 different cache lines -- two scattered 4-byte stores per
+    // instance were most of this kernel (66 -> see DESIGN.md section 4).  The tile of position j follows from the tile boundaries.
+    uint32_t *s_out = reinterpret_cast<uint32_t *>(s_a);
+    __syncthreads();   // the ranks have been read
+    VS_TS(12);
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t i = u * NT + (uint32_t)gtid;
+        if (i < cnt) s_out[base_len[u]] = (uint32_t)mine[u] & VS_ID_MASK;
+    }
+    uint32_t bnd[(1u << VS_MAX_SHIFT) - 1u];   // first position of tiles 1 .. 2^sh - 1 of the stick
+#pragma unroll
+    for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT) - 1u; ++k)
+        bnd[k] = (k + 1u) < (1u << sh) ? __builtin_amdgcn_readfirstlane(s_bin[(k + 1u) * BPS]) : 0xFFFFFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+        const uint32_t j = u * NT + (uint32_t)gtid;
+        if (j < cnt) {
+            uint32_t sub = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT) - 1u; ++k) sub += j >= bnd[k] ? 1u : 0u;
+            point_list[start + j] = s_out[j];
+            tiles_out[start + j] = (list << sh) + sub;
+        }
+    }
+    VS_TS(13);
 }
 
 __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
     const uint4 *__restrict__ big, const uint4 *__restrict__ small, const uint32_t *__restrict__ nparts,
     const uint2 *__restrict__ pairs, uint32_t sh, uint32_t T, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
-    uint2 *__restrict__ ranges)
+    uint2 *__restrict__ ranges, const VSWork wk)
 {
     extern __shared__ unsigned long long vsk_lds[];
     __shared__ uint32_t s_mm[4][VSK_THREADS / 64], s_wsum[VSK_THREADS / 64];
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the descriptor is requested together with the counts that say whether it exists (one round trip, not two)
+    VS_TS(7);
     const uint4 pd = big[min(p, VS_MAX_LISTS - 1u)];
     const uint32_t nbig = nparts[0], nsmall = nparts[1];
     if (p >= nbig) {
@@ -482,7 +537,7 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
         }
         vs_group_range<256>(kmin, kmax, pmax, nmin, s_mm, lane, wave, w0);
         vs_sort_group<256, VSK_SMALL_PER, VSK_SMALL_BINS>(mine, s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, pmax, nmin, sh,
-                                                          list, T, start, point_list, tiles_out, ranges);
+                                                          list, T, start, point_list, tiles_out, ranges, wk);
         return;
     }
     // ---- big: one list for the whole workgroup
@@ -510,7 +565,7 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
     }
     vs_group_range<VSK_THREADS>(kmin, kmax, pmax, nmin, s_mm, lane, wave, 0);
     vs_sort_group<VSK_THREADS, VSK_BIG_PER, VSK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, n, kmin, kmax, pmax, nmin, sh, list,
-                                                          T, start, point_list, tiles_out, ranges);
+                                                          T, start, point_list, tiles_out, ranges, wk);
 }
 
 // ---- host side
@@ -582,21 +637,35 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     uint32_t stride = 32;
     while (stride < NL) stride <<= 1;
     const VoxelSticks st = VoxelSticks::carve(geom.stick_temp, P);
-    VSCounters *ctr = reinterpret_cast<VSCounters *>(st.ctr);
-    const uint32_t NW = (uint32_t)st.NW;
+    const VSGrid grid = vs_grid(P, device_cu_count());
+    const uint32_t NW = grid.wgs;   // <= st.NW rows
+    int dev = 0;
+    R2_HIP_TRY(hipGetDevice(&dev));
+    VSCounters *ctr = reinterpret_cast<VSCounters *>(voxel_small_counter_block(dev, s));
+    if (!ctr) {
+        g_vs_declined.fetch_add(1, std::memory_order_relaxed);
+        return VOX_STICKS_NOT_TAKEN;
+    }
+    uint32_t *nparts = st.ctr;
 
     uint32_t *mailbox = nullptr, seq = 0;
     int rc = host_mailbox_arm(&mailbox, &seq);
     if (rc) return rc;
     { StageScope t(ST_VOX_PREPROCESS, s);
-    launch_voxel_preprocess(geom, v, P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, radii_x, radii_y,
-                            radii_z, DepthReg{}, true, s, st.ctr); }
+    launch_voxel_cull_count(geom, v, P, grid, means3D, scales, scale_modifier, rotations, cov3D_precomp, radii_x, radii_y, radii_z, sh, stride,
+                            st.H, st.wgtot, ctr, s); }
     R2_HIP_TRY(hipGetLastError());
     { StageScope t(ST_VOX_SCAN, s);
-    vox_stick_count_kernel<<<dim3(NW), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
-        P, (uint32_t)v.gx, (uint32_t)v.gy, sh, stride, geom.tiles_touched, geom.cube, st.H, st.wgtot, ctr);
     vox_stick_scan_kernel<<<dim3(stride / VSS_LISTS), dim3(VSS_THREADS), 0, s>>>(st.H, NW, stride, st.totals, ctr, geom.host_words,
                                                                                 mailbox, seq); }
+    R2_HIP_TRY(hipGetLastError());
+    // the render records: nothing before the render kernel reads them, so they are written while the host waits for the totals,
+    // sizes the two remaining state buffers and launches the rest (as a part of the first kernel they left the GPU idle for 12 us
+    // there).  Measured and left out: a first message with the instance count from the cull + count kernel's last workgroup, the
+    // rest of the chain enqueued before the scan's verdict on the longest list is read -- the records kernel already covers the
+    // wait, and the extra counter cost the first kernel 4 us (475 -> 482 us per query)
+    { StageScope t(ST_VOX_PREPROCESS, s);
+    launch_voxel_records(geom, v, P, means3D, opacities, cov3D_precomp, s); }
     R2_HIP_TRY(hipGetLastError());
     uint32_t hw[DW_COUNT] = { 0 };
     rc = host_mailbox_wait(seq, hw, DW_COUNT, s);
@@ -621,20 +690,26 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
     const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false);
     uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // the backward's moment scratch (48 bytes per instance), free until then
+    // the render kernel's work list: for more than 4096 tiles the sort kernel leaves the work items per block of tiles behind
+    // (one launch of the construction instead of two)
+    const bool sums = T > 4096 && img.work_temp != nullptr && R > 0;
+    const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_chunk_for(R),
+                    voxel_short_list_min(false)};
+    const uint32_t n_partial = sums ? (uint32_t)((T + wk.block_tiles - 1) / wk.block_tiles) : 0u;
     { StageScope t(ST_VOX_DUPLICATE, s);
     vox_stick_scatter_kernel<<<dim3(NW + 1u), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
-        P, (uint32_t)v.gx, (uint32_t)v.gy, (uint32_t)T, sh, NL, stride, geom.tiles_touched, geom.cube, geom.depth_key, geom.first,
-        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, ctr->nparts); }
+        P, grid.per_wg, grid.ni, (uint32_t)v.gx, (uint32_t)v.gy, (uint32_t)T, sh, NL, stride, geom.tiles_touched, geom.cube, geom.depth_key, geom.first,
+        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, nparts, wk.partial, n_partial); }
     R2_HIP_TRY(hipGetLastError());
     if (R > 0) {
         StageScope t(ST_VOX_SORT, s);
         vox_stick_sort_kernel<<<dim3(NL + (NL + VSK_GROUPS - 1) / VSK_GROUPS), dim3(VSK_THREADS), VSK_LDS, s>>>(
-            st.big, st.small, ctr->nparts, pairs, sh, (uint32_t)T, bin.point_list, bin.tiles, img.ranges);
+            st.big, st.small, nparts, pairs, sh, (uint32_t)T, bin.point_list, bin.tiles, img.ranges, wk);
     }
     R2_HIP_TRY(hipGetLastError());
     { StageScope t(ST_VOX_RANGES, s);
-    launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(R), img.chunk_base, img.work_tile, img.work_temp, s,
-                      voxel_short_list_min(false)); }
+    if (sums) launch_build_work_from_partials(img.ranges, (uint32_t)T, wk.chunk, img.chunk_base, img.work_tile, wk.partial, s, wk.min_len);
+    else launch_build_work(img.ranges, (uint32_t)T, wk.chunk, img.chunk_base, img.work_tile, img.work_temp, s, wk.min_len); }
     R2_HIP_TRY(hipGetLastError());
     { StageScope t(ST_VOX_RENDER_FWD, s);
     launch_voxel_render_forward(geom, bin, img, v, out_volume, false, s); }

@@ -404,6 +404,17 @@ int main(int argc, char **argv)
     CHECK(hipStreamSynchronize(s));
     const double tv = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count() / 10;
     printf("voxel 256^3: %.3f ms  %.2f GVoxel/s  (R3 %d)\n", tv * 1e3, 256.0 * 256 * 256 / tv / 1e9, R3);
+    // experiment builds: the stamp table of the stick-first chain's kernels (voxel_sticks.hip) for ONE more call, raw, for
+    // scripts/sticks_timeline.py ([16 phases][2048 workgroups] of 100 MHz ticks)
+    if (void *pt = dlsym(h, "r2_debug_ts_sticks")) {
+        CHECK(hipStreamSynchronize(s));
+        vox();
+        CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> ts(16 * 2048);
+        reinterpret_cast<int (*)(unsigned long long *)>(pt)(ts.data());
+        const char *path = getenv("R2_TS_DUMP") ? getenv("R2_TS_DUMP") : "gpurun_out/ts_sticks.bin";
+        if (FILE *f = fopen(path, "wb")) { fwrite(ts.data(), 8, ts.size(), f); fclose(f); printf("stamps of the stick chain -> %s\n", path); }
+    }
     // the training loop's TV regulariser: forward + backward on a 32^3 sub-volume (train.py, tv_vol_size = 32)
     {
         float *dLv;
