@@ -306,13 +306,13 @@ R2_API void r2_tile_first_control(int mode);
  * a densification).  out may be NULL (reset only). */
 R2_API void r2_tile_first_stats(long long out[5], int reset);
 
-/* Stick-first binning of the voxelizer (csrc/voxel_sticks.hip): grids of more than 4096 tiles (the 256^3 query of
- * test.py:105-112: 32 768) are binned without a global sort -- instances are counted and scattered per STICK of up to 8
- * consecutive tiles and every stick's list is sorted on (tile, z bits, id) on its own.  point_list, ranges, volumes and gradients
- * are identical on both chains; a scene with a stick list longer than one workgroup sorts (8192 instances) continues on the
- * general chain, and the calling thread remembers that for the (P, grid).  mode 0: never, 1: grids of more than 4096 tiles
- * (default; also the environment variable R2_VOXEL_STICKS=0/1/2), 2: every grid of more than 64 and up to 32 768 tiles,
- * 3: forget the calling thread's notes. */
+/* Stick-first binning of the voxelizer (csrc/voxel_sticks.hip): grids of more than 64 and up to 32 768 tiles (the 256^3 query of
+ * test.py:105-112) are binned without a global sort -- instances are counted and scattered per STICK of up to 8 consecutive
+ * tiles (per tile up to 4096 tiles) and every stick's list is sorted on (tile, z bits, id) on its own.  point_list, ranges,
+ * volumes and gradients are identical on both chains; a scene with a list longer than one workgroup sorts (8192 instances)
+ * continues on the general chain, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids and
+ * P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
+ * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes. */
 R2_API void r2_voxel_sticks_control(int mode);
 /* process-wide counts since the last reset: out[0] forwards that took the chain, [1] forwards that left it after its scan for
  * the general chain, [2] forwards it declined.  out may be NULL (reset only). */

@@ -146,6 +146,7 @@ __global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
     }
 }
 
+constexpr uint32_t VSS_SERVICE = 2;   // workgroups of the scatter kernel that do not scatter
 // ---- 4. scatter.  Workgroup 0 does not scatter: it builds the sort kernel's two lists from the list totals and gives the
 // tiles of empty lists their (0, 0) ranges (the reference's memset).
 __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
     uint32_t *__restrict__ first, uint32_t *__restrict__ order, const uint32_t *__restrict__ H,
     const uint32_t *__restrict__ totals, const uint32_t *__restrict__ wgtot, uint2 *__restrict__ pairs,
     uint2 *__restrict__ ranges, uint4 *__restrict__ big, uint4 *__restrict__ small, uint32_t *__restrict__ nparts,
-    uint32_t *__restrict__ work_partial, uint32_t n_partial)
+    uint32_t *__restrict__ work_partial, uint32_t n_partial, const WorkListOut wo /* ranges == nullptr: not here */)
 {
     extern __shared__ uint32_t s_pos[];   // [stride] start of the list's segment + this workgroup's offset in it, bumped per instance
     __shared__ uint32_t s_wsum[2 + VS_PER_THREAD_MAX][VS_THREADS / 64], s_carry[3], s_base;
@@ -192,7 +193,13 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
         if (tid == 0) { nparts[0] = s_carry[1]; nparts[1] = s_carry[2]; }
         return;
     }
-    const uint32_t wg = blockIdx.x - 1u;
+    if (blockIdx.x == 1) {
+        // ---- second service workgroup.  Grids of up to 4096 tiles: a list IS a tile, so the list totals are all it takes for the
+        // tile ranges and the render kernel's work list (the launch of its own that builds them from the ranges otherwise: 9 us)
+        if (wo.ranges != nullptr) ranges_and_work_block<VS_THREADS>(totals, wo);
+        return;
+    }
+    const uint32_t wg = blockIdx.x - VSS_SERVICE;
     VS_TS(4);
     // this thread's Gaussians (vs_grid): requested now, used after the scans (everything here was written by earlier kernels on
     // other XCDs)
@@ -490,6 +497,11 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
     VS_TS(13);
 }
 
+// (Measured and left out, round 5: PERSISTENT workgroups, two per CU, each taking items blockIdx.x, + gridDim.x, ... and requesting
+//  the next item's descriptor while it sorts the current one -- a workgroup's start is two dependent round trips, 4.2 of its
+//  10.7 us.  Inlined, the loop made the compiler hoist every item's address arithmetic in front of it (20 registers spilled); as
+//  calls, with the static assignment: 51 -> 82 us.  The hardware's dispatch of one workgroup per item balances lists of 1600 to
+//  6000 entries better than a stride does.)
 __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
     const uint4 *__restrict__ big, const uint4 *__restrict__ small, const uint32_t *__restrict__ nparts,
     const uint2 *__restrict__ pairs, uint32_t sh, uint32_t T, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
@@ -591,7 +603,7 @@ VSNote *vs_note(int P, const VoxelGrid &v, bool create)
 
 // forwards that took the chain, forwards that left it after the scan (a list too long), forwards it declined
 std::atomic<long long> g_vs_taken{0}, g_vs_fallback{0}, g_vs_declined{0};
-std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1: grids of more than 4096 tiles, 2: every grid it can serve
+std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1 (or 2): every grid it can serve
 
 int vs_mode()
 {
@@ -624,7 +636,7 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     uint32_t sh = 0;
     while (sh <= VS_MAX_SHIFT && ((T + ((size_t)1 << sh) - 1) >> sh) > VS_MAX_LISTS) ++sh;
     // ids share a word with the tile-in-stick bits; the cube packs tile coordinates into 16 bits; 32-bit instance offsets
-    if (mode == 0 || (mode == 1 && T <= 4096) || T <= VOX_SMALL_MAX_TILES || sh > VS_MAX_SHIFT || P >= (1 << VS_ID_BITS) ||
+    if (mode == 0 || T <= VOX_SMALL_MAX_TILES || sh > VS_MAX_SHIFT || P >= (1 << VS_ID_BITS) ||
         v.gx > 65535 || v.gy > 65535 || v.gz > 65535 || !vs_lds_ok()) {
         g_vs_declined.fetch_add(1, std::memory_order_relaxed);
         return VOX_STICKS_NOT_TAKEN;
@@ -696,10 +708,13 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_chunk_for(R),
                     voxel_short_list_min(false)};
     const uint32_t n_partial = sums ? (uint32_t)((T + wk.block_tiles - 1) / wk.block_tiles) : 0u;
+    // ... and for up to 4096 tiles (lists = tiles) the scatter kernel's second service workgroup builds ranges and work list
+    const bool direct = sh == 0u;
+    const WorkListOut wo{direct ? img.ranges : nullptr, img.chunk_base, img.work_tile, (uint32_t)T, wk.chunk, nullptr, wk.min_len, 0u};
     { StageScope t(ST_VOX_DUPLICATE, s);
-    vox_stick_scatter_kernel<<<dim3(NW + 1u), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
+    vox_stick_scatter_kernel<<<dim3(NW + VSS_SERVICE), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
         P, grid.per_wg, grid.ni, (uint32_t)v.gx, (uint32_t)v.gy, (uint32_t)T, sh, NL, stride, geom.tiles_touched, geom.cube, geom.depth_key, geom.first,
-        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, nparts, wk.partial, n_partial); }
+        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, nparts, wk.partial, n_partial, wo); }
     R2_HIP_TRY(hipGetLastError());
     if (R > 0) {
         StageScope t(ST_VOX_SORT, s);
@@ -707,7 +722,8 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
             st.big, st.small, nparts, pairs, sh, (uint32_t)T, bin.point_list, bin.tiles, img.ranges, wk);
     }
     R2_HIP_TRY(hipGetLastError());
-    { StageScope t(ST_VOX_RANGES, s);
+    if (!direct) {
+    StageScope t(ST_VOX_RANGES, s);
     if (sums) launch_build_work_from_partials(img.ranges, (uint32_t)T, wk.chunk, img.chunk_base, img.work_tile, wk.partial, s, wk.min_len);
     else launch_build_work(img.ranges, (uint32_t)T, wk.chunk, img.chunk_base, img.work_tile, img.work_temp, s, wk.min_len); }
     R2_HIP_TRY(hipGetLastError());

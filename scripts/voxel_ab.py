@@ -1,6 +1,6 @@
 """256^3 query of the benchmark cloud on the general binning chain and on the stick-first chain (csrc/voxel_sticks.hip), alternating
 on ONE box: ms per call (median of 5 x n calls, as bench.py times it), per-stage times of the same call, and the two volumes compared
-bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000] [grid=256]"""
+bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes; 2 = every grid)"""
 import ctypes as C
 import statistics
 import sys
@@ -15,6 +15,7 @@ from r2_gaussian_amd import scene as S
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 256
+MODES = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0, 1)
 dev = torch.device("cuda:0")
 c = S.make_cloud(P, seed=0)
 e = torch.empty(0)
@@ -23,7 +24,7 @@ a = (c.xyz.to(dev), c.density.to(dev), c.scales.to(dev), c.rotations.to(dev), 1.
 L = _lib.lib()
 vols = {}
 for rep in range(2):
-    for mode in (0, 1):
+    for mode in MODES:
         L.r2_voxel_sticks_control(mode)
         with torch.no_grad():
             for _ in range(3):
@@ -51,6 +52,6 @@ for rep in range(2):
             flush=True)
         vols[mode] = out[1].clone()
 L.r2_voxel_sticks_control(1)
-same = torch.equal(vols[0].view(torch.int32), vols[1].view(torch.int32))
+same = torch.equal(vols[MODES[0]].view(torch.int32), vols[MODES[-1]].view(torch.int32))
 print("volumes identical bit for bit:", same)
 sys.exit(0 if same else 1)

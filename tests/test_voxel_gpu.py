@@ -235,6 +235,7 @@ def test_backward_after_a_hinted_overflow(oracle, gpu):
     c = S.make_cloud(P, seed=6)
     n, s, ctr = (40, 40, 40), (1.0, 1.0, 1.0), (0.5, 0.0, 0.0)     # x < 0 is outside: about half of the cloud is culled
     try:
+        L.r2_voxel_sticks_control(0)                               # the general binning chain is the one with a depth order
         L.r2_depth_hint_control(2)
         Hh.hip_voxel(c, n, s, ctr, gpu)                            # un-hinted, arms the hint for this P
         xyz = c.xyz.clone()
@@ -257,6 +258,7 @@ def test_backward_after_a_hinted_overflow(oracle, gpu):
             # every visible Gaussian got a row
             assert (np.abs(gh["dL_dopacity"].reshape(-1)[o["tiles_touched"] > 0]) > 0).mean() > 0.9
     finally:
+        L.r2_voxel_sticks_control(1)
         L.r2_depth_hint_control(1)
         L.r2_depth_hint_control(2)
 

@@ -26,8 +26,7 @@ def _stats(reset=True):
 
 @pytest.fixture
 def sticks_mode():
-    """-> a setter of the chain's mode (0 off, 1 grids of more than 4096 tiles, 2 every grid it can serve); the default and the
-    thread's notes are restored afterwards"""
+    """-> a setter of the chain's mode (0 off, 1 on); the default and the thread's notes are restored afterwards"""
     L = _lib()
     L.r2_voxel_sticks_control(3)
     yield L.r2_voxel_sticks_control
@@ -35,10 +34,10 @@ def sticks_mode():
     L.r2_voxel_sticks_control(3)
 
 
-# (P, nVoxel, sVoxel, center, scale_mult, mode that selects the chain)
+# (P, nVoxel, sVoxel, center, scale_mult, mode)
 CASES = [
-    (5000, (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0), 1.0, 2),            # 512 tiles: a list is a tile (shift 0)
-    (3000, (40, 28, 52), (2.0, 1.4, 2.6), (0.05, 0.0, -0.1), 1.5, 2),          # ragged grid, 140 tiles
+    (5000, (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0), 1.0, 1),            # 512 tiles: a list is a tile (shift 0)
+    (3000, (40, 28, 52), (2.0, 1.4, 2.6), (0.05, 0.0, -0.1), 1.5, 1),          # ragged grid, 140 tiles
     (4000, (136, 136, 136), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0), 1.0, 1),         # 4913 tiles: sticks of 2, the last one partial
     (6000, (168, 136, 104), (2.0, 1.6, 1.2), (0.02, -0.03, 0.3), 1.0, 1),      # 4641 tiles, ragged, off-centre in z
     (20000, (256, 256, 256), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0), 1.0, 1),        # 32768 tiles: sticks of 8 (the headline query's grid)
@@ -133,7 +132,7 @@ def test_a_list_too_long_for_the_chain_continues_on_the_general_one(oracle, gpu,
     n, s, ctr = (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
     o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
     assert int((o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max()) > 8192
-    sticks_mode(2)
+    sticks_mode(1)
     _stats()
     h = Hh.hip_voxel(c, n, s, ctr, gpu)
     assert _stats() == [0, 1, 0] and not Hh.took_sticks(h)
