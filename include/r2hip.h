@@ -309,10 +309,12 @@ R2_API void r2_tile_first_stats(long long out[5], int reset);
 /* Stick-first binning of the voxelizer (csrc/voxel_sticks.hip): grids of more than 64 and up to 32 768 tiles (the 256^3 query of
  * test.py:105-112) are binned without a global sort -- instances are counted and scattered per STICK of up to 8 consecutive
  * tiles (per tile up to 4096 tiles) and every stick's list is sorted on (tile, z bits, id) on its own.  point_list, ranges,
- * volumes and gradients are identical on both chains; a scene with a list longer than one workgroup sorts (8192 instances)
- * continues on the general chain, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids and
- * P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
- * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes. */
+ * volumes and gradients are identical on both chains; a scene of large Gaussians in dense lists (more than 32 tiles per Gaussian on
+ * average and a list of more than 8192 instances: trained clouds, where the general chain's wave-cooperative emission is the
+ * faster one) continues on the general chain after the preprocess, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids
+ * and P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
+ * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes; 4 / 5 (tests): lists of more than 8192
+ * instances count as unsupported / are sorted in parts (default). */
 R2_API void r2_voxel_sticks_control(int mode);
 /* process-wide counts since the last reset: out[0] forwards that took the chain, [1] forwards that left it after its scan for
  * the general chain, [2] forwards it declined.  out may be NULL (reset only). */

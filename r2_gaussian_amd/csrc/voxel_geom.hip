@@ -263,21 +263,102 @@ __global__ void __launch_bounds__(VS_PRODUCER) voxel_cull_count_kernel(
     for (uint32_t i = tid; i < stride; i += VS_PRODUCER) row[i] = s_hist[i];
 }
 
-// ... and part 2 for the visible ones: the inverse covariance is recomputed from the stored 3D covariance (the same operations on
-// the same values: the same bits)
-__global__ void __launch_bounds__(256) voxel_record_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ opacities,
-                                                           const float *__restrict__ cov3Ds, const uint32_t *__restrict__ tiles_touched,
-                                                           VoxelGrid v, float4 *__restrict__ rec, float4 *__restrict__ ext)
+// ... and part 2 for the visible ones (the inverse covariance is recomputed from the stored 3D covariance: the same operations on the
+// same values, the same bits), in ONE launch with the chain's column scan -- two independent jobs, the scan on the first nscan
+// workgroups (the layout of rs_scan_kernel, radix_sort.hip: a workgroup owns 32 consecutive lists, its 32 thread rows split the
+// producer workgroups, every access is a full 128-byte row segment; its last workgroup posts the call's totals to the host).
+constexpr int VSS_THREADS = (int)VS_PRODUCER, VSS_LISTS = 32, VSS_ROWS = VSS_THREADS / VSS_LISTS, VSS_BATCH = 16;
+__device__ __forceinline__ void vs_scan_columns(uint32_t bx, uint32_t nblocks, uint32_t *__restrict__ H, uint32_t rows, uint32_t stride,
+                                                uint32_t *__restrict__ totals, VSCounters *__restrict__ ctr, uint32_t *__restrict__ words,
+                                                uint32_t *__restrict__ mailbox, uint32_t seq)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= P || tiles_touched[idx] == 0u) return;
-    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
-    const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
-    float cov3D[6], inv[6];
+    __shared__ uint32_t part[VSS_ROWS][VSS_LISTS];
+    const uint32_t dl = threadIdx.x % VSS_LISTS, row = threadIdx.x / VSS_LISTS;
+    const uint32_t d = bx * VSS_LISTS + dl;   // < stride (a multiple of 32)
+    const uint32_t per = (rows + VSS_ROWS - 1) / VSS_ROWS;
+    const uint32_t t0 = min(rows, row * per), t1 = min(rows, t0 + per);
+    uint32_t sum = 0;
+    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
+        uint32_t v[VSS_BATCH];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
-    if (!voxel_inverse(cov3D, dvx, dvy, dvz, inv)) return;   // (cannot happen: part 1 gave it tiles)
-    voxel_record_one(idx, voxel_position(p, v, dvx, dvy, dvz), inv, opacities, rec, ext);
+        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u) sum += (t + (uint32_t)u < t1) ? v[u] : 0u;
+    }
+    part[row][dl] = sum;
+    __syncthreads();
+    uint32_t run = 0, total = 0;
+#pragma unroll
+    for (int r = 0; r < VSS_ROWS; ++r) {
+        const uint32_t v = part[r][dl];
+        if ((uint32_t)r < row) run += v;
+        total += v;
+    }
+    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
+        uint32_t v[VSS_BATCH];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
+#pragma unroll
+        for (int u = 0; u < VSS_BATCH; ++u)
+            if (t + (uint32_t)u < t1) {
+                H[(size_t)(t + (uint32_t)u) * stride + d] = run;
+                run += v[u];
+            }
+    }
+    if (row == 0) totals[d] = total;
+    // the longest list of the call; the last workgroup to get here tells the host
+    if (threadIdx.x < 64) {
+        uint32_t m = row == 0 ? total : 0u;
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor(m, s));
+        if (threadIdx.x == 0) {
+            atomicMax(&ctr->maxlist, m);
+            __threadfence();
+            const uint32_t done = atomicAdd(&ctr->scan_done, 1u);
+            if (done == nblocks - 1u) {
+                __threadfence();
+                const uint32_t ml = atomicMax(&ctr->maxlist, 0u);
+                const unsigned long long tot = atomicAdd(&ctr->total, 0ull);
+                const unsigned long long r40 = tot & ((1ull << 40) - 1ull);
+                const uint32_t R = r40 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r40;
+                // DW_NVIS = 0: `order` will hold all P ids (the geometry backward walks all of it)
+                words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = VOX_STICKS_MARK; words[DW_PMAX] = ml;
+                words[DW_PNMAX] = 0u; words[DW_NMAX] = 0u; words[DW_NNMAX] = 0u; words[DW_NVIS] = 0u;
+                mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = VOX_STICKS_MARK; mailbox[DW_PMAX] = ml;
+                mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = 0u; mailbox[DW_NNMAX] = 0u; mailbox[DW_NVIS] = (uint32_t)(tot >> 40);
+                __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                // every other workgroup is through with the counters: ready for the thread's next call on this stream
+                __hip_atomic_store(&ctr->total, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr->maxlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&ctr->scan_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(VS_PRODUCER) voxel_scan_records_kernel(
+    uint32_t nscan, uint32_t *__restrict__ H, uint32_t rows, uint32_t stride, uint32_t *__restrict__ totals, VSCounters *__restrict__ ctr,
+    uint32_t *__restrict__ words, uint32_t *__restrict__ mailbox, uint32_t seq, int P, uint32_t per_wg, uint32_t ni,
+    const float *__restrict__ means3D, const float *__restrict__ opacities, const float *__restrict__ cov3Ds,
+    const uint32_t *__restrict__ tiles_touched, VoxelGrid v, float4 *__restrict__ rec, float4 *__restrict__ ext)
+{
+    if (blockIdx.x < nscan) {
+        vs_scan_columns(blockIdx.x, nscan, H, rows, stride, totals, ctr, words, mailbox, seq);
+        return;
+    }
+    const uint32_t wg = blockIdx.x - nscan;   // the producers' mapping (vs_grid): one workgroup per CU
+    const uint32_t g0 = wg * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
+    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    for (uint32_t it = 0; it < ni; ++it) {
+        const uint32_t idx = g0 + it * VS_PRODUCER + threadIdx.x;
+        if (idx >= g1 || tiles_touched[idx] == 0u) continue;
+        const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
+        float cov3D[6], inv[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) cov3D[k] = cov3Ds[6 * idx + k];
+        if (!voxel_inverse(cov3D, dvx, dvy, dvz, inv)) continue;   // (cannot happen: part 1 gave it tiles)
+        voxel_record_one((int)idx, voxel_position(p, v, dvx, dvy, dvz), inv, opacities, rec, ext);
+    }
 }
 
 int launch_voxel_cull_count(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D, const float *scales,
@@ -290,11 +371,14 @@ int launch_voxel_cull_count(const VoxelGeom &g, const VoxelGrid &v, int P, const
     return 0;
 }
 
-int launch_voxel_records(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
-                         const float *cov3D_precomp, hipStream_t s)
+int launch_voxel_scan_records(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D,
+                              const float *opacities, const float *cov3D_precomp, uint32_t *H, uint32_t rows, uint32_t stride,
+                              uint32_t *totals, VSCounters *ctr, uint32_t *mailbox, uint32_t seq, hipStream_t s)
 {
-    voxel_record_kernel<<<dim3((P + 255) / 256), dim3(256), 0, s>>>(P, means3D, opacities, cov3D_precomp ? cov3D_precomp : g.cov3D,
-                                                                    g.tiles_touched, v, g.rec, g.ext);
+    const uint32_t nscan = stride / VSS_LISTS;
+    voxel_scan_records_kernel<<<dim3(nscan + grid.wgs), dim3(VS_PRODUCER), 0, s>>>(
+        nscan, H, rows, stride, totals, ctr, g.host_words, mailbox, seq, P, grid.per_wg, grid.ni, means3D, opacities,
+        cov3D_precomp ? cov3D_precomp : g.cov3D, g.tiles_touched, v, g.rec, g.ext);
     return 0;
 }
 

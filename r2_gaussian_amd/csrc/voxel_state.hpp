@@ -45,7 +45,7 @@ __device__ __forceinline__ bool needs_exact_slab3(float D2, float F2, float L, f
     return !(smax > 0.f && need <= smax) || !(hx < 3.0e38f);
 }
 
-// Workspace of the stick-first binning chain (voxel_sticks.hip), part of the geometry state: 16 bytes per Gaussian + 150 KB.
+// Workspace of the stick-first binning chain (voxel_sticks.hip), part of the geometry state: 18 bytes per Gaussian + 150 KB.
 constexpr uint32_t VS_MAX_LISTS = 4096;     // lists (sticks of 2^shift consecutive tiles) per call: one LDS histogram
 constexpr uint32_t VS_PRODUCER = 1024;      // Gaussians per producer workgroup (512: the same scatter time, twice the rows to scan: +6 us)
 // Producer workgroups of the chain (cull + count, scatter): VS_PRODUCER threads, ONE workgroup per CU as long as a thread then
@@ -77,7 +77,9 @@ struct VoxelSticks {
     uint32_t *ctr;       // [16]  {big lists, short lists} for the sort kernel
     uint32_t *totals;    // [VS_MAX_LISTS] instances per list
     uint32_t *wgtot;     // [NW]  instances per producer workgroup
-    uint4 *big, *small;  // [VS_MAX_LISTS] each: the sort kernel's work lists {list, 0, first instance, instances}
+    uint4 *big, *small;  // the sort kernel's work lists {list, part, first instance, instances}: [bigcap] long lists (one entry per
+                         // part of a list beyond one workgroup's capacity), [VS_MAX_LISTS] short ones
+    size_t bigcap;
     uint32_t *H;         // [NW][stride] instances per (producer workgroup, list) -> after the scan: exclusive prefix over the workgroups
     size_t NW;
     size_t bytes;
@@ -89,7 +91,8 @@ struct VoxelSticks {
         t.ctr = b.take<uint32_t>(16);
         t.totals = b.take<uint32_t>(VS_MAX_LISTS);
         t.wgtot = b.take<uint32_t>(t.NW);
-        t.big = b.take<uint4>(VS_MAX_LISTS);
+        t.bigcap = VS_MAX_LISTS + (size_t)(P > 0 ? P : 0) / 8;
+        t.big = b.take<uint4>(t.bigcap);
         t.small = b.take<uint4>(VS_MAX_LISTS);
         t.H = b.take<uint32_t>(t.NW * VS_MAX_LISTS);
         t.bytes = b.total();
@@ -247,12 +250,14 @@ void voxel_sticks_release();   // the calling thread's notes about that chain (r
 // 64 bytes of device memory, zero between calls, owned by the calling thread for (current device, stream); nullptr: none to be had
 unsigned long long *voxel_small_counter_block(int dev, hipStream_t s);
 // the preprocess as two kernels: (1) everything the binning needs + the per-(workgroup, list) instance counts of the stick-first
-// chain (lists = tile id >> shift; H[workgroup][stride], wgtot[workgroup], the call's totals into ctr), (2) the render records
+// chain (lists = tile id >> shift; H[workgroup][stride], wgtot[workgroup], the call's totals into ctr), (2) the render records,
+// in one launch with the column scan of H (whose last workgroup posts the totals to the host mailbox)
 int launch_voxel_cull_count(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D, const float *scales,
                             float scale_modifier, const float *rotations, const float *cov3D_precomp, int *radii_x, int *radii_y,
                             int *radii_z, uint32_t shift, uint32_t stride, uint32_t *H, uint32_t *wgtot, VSCounters *ctr, hipStream_t s);
-int launch_voxel_records(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
-                         const float *cov3D_precomp, hipStream_t s);
+int launch_voxel_scan_records(const VoxelGeom &g, const VoxelGrid &v, int P, const VSGrid &grid, const float *means3D,
+                              const float *opacities, const float *cov3D_precomp, uint32_t *H, uint32_t rows, uint32_t stride,
+                              uint32_t *totals, VSCounters *ctr, uint32_t *mailbox, uint32_t seq, hipStream_t s);
 int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                          const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                          const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,

@@ -16,18 +16,19 @@
 //     bucket sort of raster_tilefirst.hip with the buckets divided among the stick's tiles -- and writes point_list, the
 //     per-instance tile ids and the ranges of its tiles.
 // Sorting every list by (tile, z bits, id) IS the reference's (tile | z bits) order with its tie rule (emission order = id
-// order): point_list and ranges are bit-identical to the general chain's, which stays as the path of debug mode, of grids of up
-// to 4096 tiles, and of scenes with a stick list longer than one workgroup sorts (trained clouds with Gaussians of many voxels:
-// the chain notices after its scan, continues on the general chain's un-hinted branch -- the preprocess is not repeated -- and
-// the thread remembers the (P, grid) for which that happened).
+// order): point_list and ranges are bit-identical to the general chain's, which stays as the path of debug mode, of grids of
+// more than 32 768 tiles, and of scenes whose long lists need more part descriptors than the state holds (the chain notices after
+// its scan, continues on the general chain's un-hinted branch -- the preprocess is not repeated -- and the thread remembers the
+// (P, grid) for which that happened).  A list beyond one workgroup's capacity (8192 entries: trained clouds, a million
+// Gaussians) is sorted by several workgroups, each a range of the list's (tile, z) axis.
 //
 //     1. voxel_cull_count_kernel (voxel_geom.hip)    the part of the preprocess the binning needs (radii, tile cube, z bits) + an LDS
 //                                                    histogram of the workgroup's instances over the lists -> H[wg][list]
-//     2. vox_stick_scan_kernel                       exclusive prefix of every column of H, list totals, longest list; the last
-//                                                    workgroup posts {num_rendered, longest list} to the host mailbox
-//     3. voxel_record_kernel (voxel_geom.hip)        the rest of the preprocess (the render kernels' records), enqueued at once:
-//                                                    it runs while the host waits for the totals and sizes the binning / image
-//                                                    state (the reference's D2H, VOX/voxelizer_impl.cu:248)
+//     2. voxel_scan_records_kernel (voxel_geom.hip)  two jobs in one launch: exclusive prefix of every column of H, list totals, longest
+//                                                    list -- the last scan workgroup posts {num_rendered, longest list} to the host
+//                                                    mailbox --, and the rest of the preprocess (the render kernels' records), which
+//                                                    runs while the host waits for the totals and sizes the binning / image state
+//                                                    (the reference's D2H, VOX/voxelizer_impl.cu:248)
 //     4. vox_stick_scatter_kernel                    instances -> list segments; first instance of every Gaussian (the backward's
 //                                                    moment rows); workgroup 0 builds the sort kernel's lists
 //     5. vox_stick_sort_kernel                       per-list sort, point_list, tiles, ranges
@@ -48,6 +49,8 @@ namespace {
 
 constexpr int VS_THREADS = (int)VS_PRODUCER;
 constexpr uint32_t VS_MAX_SHIFT = 3;       // tiles per stick = 2^shift <= 8: three bits above the 29-bit id
+constexpr uint32_t VS_MAX_TILES_PER_GAUSSIAN = 32;   // mean over the visible Gaussians of a call beyond which a scene with a list of more than
+                                                     // VSK_BIG_CAP instances goes to the general chain
 constexpr uint32_t VS_ID_BITS = 29;
 constexpr uint32_t VS_ID_MASK = (1u << VS_ID_BITS) - 1u;
 
@@ -57,7 +60,10 @@ constexpr int VSK_THREADS = 1024;
 constexpr int VSK_GROUPS = VSK_THREADS / 256;
 constexpr uint32_t VSK_SMALL_CAP = 1536, VSK_SMALL_PER = 6, VSK_SMALL_BINS = 1024;
 constexpr uint32_t VSK_BIG_CAP = 8192, VSK_BIG_PER = 8, VSK_BIG_BINS = 2048;
-constexpr size_t VSK_LDS = VSK_BIG_CAP * sizeof(unsigned long long) + (VSK_BIG_BINS + 1) * sizeof(uint32_t);
+constexpr uint32_t VSK_BIG_TARGET = 5120;   // lists beyond VSK_BIG_CAP: ceil(n / 5120) parts, each a range of the list's coarse histogram
+constexpr uint32_t VSK_COARSE = 1024;       // bins of that histogram (one per thread)
+constexpr size_t VSK_LDS = VSK_BIG_CAP * sizeof(unsigned long long) + (VSK_BIG_BINS + 1 + VSK_COARSE + 1) * sizeof(uint32_t);
+static_assert(VSK_COARSE == VSK_THREADS && VSK_BIG_CAP >= VSK_BIG_TARGET + VSK_BIG_TARGET / 2, "parts need slack over their target size");
 static_assert(VSK_GROUPS * VSK_SMALL_CAP * sizeof(unsigned long long) + VSK_GROUPS * (VSK_SMALL_BINS + 1) * sizeof(uint32_t) <= VSK_LDS,
               "the groups fit the big layout");
 static_assert(VSK_SMALL_PER * 256 == VSK_SMALL_CAP && VSK_BIG_PER * VSK_THREADS == VSK_BIG_CAP, "entries per thread");
@@ -73,79 +79,6 @@ __device__ __forceinline__ Cube cube_of(const uint4 c, uint32_t tt)
     return q;
 }
 
-// ---- 3. column scan (the layout of rs_scan_kernel, radix_sort.hip: a workgroup owns 32 consecutive lists, its 32 thread rows
-// split the producer workgroups, every access is a full 128-byte row segment) + the call's totals for the host
-constexpr int VSS_THREADS = 1024, VSS_LISTS = 32, VSS_ROWS = VSS_THREADS / VSS_LISTS, VSS_BATCH = 16;
-__global__ void __launch_bounds__(VSS_THREADS) vox_stick_scan_kernel(
-    uint32_t *__restrict__ H, uint32_t rows, uint32_t stride, uint32_t *__restrict__ totals, VSCounters *__restrict__ ctr,
-    uint32_t *__restrict__ words, uint32_t *__restrict__ mailbox, uint32_t seq)
-{
-    __shared__ uint32_t part[VSS_ROWS][VSS_LISTS];
-    VS_TS(2);
-    const uint32_t dl = threadIdx.x % VSS_LISTS, row = threadIdx.x / VSS_LISTS;
-    const uint32_t d = blockIdx.x * VSS_LISTS + dl;   // < stride (a multiple of 32)
-    const uint32_t per = (rows + VSS_ROWS - 1) / VSS_ROWS;
-    const uint32_t t0 = min(rows, row * per), t1 = min(rows, t0 + per);
-    uint32_t sum = 0;
-    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
-        uint32_t v[VSS_BATCH];
-#pragma unroll
-        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
-#pragma unroll
-        for (int u = 0; u < VSS_BATCH; ++u) sum += (t + (uint32_t)u < t1) ? v[u] : 0u;
-    }
-    part[row][dl] = sum;
-    __syncthreads();
-    uint32_t run = 0, total = 0;
-#pragma unroll
-    for (int r = 0; r < VSS_ROWS; ++r) {
-        const uint32_t v = part[r][dl];
-        if ((uint32_t)r < row) run += v;
-        total += v;
-    }
-    for (uint32_t t = t0; t < t1; t += VSS_BATCH) {
-        uint32_t v[VSS_BATCH];
-#pragma unroll
-        for (int u = 0; u < VSS_BATCH; ++u) v[u] = H[(size_t)min(t + (uint32_t)u, t1 - 1u) * stride + d];
-#pragma unroll
-        for (int u = 0; u < VSS_BATCH; ++u)
-            if (t + (uint32_t)u < t1) {
-                H[(size_t)(t + (uint32_t)u) * stride + d] = run;
-                run += v[u];
-            }
-    }
-    if (row == 0) totals[d] = total;
-    VS_TS(3);
-    // the longest list of the call; the last workgroup to get here tells the host
-    if (threadIdx.x < 64) {
-        uint32_t m = row == 0 ? total : 0u;
-#pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) m = max(m, (uint32_t)__shfl_xor(m, s));
-        if (threadIdx.x == 0) {
-            atomicMax(&ctr->maxlist, m);
-            __threadfence();
-            const uint32_t done = atomicAdd(&ctr->scan_done, 1u);
-            if (done == gridDim.x - 1u) {
-                __threadfence();
-                const uint32_t ml = atomicMax(&ctr->maxlist, 0u);
-                const unsigned long long tot = atomicAdd(&ctr->total, 0ull);
-                const unsigned long long r40 = tot & ((1ull << 40) - 1ull);
-                const uint32_t R = r40 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)r40;
-                // DW_NVIS = 0: `order` will hold all P ids (the geometry backward walks all of it)
-                words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = VOX_STICKS_MARK; words[DW_PMAX] = ml;
-                words[DW_PNMAX] = 0u; words[DW_NMAX] = 0u; words[DW_NNMAX] = 0u; words[DW_NVIS] = 0u;
-                mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = VOX_STICKS_MARK; mailbox[DW_PMAX] = ml;
-                mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = 0u; mailbox[DW_NNMAX] = 0u; mailbox[DW_NVIS] = (uint32_t)(tot >> 40);
-                __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-                // every other workgroup is through with the counters: ready for the thread's next call on this stream
-                __hip_atomic_store(&ctr->total, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctr->maxlist, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&ctr->scan_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-}
-
 constexpr uint32_t VSS_SERVICE = 2;   // workgroups of the scatter kernel that do not scatter
 // ---- 4. scatter.  Workgroup 0 does not scatter: it builds the sort kernel's two lists from the list totals and gives the
 // tiles of empty lists their (0, 0) ranges (the reference's memset).
@@ -155,7 +88,7 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
     uint32_t *__restrict__ first, uint32_t *__restrict__ order, const uint32_t *__restrict__ H,
     const uint32_t *__restrict__ totals, const uint32_t *__restrict__ wgtot, uint2 *__restrict__ pairs,
     uint2 *__restrict__ ranges, uint4 *__restrict__ big, uint4 *__restrict__ small, uint32_t *__restrict__ nparts,
-    uint32_t *__restrict__ work_partial, uint32_t n_partial, const WorkListOut wo /* ranges == nullptr: not here */)
+    uint32_t *__restrict__ work_partial, uint32_t n_partial, const WorkListOut wo /* ranges == nullptr: not here */, uint32_t big_cap)
 {
     extern __shared__ uint32_t s_pos[];   // [stride] start of the list's segment + this workgroup's offset in it, bumped per instance
     __shared__ uint32_t s_wsum[2 + VS_PER_THREAD_MAX][VS_THREADS / 64], s_carry[3], s_base;
@@ -168,7 +101,7 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
         for (uint32_t base = 0; base < NL; base += VS_THREADS) {
             const uint32_t l = base + (uint32_t)tid;
             const uint32_t c = l < NL ? totals[l] : 0u;
-            const uint32_t nb = c > VSK_SMALL_CAP ? 1u : 0u;
+            const uint32_t nb = c > VSK_SMALL_CAP ? (c > VSK_BIG_CAP ? (c + VSK_BIG_TARGET - 1u) / VSK_BIG_TARGET : 1u) : 0u;
             const uint32_t ns = (c != 0u && nb == 0u) ? 1u : 0u;
             uint32_t i0 = c, i1 = nb, i2 = ns;
 #pragma unroll
@@ -181,7 +114,8 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
             uint32_t o0 = 0, o1 = 0, o2 = 0;
             for (int w = 0; w < wave; ++w) { o0 += s_wsum[0][w]; o1 += s_wsum[1][w]; o2 += s_wsum[2][w]; }
             const uint32_t start = s_carry[0] + o0 + i0 - c, bstart = s_carry[1] + o1 + i1 - nb, sstart = s_carry[2] + o2 + i2 - ns;
-            if (nb) big[bstart] = make_uint4(l, 0u, start, c);
+            for (uint32_t q = 0; q < nb; ++q)
+                if (bstart + q < big_cap) big[bstart + q] = make_uint4(l, q, start, c);
             if (ns) small[sstart] = make_uint4(l, 0u, start, c);
             if (l < NL && c == 0u)
                 for (uint32_t sub = 0; sub < (1u << sh); ++sub)
@@ -190,7 +124,7 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
             if (tid == VS_THREADS - 1) { s_carry[0] = start + c; s_carry[1] = bstart + nb; s_carry[2] = sstart + ns; }
             __syncthreads();
         }
-        if (tid == 0) { nparts[0] = s_carry[1]; nparts[1] = s_carry[2]; }
+        if (tid == 0) { nparts[0] = min(s_carry[1], big_cap); nparts[1] = s_carry[2]; }
         return;
     }
     if (blockIdx.x == 1) {
@@ -373,7 +307,10 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
                                               uint32_t *s_wsum, int gtid, int lane, int wave, int w0, uint32_t cnt, uint32_t kmin,
                                               uint32_t kmax, uint32_t pmax, uint32_t nmin, uint32_t sh, uint32_t list, uint32_t T,
                                               uint32_t start, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
-                                              uint2 *__restrict__ ranges, const VSWork wk)
+                                              uint2 *__restrict__ ranges, const VSWork wk,
+                                              const uint32_t *s_wb = nullptr /* the entries are one PART of a longer list: [2^sh + 1] first
+                                              position of every tile in the whole list */, uint32_t out_off = 0u /* the part's */,
+                                              bool first_part = true)
 {
     const uint32_t BPS = BINS >> sh;   // buckets per tile of the stick
     // position of a key on the list's axis: its VALUE (the centres of a list's Gaussians are spread evenly in z: linear in the
@@ -429,11 +366,11 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
     // the ranges of the stick's tiles: their buckets' first and one-past-last positions (identifyTileRanges; empty tiles keep (0, 0))
     // ... and, for the render kernel's work list (launch_build_work_from_partials), the stick's work items added to the count of
     // its block of tiles (a stick never straddles two blocks; the scatter kernel zeroed the counts)
-    if (cnt != 0u && (uint32_t)gtid < (1u << sh)) {
+    if ((s_wb != nullptr ? first_part : cnt != 0u) && (uint32_t)gtid < (1u << sh)) {
         const uint32_t tile = (list << sh) + (uint32_t)gtid;
         uint32_t items = 0u;
         if (tile < T) {
-            const uint32_t a = s_bin[(uint32_t)gtid * BPS], b = s_bin[((uint32_t)gtid + 1u) * BPS];
+            const uint32_t a = s_wb ? s_wb[gtid] : s_bin[(uint32_t)gtid * BPS], b = s_wb ? s_wb[gtid + 1] : s_bin[((uint32_t)gtid + 1u) * BPS];
             ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
             items = (b - a) < wk.min_len ? 0u : (b - a + wk.chunk - 1u) / wk.chunk;
         }
@@ -481,17 +418,18 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
     uint32_t bnd[(1u << VS_MAX_SHIFT) - 1u];   // first position of tiles 1 .. 2^sh - 1 of the stick
 #pragma unroll
     for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT) - 1u; ++k)
-        bnd[k] = (k + 1u) < (1u << sh) ? __builtin_amdgcn_readfirstlane(s_bin[(k + 1u) * BPS]) : 0xFFFFFFFFu;
+        bnd[k] = (k + 1u) < (1u << sh) ? __builtin_amdgcn_readfirstlane(s_wb ? s_wb[k + 1u] : s_bin[(k + 1u) * BPS]) : 0xFFFFFFFFu;
     __syncthreads();
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t j = u * NT + (uint32_t)gtid;
         if (j < cnt) {
+            const uint32_t pos = out_off + j;   // position in the whole list
             uint32_t sub = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT) - 1u; ++k) sub += j >= bnd[k] ? 1u : 0u;
-            point_list[start + j] = s_out[j];
-            tiles_out[start + j] = (list << sh) + sub;
+            for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT) - 1u; ++k) sub += pos >= bnd[k] ? 1u : 0u;
+            point_list[start + pos] = s_out[j];
+            tiles_out[start + pos] = (list << sh) + sub;
         }
     }
     VS_TS(13);
@@ -502,18 +440,21 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
 //  10.7 us.  Inlined, the loop made the compiler hoist every item's address arithmetic in front of it (20 registers spilled); as
 //  calls, with the static assignment: 51 -> 82 us.  The hardware's dispatch of one workgroup per item balances lists of 1600 to
 //  6000 entries better than a stride does.)
+// PARTS: the call holds lists beyond one workgroup's capacity (the host knows: the scan kernel told it the longest list).  A
+// variant of its own: with that path compiled in, the kernel spills 28 registers at the 64 its two workgroups per CU allow.
+template <bool PARTS>
 __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
     const uint4 *__restrict__ big, const uint4 *__restrict__ small, const uint32_t *__restrict__ nparts,
     const uint2 *__restrict__ pairs, uint32_t sh, uint32_t T, uint32_t *__restrict__ point_list, uint32_t *__restrict__ tiles_out,
-    uint2 *__restrict__ ranges, const VSWork wk)
+    uint2 *__restrict__ ranges, const VSWork wk, uint32_t big_cap)
 {
     extern __shared__ unsigned long long vsk_lds[];
-    __shared__ uint32_t s_mm[4][VSK_THREADS / 64], s_wsum[VSK_THREADS / 64];
+    __shared__ uint32_t s_mm[4][VSK_THREADS / 64], s_wsum[VSK_THREADS / 64], s_wb[(1u << VS_MAX_SHIFT) + 1u], s_cnt, s_off;
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // the descriptor is requested together with the counts that say whether it exists (one round trip, not two)
     VS_TS(7);
-    const uint4 pd = big[min(p, VS_MAX_LISTS - 1u)];
+    const uint4 pd = big[min(p, big_cap - 1u)];
     const uint32_t nbig = nparts[0], nsmall = nparts[1];
     if (p >= nbig) {
         // ---- group: VSK_GROUPS short lists, one per 256 threads of the workgroup
@@ -552,21 +493,22 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
                                                           list, T, start, point_list, tiles_out, ranges, wk);
         return;
     }
-    // ---- big: one list for the whole workgroup
+    // ---- big: one list (or one part of a very long one) for the whole workgroup
     unsigned long long *s_a = vsk_lds;                                             // [VSK_BIG_CAP]
     uint32_t *s_bin = reinterpret_cast<uint32_t *>(s_a + VSK_BIG_CAP);             // [VSK_BIG_BINS + 1]
-    const uint32_t list = __builtin_amdgcn_readfirstlane(pd.x), start = __builtin_amdgcn_readfirstlane(pd.z),
-                   n = min(__builtin_amdgcn_readfirstlane(pd.w), VSK_BIG_CAP);   // (the host does not launch this kernel for longer lists)
+    uint32_t *s_coarse = s_bin + VSK_BIG_BINS + 1;                                 // [VSK_COARSE + 1]
+    const uint32_t list = __builtin_amdgcn_readfirstlane(pd.x), part = __builtin_amdgcn_readfirstlane(pd.y),
+                   start = __builtin_amdgcn_readfirstlane(pd.z), n = __builtin_amdgcn_readfirstlane(pd.w);
     const uint2 *__restrict__ src = pairs + start;
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u, pmax = 0u, nmin = 0xFFFFFFFFu;
     unsigned long long mine[VSK_BIG_PER];
-    {
+    if (!PARTS || n <= VSK_BIG_CAP) {
         uint2 e[VSK_BIG_PER];
 #pragma unroll
         for (uint32_t u = 0; u < VSK_BIG_PER; ++u) e[u] = src[min(u * VSK_THREADS + (uint32_t)tid, n - 1u)];
 #pragma unroll
         for (uint32_t u = 0; u < VSK_BIG_PER; ++u) {
-            const bool in = u * VSK_THREADS + (uint32_t)tid < n;
+            const bool in = u * VSK_THREADS + (uint32_t)tid < n;   // (u * VSK_THREADS + tid < VSK_BIG_CAP anyway)
             const bool neg = (e[u].x >> 31) != 0u;
             mine[u] = in ? vs_pack(e[u]) : ~0ull;
             kmin = in ? min(kmin, e[u].x) : kmin;
@@ -574,10 +516,170 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
             pmax = (in && !neg) ? max(pmax, e[u].x) : pmax;
             nmin = (in && neg) ? min(nmin, e[u].x) : nmin;
         }
+        vs_group_range<VSK_THREADS>(kmin, kmax, pmax, nmin, s_mm, lane, wave, 0);
+        vs_sort_group<VSK_THREADS, VSK_BIG_PER, VSK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, min(n, VSK_BIG_CAP), kmin, kmax,
+                                                              pmax, nmin, sh, list, T, start, point_list, tiles_out, ranges, wk);
+        return;
+    }
+    if (!PARTS) return;
+    // ---- this part's share of a list no workgroup can hold: a contiguous range of the bins of a COARSE histogram of the list over
+    // its (tile in stick, z) axis, chosen so that the parts are balanced whatever the distribution (raster_tilefirst.hip does the
+    // same over depth).  The bins are laid out from every 8th entry -- every part of the list takes the same sample, hence the
+    // same layout; the layout only balances the parts: the bin of an entry is a monotone function of (tile, key), so the parts
+    // are consecutive pieces of the sorted list, and membership and offsets below are exact.
+    constexpr uint32_t SAMPLE = 8;
+    const uint32_t nsub = 1u << sh, CB = VSK_COARSE >> sh;   // coarse bins per tile
+    const uint32_t nparts_list = (n + VSK_BIG_TARGET - 1u) / VSK_BIG_TARGET, ns = (n + SAMPLE - 1u) / SAMPLE;
+    for (uint32_t base = 0; base < ns; base += 4u * VSK_THREADS) {   // key range of the sample: four loads in flight, branch-free
+        uint32_t kk[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) kk[u] = src[min((base + u * VSK_THREADS + (uint32_t)tid) * SAMPLE, n - 1u)].x;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if (base + u * VSK_THREADS + (uint32_t)tid < ns) {
+                const bool neg = (kk[u] >> 31) != 0u;
+                kmin = min(kmin, kk[u]); kmax = max(kmax, kk[u]);
+                pmax = neg ? pmax : max(pmax, kk[u]);
+                nmin = neg ? min(nmin, kk[u]) : nmin;
+            }
     }
     vs_group_range<VSK_THREADS>(kmin, kmax, pmax, nmin, s_mm, lane, wave, 0);
-    vs_sort_group<VSK_THREADS, VSK_BIG_PER, VSK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, n, kmin, kmax, pmax, nmin, sh, list,
-                                                          T, start, point_list, tiles_out, ranges, wk);
+    // coarse bin of an entry: tile * CB + position of its key's VALUE in the sample's range (vs_sort_group has the reasoning);
+    // keys outside that range, and keys of a sign class the sample has not seen, clamp into the end bins of where they belong
+    auto fv = [](uint32_t k) { return __uint_as_float(min(k & 0x7FFFFFFFu, 0x7F7FFFFFu)); };
+    const bool has_pos = kmin < 0x80000000u, has_neg = kmax >= 0x80000000u;
+    const float f0 = fv(has_pos ? kmin : 0u), fn0 = fv(has_neg ? nmin : 0u);
+    const float noff = (has_pos && has_neg) ? fv(pmax) - f0 : 0.f;                        // where the sign-bit class starts
+    const float ptop = has_pos ? (has_neg ? noff : fv(kmax) - f0) : 0.f;                  // where the other class ends
+    const float tmax = has_neg ? noff + (fv(kmax) - fn0) : ptop;
+    const float cscale = tmax > 0.f ? (float)CB / tmax : 0.f;
+    auto coarse_of = [&](const uint2 e) {
+        const uint32_t key = e.x, sub = e.y >> VS_ID_BITS;
+        float t;
+        if (key >= 0x80000000u) t = has_neg ? noff + fmaxf(fv(key) - fn0, 0.f) : tmax;   // after every key with a clear sign bit
+        else t = has_pos ? fminf(fmaxf(fv(key) - f0, 0.f), ptop) : 0.f;                   // before every key with the sign bit set
+        return sub * CB + min((uint32_t)(t * cscale), CB - 1u);
+    };
+    for (uint32_t i = tid; i <= VSK_COARSE; i += VSK_THREADS) s_coarse[i] = 0u;
+    if (tid <= (int)(1u << VS_MAX_SHIFT)) s_wb[tid] = 0u;
+    if (tid == 0) { s_cnt = 0u; s_off = 0u; }
+    __syncthreads();
+    for (uint32_t base = 0; base < ns; base += 4u * VSK_THREADS) {
+        uint2 ee[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) ee[u] = src[min((base + u * VSK_THREADS + (uint32_t)tid) * SAMPLE, n - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u)
+            if (base + u * VSK_THREADS + (uint32_t)tid < ns) atomicAdd(&s_coarse[coarse_of(ee[u])], 1u);
+    }
+    __syncthreads();
+    {
+        // exclusive prefix over the bins (one per thread); owner of a bin = floor(prefix * parts / samples): monotone in the bin
+        const uint32_t c = s_coarse[tid];
+        uint32_t incl = c;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d);
+            if (lane >= d) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t excl = incl - c;
+        for (int w = 0; w < wave; ++w) excl += s_wsum[w];
+        const uint32_t owner = min((uint32_t)(((unsigned long long)excl * nparts_list) / ns), nparts_list - 1u);
+        __syncthreads();
+        s_coarse[tid] = owner;   // from here on: the part that owns the bin
+        __syncthreads();
+    }
+    // ---- one pass over the whole list: entries of parts before mine are counted (my offset in the sorted list), mine appended,
+    // and every tile's entries counted (the tile ranges; which tile an output position belongs to)
+    kmin = 0xFFFFFFFFu; kmax = 0u; pmax = 0u; nmin = 0xFFFFFFFFu;   // reused for this part's own key range
+    uint32_t below = 0, wsub[1u << VS_MAX_SHIFT];
+#pragma unroll
+    for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT); ++k) wsub[k] = 0u;
+    for (uint32_t base4 = 0; base4 < n; base4 += 4u * VSK_THREADS) {   // whole waves stay in the loop: the append is wave-cooperative
+        uint2 e4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) e4[u] = src[min(base4 + u * VSK_THREADS + (uint32_t)tid, n - 1u)];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t i = base4 + u * VSK_THREADS + (uint32_t)tid;
+            const uint2 e = e4[u];
+            const bool in = i < n;
+            const uint32_t own = in ? s_coarse[coarse_of(e)] : 0xFFFFFFFFu;
+            below += own < part ? 1u : 0u;
+            const uint32_t sub = e.y >> VS_ID_BITS;
+#pragma unroll
+            for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT); ++k)
+                if (k < nsub) wsub[k] += (uint32_t)__popcll(__ballot(in && sub == k));   // (per wave: the same in all its lanes)
+            const bool take = own == part;
+            const unsigned long long mm = __ballot(take);
+            if (mm) {
+                uint32_t wbase = 0;
+                const int leader = __ffsll((long long)mm) - 1;
+                if (lane == leader) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(mm));
+                wbase = __shfl(wbase, leader);
+                const uint32_t slot = wbase + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull));
+                if (take && slot < VSK_BIG_CAP) {
+                    s_a[slot] = vs_pack(e);
+                    const bool neg = (e.x >> 31) != 0u;
+                    kmin = min(kmin, e.x); kmax = max(kmax, e.x);
+                    pmax = neg ? pmax : max(pmax, e.x);
+                    nmin = neg ? min(nmin, e.x) : nmin;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) below += __shfl_xor(below, d);
+    if (lane == 0) {
+        atomicAdd(&s_off, below);
+#pragma unroll
+        for (uint32_t k = 0; k < (1u << VS_MAX_SHIFT); ++k)
+            if (k < nsub) atomicAdd(&s_wb[k + 1u], wsub[k]);
+    }
+    __syncthreads();
+    if (tid == 0) {   // counts -> first position of every tile in the list
+        uint32_t run = 0;
+        for (uint32_t k = 1; k <= nsub; ++k) { run += s_wb[k]; s_wb[k] = run; }
+    }
+    __syncthreads();
+    const uint32_t cnt = s_cnt, out_off = s_off;
+    if (cnt > VSK_BIG_CAP) {
+        // (more entries inside one sliver of the axis than the LDS holds: equal z.)  Rank by counting, straight from memory:
+        // O(cnt x n).  Exact like everything else.
+        if (part == 0u && (uint32_t)tid < nsub) {
+            const uint32_t tile = (list << sh) + (uint32_t)tid;
+            if (tile < T) {
+                const uint32_t a = s_wb[tid], b = s_wb[tid + 1];
+                ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
+                const uint32_t items = (b - a) < wk.min_len ? 0u : (b - a + wk.chunk - 1u) / wk.chunk;
+                if (wk.partial != nullptr && items != 0u) atomicAdd(&wk.partial[(list << sh) / wk.block_tiles], items);
+            }
+        }
+        for (uint32_t i = tid; i < n; i += VSK_THREADS) {
+            const uint2 e = src[i];
+            if (s_coarse[coarse_of(e)] != part) continue;
+            const unsigned long long me = vs_pack(e);
+            uint32_t r = 0;
+            for (uint32_t j = 0; j < n; ++j) {
+                const uint2 o = src[j];
+                if (s_coarse[coarse_of(o)] == part && vs_pack(o) < me) ++r;
+            }
+            point_list[start + out_off + r] = e.y & VS_ID_MASK;
+            tiles_out[start + out_off + r] = (list << sh) + (e.y >> VS_ID_BITS);
+        }
+        return;
+    }
+    vs_group_range<VSK_THREADS>(kmin, kmax, pmax, nmin, s_mm, lane, wave, 0);   // (its barriers also order the appends before the reads)
+#pragma unroll
+    for (uint32_t u = 0; u < VSK_BIG_PER; ++u) {
+        const uint32_t i = u * VSK_THREADS + (uint32_t)tid;
+        mine[u] = i < cnt ? s_a[i] : ~0ull;
+    }
+    __syncthreads();   // everybody holds its entries: s_a may be overwritten by the placement
+    vs_sort_group<VSK_THREADS, VSK_BIG_PER, VSK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, pmax, nmin, sh,
+                                                          list, T, start, point_list, tiles_out, ranges, wk, s_wb, out_off, part == 0u);
 }
 
 // ---- host side
@@ -603,6 +705,7 @@ VSNote *vs_note(int P, const VoxelGrid &v, bool create)
 
 // forwards that took the chain, forwards that left it after the scan (a list too long), forwards it declined
 std::atomic<long long> g_vs_taken{0}, g_vs_fallback{0}, g_vs_declined{0};
+std::atomic<int> g_vs_no_parts{0};   // tests: treat a list beyond one workgroup's capacity as unsupported (the fallback's path)
 std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1 (or 2): every grid it can serve
 
 int vs_mode()
@@ -618,9 +721,10 @@ int vs_mode()
 
 bool vs_lds_ok()
 {
-    static signed char lds_state[R2_MAX_DEVICES] = {};
+    static signed char lds_state[R2_MAX_DEVICES] = {}, lds_state2[R2_MAX_DEVICES] = {};
     return VSK_LDS <= device_lds_optin_bytes() &&
-           allow_dynamic_lds(reinterpret_cast<const void *>(vox_stick_sort_kernel), (int)VSK_LDS, lds_state);
+           allow_dynamic_lds(reinterpret_cast<const void *>(vox_stick_sort_kernel<false>), (int)VSK_LDS, lds_state) &&
+           allow_dynamic_lds(reinterpret_cast<const void *>(vox_stick_sort_kernel<true>), (int)VSK_LDS, lds_state2);
 }
 
 }  // namespace
@@ -667,17 +771,15 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     launch_voxel_cull_count(geom, v, P, grid, means3D, scales, scale_modifier, rotations, cov3D_precomp, radii_x, radii_y, radii_z, sh, stride,
                             st.H, st.wgtot, ctr, s); }
     R2_HIP_TRY(hipGetLastError());
+    // one launch for two independent jobs: the column scan (its last workgroup posts the totals to the host) and the render
+    // records, which nothing before the render kernel reads -- they are written while the host waits for the totals, sizes the
+    // two remaining state buffers and launches the rest (as a part of the first kernel they left the GPU idle for 12 us there; as
+    // a launch of their own behind the scan they cost a kernel boundary).  Measured and left out: a first message with the
+    // instance count from the cull + count kernel's last workgroup, the rest of the chain enqueued before the scan's verdict on
+    // the longest list is read -- the records already cover the wait, and the extra counter cost the first kernel 4 us
+    // (475 -> 482 us per query)
     { StageScope t(ST_VOX_SCAN, s);
-    vox_stick_scan_kernel<<<dim3(stride / VSS_LISTS), dim3(VSS_THREADS), 0, s>>>(st.H, NW, stride, st.totals, ctr, geom.host_words,
-                                                                                mailbox, seq); }
-    R2_HIP_TRY(hipGetLastError());
-    // the render records: nothing before the render kernel reads them, so they are written while the host waits for the totals,
-    // sizes the two remaining state buffers and launches the rest (as a part of the first kernel they left the GPU idle for 12 us
-    // there).  Measured and left out: a first message with the instance count from the cull + count kernel's last workgroup, the
-    // rest of the chain enqueued before the scan's verdict on the longest list is read -- the records kernel already covers the
-    // wait, and the extra counter cost the first kernel 4 us (475 -> 482 us per query)
-    { StageScope t(ST_VOX_PREPROCESS, s);
-    launch_voxel_records(geom, v, P, means3D, opacities, cov3D_precomp, s); }
+    launch_voxel_scan_records(geom, v, P, grid, means3D, opacities, cov3D_precomp, st.H, NW, stride, st.totals, ctr, mailbox, seq, s); }
     R2_HIP_TRY(hipGetLastError());
     uint32_t hw[DW_COUNT] = { 0 };
     rc = host_mailbox_wait(seq, hw, DW_COUNT, s);
@@ -687,7 +789,19 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
         set_error("r2_voxel_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
         return R2_ERR_INVALID;
     }
-    if (longest > VSK_BIG_CAP) {   // a stick's list is longer than one workgroup sorts: the general chain, from here and from now on
+    // lists beyond one workgroup's capacity are sorted in parts: at most NL + R / VSK_BIG_TARGET descriptors of long lists.  More
+    // than the state holds (Gaussians of hundreds of tiles each): the general chain, from here and from now on
+    const size_t parts_bound = (size_t)NL + (size_t)num_rendered / VSK_BIG_TARGET + 1;
+    // ... and so do scenes of LARGE Gaussians packed into DENSE lists (trained clouds: 65 tiles per Gaussian, lists of 30 000 and
+    // more).  This chain's producers walk a Gaussian's tiles one lane per Gaussian and bump LDS counters which the Gaussians of such
+    // a scene share -- they sit on the object's surface, and neighbours in memory are neighbours in space --: measured on the 92k /
+    // 331k trained clouds at 256^3, scatter 245 / 430 us against the general chain's wave-cooperative emission at 71 / 112, the
+    // query 964 / 2806 us against 791 / 2215.  Either property alone is fine: 20k large Gaussians spread over the volume (110
+    // tiles each, short lists) 406 -> 388 us, a million small ones (lists of 30 000, sorted in parts) 1340 -> 1276 us.
+    const uint32_t nvis = hw[DW_NVIS];
+    static const uint32_t max_tpg = [] { const char *e = getenv("R2_VOXEL_STICKS_MAXTPG"); return e ? (uint32_t)atoi(e) : VS_MAX_TILES_PER_GAUSSIAN; }();
+    const bool large = (size_t)num_rendered > (size_t)max_tpg * (nvis ? nvis : 1u) && longest > VSK_BIG_CAP;
+    if (large || parts_bound > st.bigcap || (g_vs_no_parts.load(std::memory_order_relaxed) && longest > VSK_BIG_CAP)) {
         vs_note(P, v, true)->bad = true;
         g_vs_fallback.fetch_add(1, std::memory_order_relaxed);
         return VOX_STICKS_FALLBACK;
@@ -714,12 +828,17 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     { StageScope t(ST_VOX_DUPLICATE, s);
     vox_stick_scatter_kernel<<<dim3(NW + VSS_SERVICE), dim3(VS_THREADS), stride * sizeof(uint32_t), s>>>(
         P, grid.per_wg, grid.ni, (uint32_t)v.gx, (uint32_t)v.gy, (uint32_t)T, sh, NL, stride, geom.tiles_touched, geom.cube, geom.depth_key, geom.first,
-        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, nparts, wk.partial, n_partial, wo); }
+        geom.order, st.H, st.totals, st.wgtot, pairs, img.ranges, st.big, st.small, nparts, wk.partial, n_partial, wo, (uint32_t)st.bigcap); }
     R2_HIP_TRY(hipGetLastError());
     if (R > 0) {
         StageScope t(ST_VOX_SORT, s);
-        vox_stick_sort_kernel<<<dim3(NL + (NL + VSK_GROUPS - 1) / VSK_GROUPS), dim3(VSK_THREADS), VSK_LDS, s>>>(
-            st.big, st.small, nparts, pairs, sh, (uint32_t)T, bin.point_list, bin.tiles, img.ranges, wk);
+        const dim3 sgrid((unsigned)(std::min(parts_bound, st.bigcap) + (NL + VSK_GROUPS - 1) / VSK_GROUPS));
+        if (longest > VSK_BIG_CAP)
+            vox_stick_sort_kernel<true><<<sgrid, dim3(VSK_THREADS), VSK_LDS, s>>>(st.big, st.small, nparts, pairs, sh, (uint32_t)T, bin.point_list,
+                                                                                  bin.tiles, img.ranges, wk, (uint32_t)st.bigcap);
+        else
+            vox_stick_sort_kernel<false><<<sgrid, dim3(VSK_THREADS), VSK_LDS, s>>>(st.big, st.small, nparts, pairs, sh, (uint32_t)T, bin.point_list,
+                                                                                   bin.tiles, img.ranges, wk, (uint32_t)st.bigcap);
     }
     R2_HIP_TRY(hipGetLastError());
     if (!direct) {
@@ -751,4 +870,5 @@ extern "C" void r2_voxel_sticks_control(int mode)
 {
     if (mode >= 0 && mode <= 2) r2::g_vs_mode.store(mode, std::memory_order_relaxed);
     if (mode == 3) r2::g_vs_notes.clear();   // the calling thread's notes
+    if (mode == 4 || mode == 5) r2::g_vs_no_parts.store(mode == 4 ? 1 : 0, std::memory_order_relaxed);   // tests
 }

@@ -1,6 +1,6 @@
 """256^3 query of the benchmark cloud on the general binning chain and on the stick-first chain (csrc/voxel_sticks.hip), alternating
 on ONE box: ms per call (median of 5 x n calls, as bench.py times it), per-stage times of the same call, and the two volumes compared
-bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes; 2 = every grid)"""
+bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000 | small | large] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes; 2 = every grid)"""
 import ctypes as C
 import statistics
 import sys
@@ -13,11 +13,18 @@ from r2_gaussian_amd import _C, _lib
 from r2_gaussian_amd import scene as S
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-P = int(sys.argv[2]) if len(sys.argv) > 2 else 300000
+CLOUD = sys.argv[2] if len(sys.argv) > 2 and not sys.argv[2].isdigit() else None   # "small" / "large": a trained cloud (tests/trained_cloud.py)
+P = int(sys.argv[2]) if len(sys.argv) > 2 and CLOUD is None else 300000
 G = int(sys.argv[3]) if len(sys.argv) > 3 else 256
 MODES = tuple(int(x) for x in sys.argv[4].split(",")) if len(sys.argv) > 4 else (0, 1)
 dev = torch.device("cuda:0")
-c = S.make_cloud(P, seed=0)
+if CLOUD:
+    from tests import trained_cloud as TCl
+    c, info = TCl.load(CLOUD)
+    P = c.xyz.shape[0]
+    print("trained cloud %s: %d Gaussians" % (CLOUD, P), flush=True)
+else:
+    c = S.make_cloud(P, seed=0)
 e = torch.empty(0)
 a = (c.xyz.to(dev), c.density.to(dev), c.scales.to(dev), c.rotations.to(dev), 1.0, e, G, G, G, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0,
      False, False)

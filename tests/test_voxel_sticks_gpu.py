@@ -31,6 +31,7 @@ def sticks_mode():
     L.r2_voxel_sticks_control(3)
     yield L.r2_voxel_sticks_control
     L.r2_voxel_sticks_control(1)
+    L.r2_voxel_sticks_control(5)
     L.r2_voxel_sticks_control(3)
 
 
@@ -123,16 +124,78 @@ def test_the_headline_query_takes_the_chain(gpu, sticks_mode):
     assert np.array_equal(np.cumsum(tt[vis]) - tt[vis], start)   # moment rows in id order, a partition of [0, R)
 
 
-def test_a_list_too_long_for_the_chain_continues_on_the_general_one(oracle, gpu, sticks_mode):
-    """20k Gaussians squeezed into a few tiles of a 64^3 grid: one list holds far more than a workgroup sorts (8192).  The chain
-    notices after its scan, the call finishes on the general chain (same result), and the thread skips the chain for that
-    (P, grid) from then on."""
-    c0 = S.make_cloud(20000, seed=5)
-    c = S.Cloud(c0.xyz * 0.03, c0.scales, c0.rotations, c0.density)
-    n, s, ctr = (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+def _squeezed(P, seed, f, flat_z=False, scale_mult=1.0):
+    c0 = S.make_cloud(P, seed=seed, scale_mult=scale_mult)
+    xyz = c0.xyz * f
+    if flat_z:
+        xyz = xyz.clone()
+        xyz[:, 2] = 0.0123
+    return S.Cloud(xyz, c0.scales, c0.rotations, c0.density)
+
+
+LONG = [
+    # (cloud, grid): every Gaussian squeezed into a few tiles -- lists of 12 000 .. 60 000 instances, sorted by several workgroups each
+    ("tile_lists_64cube", lambda: _squeezed(20000, 5, 0.03), (64, 64, 64)),            # a list is a tile: parts are ranges of z
+    ("stick_lists_136cube", lambda: _squeezed(30000, 7, 0.05), (136, 136, 136)),       # sticks of 2 tiles: parts are ranges of (tile, z)
+    ("stick_lists_256cube", lambda: _squeezed(40000, 9, 0.1, scale_mult=0.5), (256, 256, 256)),   # sticks of 8
+    ("equal_z_64cube", lambda: _squeezed(12000, 11, 0.03, flat_z=True), (64, 64, 64)),  # one value of z: a part cannot be cut -> ranked by counting
+]
+
+
+@pytest.mark.parametrize("name,make,n", LONG, ids=[c[0] for c in LONG])
+def test_lists_beyond_one_workgroup_are_sorted_in_parts(name, make, n, oracle, gpu, sticks_mode):
+    c = make()
+    s, ctr = (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
     o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
     assert int((o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max()) > 8192
+    sticks_mode(0)
+    h0 = Hh.hip_voxel(c, n, s, ctr, gpu)
     sticks_mode(1)
+    _stats()
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert _stats() == [1, 0, 0] and Hh.took_sticks(h) and int(h["host_words"][3]) > 8192   # (host word 3: the longest list)
+    assert h["num_rendered"] == o["num_rendered"]
+    Hh.check_binning(h, o)
+    assert np.array_equal(h0["vol"].view(np.uint32), h["vol"].view(np.uint32))
+    g = torch.Generator().manual_seed(2)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    g0 = Hh.hip_voxel_backward(h0, c, n, s, ctr, dL, gpu)
+    g1 = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+    for k in g0:
+        assert np.array_equal(g0[k].view(np.uint32), g1[k].view(np.uint32)), k
+
+
+def test_large_gaussians_continue_on_the_general_chain(oracle, gpu, sticks_mode):
+    """More than 32 tiles per Gaussian on average AND a list of more than 8192 instances (a trained cloud: 65 tiles, lists of
+    30 000; here a synthetic cloud squeezed towards the centre): the general chain's wave-cooperative emission is the faster one,
+    the stick chain hands over after the preprocess."""
+    c = _squeezed(12000, 3, 0.2, scale_mult=1.5)
+    n, s, ctr = (136, 136, 136), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
+    assert o["num_rendered"] > 32 * 12000 and int((o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max()) > 8192
+    sticks_mode(1)
+    _stats()
+    h = Hh.hip_voxel(c, n, s, ctr, gpu)
+    assert _stats() == [0, 1, 0] and not Hh.took_sticks(h)
+    assert h["num_rendered"] == o["num_rendered"]
+    for k in ("radii_x", "radii_y", "radii_z"):
+        assert np.array_equal(h[k], o[k])
+    Hh.check_binning(h, o)
+    h2 = Hh.hip_voxel(c, n, s, ctr, gpu)                      # the thread remembers: declined, the hinted general chain
+    assert _stats() == [0, 0, 1]
+    assert np.array_equal(h2["point_list"], h["point_list"]) and np.array_equal(h2["vol"].view(np.uint32), h["vol"].view(np.uint32))
+
+
+def test_a_scene_the_chain_cannot_serve_continues_on_the_general_one(oracle, gpu, sticks_mode):
+    """The chain gives up after its scan when the long lists of a scene need more part descriptors than the geometry state holds
+    (Gaussians of hundreds of tiles each); forced here by declaring lists beyond one workgroup's capacity unsupported (mode 4).
+    The call finishes on the general chain (same result, the preprocess is not repeated), and the thread skips the chain for that
+    (P, grid) from then on."""
+    c = _squeezed(20000, 5, 0.03)
+    n, s, ctr = (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
+    sticks_mode(1)
+    sticks_mode(4)
     _stats()
     h = Hh.hip_voxel(c, n, s, ctr, gpu)
     assert _stats() == [0, 1, 0] and not Hh.took_sticks(h)
