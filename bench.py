@@ -813,6 +813,9 @@ def main():
     if not args.no_voxel and rank == 0:
         with torch.no_grad():
             va = (xyz, dens, scal, rot, 1.0, e, 256, 256, 256, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0, False, False)
+            import ctypes as _ct
+            vstat = (_ct.c_longlong * 3)()
+            _lib.lib().r2_voxel_sticks_stats(vstat, 1)
             for _ in range(3):
                 R3 = _C.voxelize_gaussians(*va)[0]
             tvs = []
@@ -831,6 +834,7 @@ def main():
             torch.cuda.synchronize()
             vprof = _lib.profile_read(reset=True)
             _lib.profile_enable([])
+            _lib.lib().r2_voxel_sticks_stats(vstat, 0)
         # the training loop's TV regulariser: forward + backward of a 32^3 patch through the drop-in voxelizer
         from r2_gaussian_amd import GaussianVoxelizationSettings, GaussianVoxelizer
         vox32 = [GaussianVoxelizer(GaussianVoxelizationSettings(1.0, 32, 32, 32, 0.25, 0.25, 0.25, -0.3 + 0.1 * (i % 7),
@@ -858,6 +862,10 @@ def main():
         gvox = {"gvoxel_per_s": round(256 ** 3 / tv / 1e9, 3), "ms": round(tv * 1e3, 3), "ms_min": round(min(tvs) * 1e3, 3),
                 "R3": int(R3), "alg_MB": round(vbytes / 1e6, 1), "hbm_frac": round(vbytes / tv / 1e9 / HBM_PEAK_GBS, 4),
                 "stages_us": {k_: round(1e3 * ms / cnt, 1) for k_, (ms, cnt) in sorted(vprof.items()) if k_.startswith("voxel.")},
+                # which binning chain the 256^3 queries above took: csrc/voxel_sticks.hip (stick-first: no global sort) or the general
+                # one (depth order + radix passes); on the stick chain the stages are preprocess = cull + count, scan = column scan +
+                # render records (one launch), duplicate = scatter, sort = per-list sort, ranges = work list
+                "binning": {"stick_chain_calls": int(vstat[0]), "left_for_general_chain": int(vstat[1]), "general_chain_calls": int(vstat[2])},
                 "tv_patch_32cube_fwd_bwd_us": round(ttv * 1e6, 1), "tv_patch_us_min": round(min(ttvs) * 1e6, 1),
                 "tv_patch_us_max": round(max(ttvs) * 1e6, 1)}
 
