@@ -309,9 +309,9 @@ R2_API void r2_tile_first_stats(long long out[5], int reset);
 /* Stick-first binning of the voxelizer (csrc/voxel_sticks.hip): grids of more than 64 and up to 32 768 tiles (the 256^3 query of
  * test.py:105-112) are binned without a global sort -- instances are counted and scattered per STICK of up to 8 consecutive
  * tiles (per tile up to 4096 tiles) and every stick's list is sorted on (tile, z bits, id) on its own.  point_list, ranges,
- * volumes and gradients are identical on both chains; a scene of large Gaussians in dense lists (more than 32 tiles per Gaussian on
- * average and a list of more than 8192 instances: trained clouds, where the general chain's wave-cooperative emission is the
- * faster one) continues on the general chain after the preprocess, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids
+ * volumes and gradients are identical on both chains; a large scene of large Gaussians (more than 32 tiles per Gaussian on average
+ * and more than 4 Mi instances: trained clouds, where the general chain's wave-cooperative emission is the faster one)
+ * continues on the general chain after the preprocess, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids
  * and P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
  * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes; 4 / 5 (tests): lists of more than 8192
  * instances count as unsupported / are sorted in parts (default). */
@@ -321,8 +321,9 @@ R2_API void r2_voxel_sticks_control(int mode);
 R2_API void r2_voxel_sticks_stats(long long out[3], int reset);
 
 /* Per-thread state.  The library keeps a few KB per host thread: self-resetting device counters of the tile-first rasterizer chain
- * and of the small-grid voxelizer path (one block per (device, stream) the thread has used, at most 16 of each: the least
- * recently used one is evicted), 128 bytes of pinned host memory for the num_rendered read-back, and the thread's predictions.
+ * and of the voxelizer's small-grid path and stick-first chain (one block per (device, stream) the thread has used, at most 16 of each:
+ * the least recently used one is evicted), 128 bytes of pinned host memory for the num_rendered read-back, and the thread's
+ * predictions and notes.
  * These -- and the convenience form r2_knn_dist2 -- are the only memory the library obtains itself; all of it is released when the
  * thread exits, or earlier by this call (waits for the device; the thread's next forward starts over). */
 R2_API void r2_thread_release(void);

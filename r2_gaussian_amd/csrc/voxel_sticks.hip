@@ -49,8 +49,8 @@ namespace {
 
 constexpr int VS_THREADS = (int)VS_PRODUCER;
 constexpr uint32_t VS_MAX_SHIFT = 3;       // tiles per stick = 2^shift <= 8: three bits above the 29-bit id
-constexpr uint32_t VS_MAX_TILES_PER_GAUSSIAN = 32;   // mean over the visible Gaussians of a call beyond which a scene with a list of more than
-                                                     // VSK_BIG_CAP instances goes to the general chain
+constexpr uint32_t VS_MAX_TILES_PER_GAUSSIAN = 32;   // a call with more tiles per visible Gaussian on average AND more than ...
+constexpr uint32_t VS_LARGE_SCENE = 4u << 20;        // ... this many instances goes to the general chain
 constexpr uint32_t VS_ID_BITS = 29;
 constexpr uint32_t VS_ID_MASK = (1u << VS_ID_BITS) - 1u;
 
@@ -792,15 +792,20 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     // lists beyond one workgroup's capacity are sorted in parts: at most NL + R / VSK_BIG_TARGET descriptors of long lists.  More
     // than the state holds (Gaussians of hundreds of tiles each): the general chain, from here and from now on
     const size_t parts_bound = (size_t)NL + (size_t)num_rendered / VSK_BIG_TARGET + 1;
-    // ... and so do scenes of LARGE Gaussians packed into DENSE lists (trained clouds: 65 tiles per Gaussian, lists of 30 000 and
-    // more).  This chain's producers walk a Gaussian's tiles one lane per Gaussian and bump LDS counters which the Gaussians of such
-    // a scene share -- they sit on the object's surface, and neighbours in memory are neighbours in space --: measured on the 92k /
-    // 331k trained clouds at 256^3, scatter 245 / 430 us against the general chain's wave-cooperative emission at 71 / 112, the
-    // query 964 / 2806 us against 791 / 2215.  Either property alone is fine: 20k large Gaussians spread over the volume (110
-    // tiles each, short lists) 406 -> 388 us, a million small ones (lists of 30 000, sorted in parts) 1340 -> 1276 us.
+    // ... and so do LARGE scenes of LARGE Gaussians (trained clouds: 65 tiles per Gaussian, 6 and 22 M instances).  This chain's
+    // producers walk a Gaussian's tiles one lane per Gaussian, the general chain emits instances wave-cooperatively.  Measured on
+    // the 92k / 331k trained clouds at 256^3: count 54 / 77 us and scatter 245 / 430 us (41 / 19 us per million instances; 8 on the
+    // benchmark cloud's 16 tiles per Gaussian) against the general chain's emission at 71 / 112, the query 964 / 2806 us against
+    // 791 / 2215.  Synthetic clouds of as large Gaussians are fine while they are small (20k Gaussians of 110 tiles, 2.2 M instances:
+    // 406 -> 388 us; 50k of 55: 386 -> 365), and so are large scenes of small Gaussians (a million of 8 tiles, lists of 10 000
+    // sorted in parts: 1340 -> 1276 us).  The fullest per-workgroup list counter (how hard a workgroup's lanes contend for one
+    // LDS counter) was measured as a possible criterion and does not separate them: 235 on the large trained cloud, 219 on the
+    // 20k synthetic one (and the reduction cost the count kernel 2 us).
     const uint32_t nvis = hw[DW_NVIS];
+    static const bool dbg = [] { const char *e = getenv("R2_VOXEL_STICKS_DEBUG"); return e && e[0] == '1'; }();
+    if (dbg) fprintf(stderr, "voxel sticks: P %d R %u visible %u longest list %u\n", P, num_rendered, nvis, longest);
     static const uint32_t max_tpg = [] { const char *e = getenv("R2_VOXEL_STICKS_MAXTPG"); return e ? (uint32_t)atoi(e) : VS_MAX_TILES_PER_GAUSSIAN; }();
-    const bool large = (size_t)num_rendered > (size_t)max_tpg * (nvis ? nvis : 1u) && longest > VSK_BIG_CAP;
+    const bool large = (size_t)num_rendered > (size_t)max_tpg * (nvis ? nvis : 1u) && num_rendered > VS_LARGE_SCENE;
     if (large || parts_bound > st.bigcap || (g_vs_no_parts.load(std::memory_order_relaxed) && longest > VSK_BIG_CAP)) {
         vs_note(P, v, true)->bad = true;
         g_vs_fallback.fetch_add(1, std::memory_order_relaxed);

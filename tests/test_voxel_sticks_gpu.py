@@ -165,14 +165,14 @@ def test_lists_beyond_one_workgroup_are_sorted_in_parts(name, make, n, oracle, g
         assert np.array_equal(g0[k].view(np.uint32), g1[k].view(np.uint32)), k
 
 
-def test_large_gaussians_continue_on_the_general_chain(oracle, gpu, sticks_mode):
-    """More than 32 tiles per Gaussian on average AND a list of more than 8192 instances (a trained cloud: 65 tiles, lists of
-    30 000; here a synthetic cloud squeezed towards the centre): the general chain's wave-cooperative emission is the faster one,
-    the stick chain hands over after the preprocess."""
-    c = _squeezed(12000, 3, 0.2, scale_mult=1.5)
+def test_a_large_scene_of_large_gaussians_continues_on_the_general_chain(oracle, gpu, sticks_mode):
+    """More than 32 tiles per Gaussian on average AND more than 4 Mi instances (a trained cloud: 65 tiles, 6 to 22 M instances; here a
+    synthetic cloud with 2.5 x the scales): the general chain's wave-cooperative emission is the faster one, the stick chain hands
+    over after the preprocess."""
+    c = S.make_cloud(20000, seed=3, scale_mult=2.5)
     n, s, ctr = (136, 136, 136), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
     o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
-    assert o["num_rendered"] > 32 * 12000 and int((o["ranges"][:, 1].astype(np.int64) - o["ranges"][:, 0]).max()) > 8192
+    assert o["num_rendered"] > 32 * 20000 and o["num_rendered"] > 4 << 20
     sticks_mode(1)
     _stats()
     h = Hh.hip_voxel(c, n, s, ctr, gpu)
