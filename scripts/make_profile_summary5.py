@@ -86,8 +86,8 @@ if os.path.exists(vs):
     vpmc = json.load(open(vp)) if os.path.exists(vp) else {}
     with open(os.path.join(P, "%s_voxel256_summary.md" % tag), "w") as f:
         f.write("# Voxelizer, 256^3 query of the 300k-Gaussian benchmark cloud alone (%s)\n\n" % tag)
-        f.write("`rocprofv3 --kernel-trace --stats -- python scripts/voxel_query_only.py 12` (12 calls; the first takes the un-hinted depth "
-                "order) and separate `--pmc` passes over the same command (FETCH_SIZE, WRITE_SIZE, SQ_*), averaged per launch.\n\n")
+        f.write("`rocprofv3 --kernel-trace --stats -- python scripts/voxel_query_only.py 12` (12 calls on the stick-first chain, "
+                "csrc/voxel_sticks.hip) and separate `--pmc` passes over the same command (FETCH_SIZE, WRITE_SIZE, SQ_*), averaged per launch.\n\n")
         f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) | waves |\n|---|---|---|---|---|---|---|---|\n")
         for r in vrows[:24]:
             k = short(r['Name']); p = vpmc.get(k, {})
