@@ -309,13 +309,16 @@ R2_API void r2_tile_first_stats(long long out[5], int reset);
 /* Stick-first binning of the voxelizer (csrc/voxel_sticks.hip): grids of more than 64 and up to 32 768 tiles (the 256^3 query of
  * test.py:105-112) are binned without a global sort -- instances are counted and scattered per STICK of up to 8 consecutive
  * tiles (per tile up to 4096 tiles) and every stick's list is sorted on (tile, z bits, id) on its own.  point_list, ranges,
- * volumes and gradients are identical on both chains; a large scene of large Gaussians (more than 32 tiles per Gaussian on average
- * and more than 4 Mi instances: trained clouds, where the general chain's wave-cooperative emission is the faster one)
- * continues on the general chain after the preprocess, and the calling thread remembers that for the (P, grid).  Debug mode, larger grids
+ * volumes and gradients are identical on both chains; a large scene with very long lists (a list of more than 20 480 instances
+ * and more than 8 Mi instances in all: the part-wise sort of such lists costs more than the general chain's radix passes;
+ * r2_voxel_sticks_limits) continues on the general chain after the preprocess, and the calling thread remembers that for the
+ * (P, grid).  Debug mode, larger grids
  * and P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
  * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes; 4 / 5 (tests): lists of more than 8192
  * instances count as unsupported / are sorted in parts (default). */
 R2_API void r2_voxel_sticks_control(int mode);
+/* The two limits of that rule (process-wide; <= 0: the default). */
+R2_API void r2_voxel_sticks_limits(long long longest_list, long long instances);
 /* process-wide counts since the last reset: out[0] forwards that took the chain, [1] forwards that left it after its scan for
  * the general chain, [2] forwards it declined.  out may be NULL (reset only). */
 R2_API void r2_voxel_sticks_stats(long long out[3], int reset);

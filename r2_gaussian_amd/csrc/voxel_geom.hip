@@ -224,26 +224,43 @@ __global__ void __launch_bounds__(VS_PRODUCER) voxel_cull_count_kernel(
     __syncthreads();
     const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
     uint32_t sum = 0u, vis = 0u;
+    const uint32_t nsub = 1u << sh;
+    auto count_row = [&](uint32_t t0, uint32_t rw) {   // the row's tiles, stick by stick
+        const uint32_t t1 = t0 + rw - 1u;
+        for (uint32_t l = t0 >> sh; l <= (t1 >> sh); ++l) {
+            const uint32_t a = max(t0, l << sh), b = min(t1, (l << sh) + nsub - 1u);
+            atomicAdd(&s_hist[l], b - a + 1u);
+        }
+    };
     for (uint32_t it = 0; it < ni; ++it) {
         const uint32_t idx = g0 + it * VS_PRODUCER + (uint32_t)tid;
-        if (idx >= g1) continue;
         float3 pv;
         float inv[6];
-        int3 lo, hi;
-        const uint32_t tt = voxel_cull_one((int)idx, means3D, scales, scale_modifier, rotations, cov3D_precomp, v, radii_x, radii_y,
-                                           radii_z, depth_key, cov3Ds, tiles_touched, cube, pv, inv, lo, hi);
-        if (tt == 0u) continue;
+        int3 lo = make_int3(0, 0, 0), hi = make_int3(0, 0, 0);
+        uint32_t tt = 0u;
+        if (idx < g1)
+            tt = voxel_cull_one((int)idx, means3D, scales, scale_modifier, rotations, cov3D_precomp, v, radii_x, radii_y, radii_z, depth_key,
+                                cov3Ds, tiles_touched, cube, pv, inv, lo, hi);
         sum += tt;
-        vis += 1u;
-        const uint32_t nsub = 1u << sh, rw = (uint32_t)(hi.x - lo.x);
-        for (int z = lo.z; z < hi.z; ++z)
-            for (int y = lo.y; y < hi.y; ++y) {
-                const uint32_t t0 = ((uint32_t)z * (uint32_t)v.gy + (uint32_t)y) * (uint32_t)v.gx + (uint32_t)lo.x, t1 = t0 + rw - 1u;
-                for (uint32_t l = t0 >> sh; l <= (t1 >> sh); ++l) {   // the row's tiles, stick by stick
-                    const uint32_t a = max(t0, l << sh), b = min(t1, (l << sh) + nsub - 1u);
-                    atomicAdd(&s_hist[l], b - a + 1u);
-                }
+        vis += tt != 0u ? 1u : 0u;
+        // (a Gaussian of many tiles: walked by the whole wave, a row per lane -- see the scatter kernel, voxel_sticks.hip)
+        const bool big = tt > VS_BIG_GAUSSIAN;
+        if (tt != 0u && !big)
+            for (int z = lo.z; z < hi.z; ++z)
+                for (int y = lo.y; y < hi.y; ++y)
+                    count_row(((uint32_t)z * (uint32_t)v.gy + (uint32_t)y) * (uint32_t)v.gx + (uint32_t)lo.x, (uint32_t)(hi.x - lo.x));
+        unsigned long long todo = __ballot(big);
+        while (todo) {   // (wave-uniform)
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const int ox = __shfl(lo.x, src), oy = __shfl(lo.y, src), oz = __shfl(lo.z, src);
+            const uint32_t rw = (uint32_t)(__shfl(hi.x, src) - ox), rh = (uint32_t)(__shfl(hi.y, src) - oy),
+                           rd = (uint32_t)(__shfl(hi.z, src) - oz);
+            for (uint32_t r = (uint32_t)lane; r < rd * rh; r += 64u) {
+                const uint32_t z = r / rh, y = r - z * rh;
+                count_row((((uint32_t)oz + z) * (uint32_t)v.gy + (uint32_t)oy + y) * (uint32_t)v.gx + (uint32_t)ox, rw);
             }
+        }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {

@@ -52,6 +52,7 @@ constexpr uint32_t VS_PRODUCER = 1024;      // Gaussians per producer workgroup 
 // owns at most VS_PER_THREAD_MAX Gaussians (293 workgroups of 1024 Gaussians on 256 CUs: the 37 CUs with two of them finished
 // 17 us after the others); thread t of workgroup w owns Gaussians w * per_wg + it * VS_PRODUCER + t, it < ni, below (w + 1) * per_wg
 constexpr uint32_t VS_PER_THREAD_MAX = 2;
+constexpr uint32_t VS_BIG_GAUSSIAN = 256;   // tiles beyond which a Gaussian's tile cube is walked by its whole wave, a row per lane
 struct VSGrid { uint32_t wgs, per_wg, ni; };
 inline VSGrid vs_grid(int P, int cus)
 {

@@ -49,8 +49,6 @@ namespace {
 
 constexpr int VS_THREADS = (int)VS_PRODUCER;
 constexpr uint32_t VS_MAX_SHIFT = 3;       // tiles per stick = 2^shift <= 8: three bits above the 29-bit id
-constexpr uint32_t VS_MAX_TILES_PER_GAUSSIAN = 32;   // a call with more tiles per visible Gaussian on average AND more than ...
-constexpr uint32_t VS_LARGE_SCENE = 4u << 20;        // ... this many instances goes to the general chain
 constexpr uint32_t VS_ID_BITS = 29;
 constexpr uint32_t VS_ID_MASK = (1u << VS_ID_BITS) - 1u;
 
@@ -227,37 +225,58 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
     __syncthreads();
     VS_TS(5);
     const uint32_t smask = (1u << sh) - 1u;
+    // one row of a Gaussian's tile cube (tiles t0r .. t0r + rw - 1: one stick, sometimes more): one LDS atomic per (row, stick), and
+    // its instances leave two to a 16-byte store.  The walk is bound by scattered store transactions: ~19 us for a workgroup's 19 k
+    // instances whatever the number of workgroups per CU.  Non-temporal stores (the dirty lines then do not wait in the L2s for the
+    // end of the kernel): 38 -> 123 us -- the L2's write combining is what makes this affordable
+    auto emit_row = [&](uint32_t g, uint32_t key, uint32_t t0r, uint32_t rw) {
+        const uint32_t t1r = t0r + rw - 1u;
+        for (uint32_t l = t0r >> sh; l <= (t1r >> sh); ++l) {
+            const uint32_t a = max(t0r, l << sh), b = min(t1r, (l << sh) + smask);
+            const uint32_t cnt = b - a + 1u;
+            const uint32_t pos = atomicAdd(&s_pos[l], cnt);
+            uint32_t k = 0;
+            for (; k + 1u < cnt; k += 2u) {
+                Pair2 w;
+                w.a = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
+                w.b = make_uint2(key, g | (((a + k + 1u) & smask) << VS_ID_BITS));
+                *reinterpret_cast<Pair2 *>(pairs + pos + k) = w;
+            }
+            if (k < cnt) pairs[pos + k] = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
+        }
+    };
 #pragma unroll
-    for (int it = 0; it < NI; ++it)
+    for (int it = 0; it < NI; ++it) {
+        // a Gaussian of MANY tiles is not walked by its own lane (a trained scene holds a few of tens of thousands of tiles: one lane
+        // walked for 235 us while a workgroup's median was 26) but, below, by the whole wave
+        const bool big = g_tt[it] > VS_BIG_GAUSSIAN;
         if (g_tt[it] != 0u) {
-            const uint32_t g = g_idx[it], key = g_key[it];
+            const uint32_t g = g_idx[it];
             // what the backward needs per Gaussian: its run of moment rows (any disjoint assignment serves: here id order)
             first[g] = firstv[it];
             reinterpret_cast<uint32_t *>(cube + g)[0] = firstv[it];
-            // ---- every instance of this Gaussian (a row of the cube lies in one stick, sometimes two: one LDS atomic per (row,
-            // stick), and its instances leave two to a 16-byte store).  The loop is bound by scattered store transactions:
-            // ~19 us for a workgroup's 19 k instances whatever the number of workgroups per CU.  Non-temporal stores (the dirty
-            // lines then do not wait in the L2s for the end of the kernel): 38 -> 123 us -- the L2's write combining is what
-            // makes this loop affordable)
-            const Cube q = cube_of(g_cb[it], g_tt[it]);
-            for (uint32_t z = 0; z < q.rd; ++z)
-                for (uint32_t y = 0; y < q.rh; ++y) {
-                    const uint32_t t0r = ((q.lz + z) * gy + q.ly + y) * gx + q.lx, t1r = t0r + q.rw - 1u;
-                    for (uint32_t l = t0r >> sh; l <= (t1r >> sh); ++l) {
-                        const uint32_t a = max(t0r, l << sh), b = min(t1r, (l << sh) + smask);
-                        const uint32_t cnt = b - a + 1u;
-                        const uint32_t pos = atomicAdd(&s_pos[l], cnt);
-                        uint32_t k = 0;
-                        for (; k + 1u < cnt; k += 2u) {
-                            Pair2 w;
-                            w.a = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
-                            w.b = make_uint2(key, g | (((a + k + 1u) & smask) << VS_ID_BITS));
-                            *reinterpret_cast<Pair2 *>(pairs + pos + k) = w;
-                        }
-                        if (k < cnt) pairs[pos + k] = make_uint2(key, g | (((a + k) & smask) << VS_ID_BITS));
-                    }
-                }
+            if (!big) {
+                const Cube q = cube_of(g_cb[it], g_tt[it]);
+                for (uint32_t z = 0; z < q.rd; ++z)
+                    for (uint32_t y = 0; y < q.rh; ++y) emit_row(g, g_key[it], ((q.lz + z) * gy + q.ly + y) * gx + q.lx, q.rw);
+            }
         }
+        unsigned long long todo = __ballot(big);
+        while (todo) {   // (wave-uniform) one such Gaussian at a time, a row per lane
+            const int src = __ffsll((long long)todo) - 1;
+            todo &= todo - 1ull;
+            const uint32_t og = (uint32_t)__shfl((int)g_idx[it], src), okey = (uint32_t)__shfl((int)g_key[it], src),
+                           ott = (uint32_t)__shfl((int)g_tt[it], src);
+            const uint4 ocb = make_uint4(0u, (uint32_t)__shfl((int)g_cb[it].y, src), (uint32_t)__shfl((int)g_cb[it].z, src),
+                                         (uint32_t)__shfl((int)g_cb[it].w, src));
+            const Cube q = cube_of(ocb, ott);
+            const uint32_t rows = q.rd * q.rh;
+            for (uint32_t r = (uint32_t)lane; r < rows; r += 64u) {
+                const uint32_t z = r / q.rh, y = r - z * q.rh;
+                emit_row(og, okey, ((q.lz + z) * gy + q.ly + y) * gx + q.lx, q.rw);
+            }
+        }
+    }
     VS_TS(6);
 }
 
@@ -705,6 +724,9 @@ VSNote *vs_note(int P, const VoxelGrid &v, bool create)
 
 // forwards that took the chain, forwards that left it after the scan (a list too long), forwards it declined
 std::atomic<long long> g_vs_taken{0}, g_vs_fallback{0}, g_vs_declined{0};
+// a call whose longest list exceeds the first AND whose instances exceed the second goes to the general chain (r2_voxel_sticks_limits)
+constexpr long long VS_LONG_LIST = 4 * 5120, VS_LONG_SCENE = 8ll << 20;
+std::atomic<long long> g_vs_long_list{VS_LONG_LIST}, g_vs_long_scene{VS_LONG_SCENE};
 std::atomic<int> g_vs_no_parts{0};   // tests: treat a list beyond one workgroup's capacity as unsupported (the fallback's path)
 std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1 (or 2): every grid it can serve
 
@@ -792,20 +814,18 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     // lists beyond one workgroup's capacity are sorted in parts: at most NL + R / VSK_BIG_TARGET descriptors of long lists.  More
     // than the state holds (Gaussians of hundreds of tiles each): the general chain, from here and from now on
     const size_t parts_bound = (size_t)NL + (size_t)num_rendered / VSK_BIG_TARGET + 1;
-    // ... and so do LARGE scenes of LARGE Gaussians (trained clouds: 65 tiles per Gaussian, 6 and 22 M instances).  This chain's
-    // producers walk a Gaussian's tiles one lane per Gaussian, the general chain emits instances wave-cooperatively.  Measured on
-    // the 92k / 331k trained clouds at 256^3: count 54 / 77 us and scatter 245 / 430 us (41 / 19 us per million instances; 8 on the
-    // benchmark cloud's 16 tiles per Gaussian) against the general chain's emission at 71 / 112, the query 964 / 2806 us against
-    // 791 / 2215.  Synthetic clouds of as large Gaussians are fine while they are small (20k Gaussians of 110 tiles, 2.2 M instances:
-    // 406 -> 388 us; 50k of 55: 386 -> 365), and so are large scenes of small Gaussians (a million of 8 tiles, lists of 10 000
-    // sorted in parts: 1340 -> 1276 us).  The fullest per-workgroup list counter (how hard a workgroup's lanes contend for one
-    // LDS counter) was measured as a possible criterion and does not separate them: 235 on the large trained cloud, 219 on the
-    // 20k synthetic one (and the reduction cost the count kernel 2 us).
+    // ... and so do large scenes with VERY long lists (the 331k trained cloud: 22 M instances, lists of 28 000): every part of such
+    // a list reads the whole list, and the part-wise sort then costs more than the general chain's two radix passes -- sort 572 us
+    // against 341 + 66 for the depth order, the ranges and the work list; the query 2449 us against 2223.  Long lists in smaller
+    // scenes are fine (a million small Gaussians, 8 M instances, lists of 10 000: 1340 -> 1276 us), and so are large Gaussians
+    // (the 92k trained cloud, 65 tiles per Gaussian, 6 M instances, longest list 7245: 791 -> 755 us) -- since a Gaussian of
+    // thousands of tiles is walked by its whole wave in the count and scatter kernels; before that, one lane walked a background
+    // blob's tiles for 235 us and the same query took 964.
     const uint32_t nvis = hw[DW_NVIS];
     static const bool dbg = [] { const char *e = getenv("R2_VOXEL_STICKS_DEBUG"); return e && e[0] == '1'; }();
     if (dbg) fprintf(stderr, "voxel sticks: P %d R %u visible %u longest list %u\n", P, num_rendered, nvis, longest);
-    static const uint32_t max_tpg = [] { const char *e = getenv("R2_VOXEL_STICKS_MAXTPG"); return e ? (uint32_t)atoi(e) : VS_MAX_TILES_PER_GAUSSIAN; }();
-    const bool large = (size_t)num_rendered > (size_t)max_tpg * (nvis ? nvis : 1u) && num_rendered > VS_LARGE_SCENE;
+    const bool large = (long long)longest > g_vs_long_list.load(std::memory_order_relaxed) &&
+                       (long long)num_rendered > g_vs_long_scene.load(std::memory_order_relaxed);
     if (large || parts_bound > st.bigcap || (g_vs_no_parts.load(std::memory_order_relaxed) && longest > VSK_BIG_CAP)) {
         vs_note(P, v, true)->bad = true;
         g_vs_fallback.fetch_add(1, std::memory_order_relaxed);
@@ -869,6 +889,12 @@ extern "C" void r2_voxel_sticks_stats(long long *out, int reset)
         if (out) out[i] = c[i]->load(std::memory_order_relaxed);
         if (reset) c[i]->store(0, std::memory_order_relaxed);
     }
+}
+
+extern "C" void r2_voxel_sticks_limits(long long longest_list, long long instances)
+{
+    r2::g_vs_long_list.store(longest_list > 0 ? longest_list : r2::VS_LONG_LIST, std::memory_order_relaxed);
+    r2::g_vs_long_scene.store(instances > 0 ? instances : r2::VS_LONG_SCENE, std::memory_order_relaxed);
 }
 
 extern "C" void r2_voxel_sticks_control(int mode)

@@ -165,25 +165,61 @@ def test_lists_beyond_one_workgroup_are_sorted_in_parts(name, make, n, oracle, g
         assert np.array_equal(g0[k].view(np.uint32), g1[k].view(np.uint32)), k
 
 
-def test_a_large_scene_of_large_gaussians_continues_on_the_general_chain(oracle, gpu, sticks_mode):
-    """More than 32 tiles per Gaussian on average AND more than 4 Mi instances (a trained cloud: 65 tiles, 6 to 22 M instances; here a
-    synthetic cloud with 2.5 x the scales): the general chain's wave-cooperative emission is the faster one, the stick chain hands
-    over after the preprocess."""
-    c = S.make_cloud(20000, seed=3, scale_mult=2.5)
+def test_gaussians_of_thousands_of_tiles_are_walked_by_their_wave(oracle, gpu, sticks_mode):
+    """A trained scene holds a few Gaussians that span much of the volume (background blobs): their tile cubes -- here 2197 and 4913
+    tiles on a 136^3 grid, among 5000 ordinary Gaussians -- are walked by the whole wave, a row per lane, in the count and scatter
+    kernels (one lane walked for 235 us on the 92k trained cloud)."""
+    c0 = S.make_cloud(5000, seed=4)
+    scales = c0.scales.clone()
+    scales[7] = 0.25       # radius 3 sigma = 0.75 of a 2.0 volume: a cube of 13 tiles a side
+    scales[1500] = 0.6     # covers the whole grid
+    scales[4999] = 0.6
+    c = S.Cloud(c0.xyz, scales, c0.rotations, c0.density)
     n, s, ctr = (136, 136, 136), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
     o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
-    assert o["num_rendered"] > 32 * 20000 and o["num_rendered"] > 4 << 20
+    assert int(o["tiles_touched"].max()) == 17 ** 3 and int((o["tiles_touched"] > 256).sum()) >= 3
+    sticks_mode(0)
+    h0 = Hh.hip_voxel(c, n, s, ctr, gpu)
     sticks_mode(1)
     _stats()
     h = Hh.hip_voxel(c, n, s, ctr, gpu)
-    assert _stats() == [0, 1, 0] and not Hh.took_sticks(h)
+    assert _stats() == [1, 0, 0] and Hh.took_sticks(h)
     assert h["num_rendered"] == o["num_rendered"]
-    for k in ("radii_x", "radii_y", "radii_z"):
-        assert np.array_equal(h[k], o[k])
     Hh.check_binning(h, o)
-    h2 = Hh.hip_voxel(c, n, s, ctr, gpu)                      # the thread remembers: declined, the hinted general chain
-    assert _stats() == [0, 0, 1]
-    assert np.array_equal(h2["point_list"], h["point_list"]) and np.array_equal(h2["vol"].view(np.uint32), h["vol"].view(np.uint32))
+    assert np.array_equal(h0["vol"].view(np.uint32), h["vol"].view(np.uint32))
+    g = torch.Generator().manual_seed(3)
+    dL = ((torch.rand(*n, generator=g) * 2 - 1) / float(np.prod(n))).numpy()
+    g0 = Hh.hip_voxel_backward(h0, c, n, s, ctr, dL, gpu)
+    g1 = Hh.hip_voxel_backward(h, c, n, s, ctr, dL, gpu)
+    for k in g0:
+        assert np.array_equal(g0[k].view(np.uint32), g1[k].view(np.uint32)), k
+
+
+def test_a_large_scene_with_very_long_lists_continues_on_the_general_chain(oracle, gpu, sticks_mode):
+    """A list of more than 20 480 instances in a scene of more than 8 Mi (the 331k trained cloud: lists of 28 000, 22 M instances): the
+    part-wise sort costs more than the general chain's radix passes, the stick chain hands over after the preprocess.  The two
+    limits are lowered here so that a small scene shows the rule."""
+    c = _squeezed(20000, 5, 0.03)
+    n, s, ctr = (64, 64, 64), (2.0, 2.0, 2.0), (0.0, 0.0, 0.0)
+    o = Hh.oracle_voxel(oracle, c, n, s, ctr, render=False)
+    L = _lib()
+    try:
+        L.r2_voxel_sticks_limits(10000, 100000)     # the scene: lists of 20 000, 160 000 instances
+        sticks_mode(1)
+        _stats()
+        h = Hh.hip_voxel(c, n, s, ctr, gpu)
+        assert _stats() == [0, 1, 0] and not Hh.took_sticks(h)
+        assert h["num_rendered"] == o["num_rendered"]
+        Hh.check_binning(h, o)
+        h2 = Hh.hip_voxel(c, n, s, ctr, gpu)                      # the thread remembers: declined, the hinted general chain
+        assert _stats() == [0, 0, 1]
+        assert np.array_equal(h2["point_list"], h["point_list"]) and np.array_equal(h2["vol"].view(np.uint32), h["vol"].view(np.uint32))
+        L.r2_voxel_sticks_limits(10000, 1000000)    # only one of the two limits exceeded: the chain serves it
+        sticks_mode(3)
+        h3 = Hh.hip_voxel(c, n, s, ctr, gpu)
+        assert _stats() == [1, 0, 0] and Hh.took_sticks(h3)
+    finally:
+        L.r2_voxel_sticks_limits(0, 0)
 
 
 def test_a_scene_the_chain_cannot_serve_continues_on_the_general_one(oracle, gpu, sticks_mode):
