@@ -27,7 +27,11 @@ for suffix in ("_tf0", "_tf1"):
     cp(os.path.join(G, "cbench_%s%s.txt" % (tag, suffix)), os.path.join(P, "%s_cbench%s.txt" % (tag, suffix)))
 cp(os.path.join(G, "timeline_%s.txt" % tag), os.path.join(P, "%s_timeline_stamps.txt" % tag))
 for suffix in ("", "_driver", "_B", "_C", "_E", "_trained_small", "_trained_large", "_forcecomm"):
-    cp(os.path.join(G, "bench_%s%s.json" % (tag, suffix)), os.path.join(P, "%s_bench%s.json" % (tag, suffix)))
+    src, dst = os.path.join(G, "bench_%s%s.json" % (tag, suffix)), os.path.join(P, "%s_bench%s.json" % (tag, suffix))
+    if os.path.exists(src):   # only the JSON line (RCCL prints a version banner to stdout in front of it)
+        lines = [l for l in open(src).read().splitlines() if l.startswith('{"metric')]
+        if lines:
+            open(dst, "w").write(lines[-1] + "\n")
 cp(os.path.join(G, "cbench_%s.txt" % tag), os.path.join(P, "%s_cbench.txt" % tag))
 for f in ("train_synthetic_fused.json",):
     cp(os.path.join(G, f), os.path.join(P, "%s_%s" % (tag, f)))
