@@ -17,10 +17,11 @@
 //     per-instance tile ids and the ranges of its tiles.
 // Sorting every list by (tile, z bits, id) IS the reference's (tile | z bits) order with its tie rule (emission order = id
 // order): point_list and ranges are bit-identical to the general chain's, which stays as the path of debug mode, of grids of
-// more than 32 768 tiles, and of scenes whose long lists need more part descriptors than the state holds (the chain notices after
-// its scan, continues on the general chain's un-hinted branch -- the preprocess is not repeated -- and the thread remembers the
-// (P, grid) for which that happened).  A list beyond one workgroup's capacity (8192 entries: trained clouds, a million
-// Gaussians) is sorted by several workgroups, each a range of the list's (tile, z) axis.
+// more than 32 768 tiles, and of large scenes with very long lists (more than 20 480 instances in a list and 8 Mi in all: the 331k
+// trained cloud; the chain notices after its scan, continues on the general chain's un-hinted branch -- the preprocess is not
+// repeated -- and the thread remembers the (P, grid) for which that happened).  A list beyond one workgroup's capacity (8192 entries:
+// trained clouds, a million Gaussians) is sorted by several workgroups, each a range of the list's (tile, z) axis; a Gaussian of more
+// than 256 tiles (a trained scene's background blobs have tens of thousands) is walked by its whole wave, a row per lane.
 //
 //     1. voxel_cull_count_kernel (voxel_geom.hip)    the part of the preprocess the binning needs (radii, tile cube, z bits) + an LDS
 //                                                    histogram of the workgroup's instances over the lists -> H[wg][list]
