@@ -62,7 +62,7 @@ extern "C" int r2_voxel_forward(
         }
     }
 
-    // large grids (> 4096 tiles, e.g. the 256^3 query): stick-first binning, no global sort (voxel_sticks.hip)
+    // grids of 65 to 32 768 tiles (64^3 ... the 256^3 query): stick-first binning, no global sort (voxel_sticks.hip)
     bool preprocessed = false;   // that chain left after its scan (a list too long for it): the preprocess has run, un-hinted
     if (!debug) {
         const int st = voxel_forward_sticks(binningBuffer, binning_user, imageBuffer, image_user, geom, v, P, means3D, opacities, scales,

@@ -1,6 +1,6 @@
-// voxel_sticks.hip -- stick-first binning of the voxelizer's LARGE grids (round 5): the reference's duplicateWithKeys ->
-// SortPairs(tile | z bits) -> identifyTileRanges (VOX/voxelizer_impl.cu:54-128,244-287) for grids of more than 4096 tiles (the 256^3
-// query of test.py:105-112 has 32 768) without a global sort.
+// voxel_sticks.hip -- stick-first binning of the voxelizer (round 5): the reference's duplicateWithKeys -> SortPairs(tile | z bits) ->
+// identifyTileRanges (VOX/voxelizer_impl.cu:54-128,244-287) for grids of 65 to 32 768 tiles (the 256^3 query of test.py:105-112 has
+// 32 768; smaller grids take voxel_small.hip) without a global sort.
 //
 // Why.  The general chain (voxel_api.hip) orders the Gaussians by their z bits (five launches), emits the instances in that order
 // and sorts them by their 15-bit tile id with two 8-bit radix passes (six launches) before the ranges and the work list (three):
@@ -8,7 +8,8 @@
 // rasterizer's tile-first chain (raster_tilefirst.hip) does not carry over as it is: 32 768 tile counters do not fit one LDS
 // histogram, and one returning global atomic per (workgroup, tile) is 10^6 atomics here (the Gaussians of a workgroup are spread
 // over the whole volume).  So:
-//   * a LIST is a STICK of 2^shift consecutive tile ids (8 tiles along x at 256^3): <= 4096 lists, one LDS histogram;
+//   * a LIST is a STICK of 2^shift consecutive tile ids (8 tiles along x at 256^3, one tile up to 4096 tiles): <= 4096 lists, one
+//     LDS histogram;
 //   * the per-(workgroup, list) counts go to memory with plain stores (16 KB per workgroup of 1024 Gaussians) and a column scan
 //     turns them into offsets -- no global atomics except one per workgroup for the call's totals;
 //   * every instance is then written straight into its list's segment as (z bits, id | tile-in-stick << 29), in arbitrary order;
