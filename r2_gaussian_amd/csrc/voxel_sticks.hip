@@ -22,7 +22,7 @@
 // trained cloud; the chain notices after its scan, continues on the general chain's un-hinted branch -- the preprocess is not
 // repeated -- and the thread remembers the (P, grid) for which that happened).  A list beyond one workgroup's capacity (8192 entries:
 // trained clouds, a million Gaussians) is sorted by several workgroups, each a range of the list's (tile, z) axis; a Gaussian of more
-// than 256 tiles (a trained scene's background blobs have tens of thousands) is walked by its whole wave, a row per lane.
+// than 256 tiles (a trained scene's background blobs have thousands) is walked by its whole wave, a row per lane.
 //
 //     1. voxel_cull_count_kernel (voxel_geom.hip)    the part of the preprocess the binning needs (radii, tile cube, z bits) + an LDS
 //                                                    histogram of the workgroup's instances over the lists -> H[wg][list]
@@ -249,7 +249,7 @@ __global__ void __launch_bounds__(VS_THREADS) vox_stick_scatter_kernel(
     };
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
-        // a Gaussian of MANY tiles is not walked by its own lane (a trained scene holds a few of tens of thousands of tiles: one lane
+        // a Gaussian of MANY tiles is not walked by its own lane (a trained scene holds a few of thousands of tiles: one lane
         // walked for 235 us while a workgroup's median was 26) but, below, by the whole wave
         const bool big = g_tt[it] > VS_BIG_GAUSSIAN;
         if (g_tt[it] != 0u) {
