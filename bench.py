@@ -249,9 +249,13 @@ def stub_ops(P, HW):
             self.st = st
 
         def __call__(self, means3D, opacities, scales, rotations):
-            n = (self.st.nVoxel_x, self.st.nVoxel_y, self.st.nVoxel_z)
-            c = float(self.st.center_x)   # (a slab knows where it is: the gathered volume can be checked)
-            return torch.full(n, c) + 0.0 * means3D.sum(), None
+            # a slab = the full volume's settings + its range of tile layers (dist.slab_settings); it is filled with the centre
+            # of that range, so that the gathered volume can be checked
+            t0, t1 = int(getattr(self.st, "tile_x0", 0)), int(getattr(self.st, "tile_x1", (self.st.nVoxel_x + 7) // 8))
+            x0, x1 = 8 * t0, min(8 * t1, self.st.nVoxel_x)
+            dv = float(self.st.sVoxel_x) / self.st.nVoxel_x
+            c = float(self.st.center_x) - 0.5 * float(self.st.sVoxel_x) + (x0 + 0.5 * (x1 - x0)) * dv
+            return torch.full((x1 - x0, self.st.nVoxel_y, self.st.nVoxel_z), c) + 0.0 * means3D.sum(), None
     return {"render": render, "image_loss": lambda img, vi: img.abs().mean(),
             "densify_stats": lambda radii, g2, mr, ga, dn: None,
             "query32": lambda k, x, d, s, r: (x.sum() + d.sum() + s.sum() + r.sum()) * 1e-6 * torch.ones((4, 4, 4)),

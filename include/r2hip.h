@@ -47,7 +47,7 @@ extern "C" {
 #define R2_API
 #endif
 
-#define R2_ABI_VERSION 2
+#define R2_ABI_VERSION 3
 #define R2_ERR_INVALID (-10001) /* bad argument (NULL where data is required, negative size ...) */
 #define R2_ERR_ALLOC   (-10002) /* an r2_alloc_fn callback returned NULL */
 
@@ -239,6 +239,47 @@ R2_API int r2_voxel_backward(
     float *dL_dcov3D,          /* [P,6] */
     float *dL_dscale,          /* [P,3] */
     float *dL_drot,            /* [P,4] */
+    int debug, void *stream);
+
+/* ---- voxelizer, one x-slab of the grid (NEW functionality: the unit of the sharded full-volume query) ----
+ * Tile layers [tile_x0, tile_x1) along x (layers of 8 voxels; 0 <= tile_x0 < tile_x1 <= ceil(nVoxel_x / 8)) of the volume the
+ * other arguments describe -- nVoxel / sVoxel / center are the FULL volume's, exactly as for r2_voxel_forward.  The call evaluates
+ * the full grid's arithmetic (voxel size, voxel-space positions, radii, tile cubes, distances to the voxel centres) and bins /
+ * renders only the slab's tiles: out_volume is the [min(8 tile_x1, nVoxel_x) - 8 tile_x0, ny, nz] block of the full volume,
+ * BIT-IDENTICAL to the same voxels of r2_voxel_forward's result, and the slab's tile lists are the full call's lists of those tiles
+ * (reference: ONE grid with one arithmetic, test.py:105-112, SUB/cuda_voxelizer/forward.cu:58-178, voxelizer_impl.cu:54-101).
+ * Slabs are independent: no exchange between them.  radii_{x,y,z}: the full call's radii for Gaussians with a tile in the slab, 0
+ * for the others.  Returns the slab's num_rendered.  r2_voxel_forward(...) == r2_voxel_forward_slab(..., 0, ceil(nVoxel_x / 8), ...).
+ * The backward takes the same two numbers; dL_dvol is the slab's block. */
+R2_API int r2_voxel_forward_slab(
+    r2_alloc_fn geometryBuffer, void *geometry_user,
+    r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user,
+    int P,
+    int nVoxel_x, int nVoxel_y, int nVoxel_z,
+    float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z,
+    int tile_x0, int tile_x1,
+    const float *means3D, const float *opacities, const float *scales, float scale_modifier,
+    const float *rotations, const float *cov3D_precomp,
+    int prefiltered,
+    float *out_volume,         /* [slab nx,ny,nz] */
+    int *radii_x, int *radii_y, int *radii_z, /* [P] each */
+    int debug, void *stream);
+
+R2_API int r2_voxel_backward_slab(
+    int P, int R,
+    int nVoxel_x, int nVoxel_y, int nVoxel_z,
+    float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z,
+    int tile_x0, int tile_x1,
+    const float *means3D, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp,
+    const int *radii_x, const int *radii_y, const int *radii_z,
+    char *geom_buffer, char *binning_buffer, char *img_buffer,
+    const float *dL_dvol,      /* [slab nx,ny,nz] */
+    float *dL_dmean3D_norm, float *dL_dconic3D, float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale,
+    float *dL_drot,
     int debug, void *stream);
 
 /* ---- simple-knn ------------------------------------------------------------------------------ */

@@ -335,40 +335,66 @@ def mark_visible(means3D, viewmatrix, projmatrix):
     return present
 
 
+TILE3D = 8
+
+
+def _slab_tiles(nVoxel_x, tile_x0, tile_x1):
+    """(tile_x0, tile_x1, voxels of the slab along x); tile_x1 None / negative = up to the last layer."""
+    layers = (int(nVoxel_x) + TILE3D - 1) // TILE3D
+    t0 = int(tile_x0)
+    t1 = layers if tile_x1 is None or int(tile_x1) < 0 else int(tile_x1)
+    if not (0 <= t0 < t1 <= layers):
+        raise _lib.R2HipError("x-slab [%d, %d) is not a non-empty range of the grid's %d tile layers" % (t0, t1, layers))
+    return t0, t1, min(t1 * TILE3D, int(nVoxel_x)) - t0 * TILE3D
+
+
 def voxelize_gaussians(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, nVoxel_x, nVoxel_y,
                        nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, prefiltered, debug):
     """-> (num_rendered, out_volume[nx,ny,nz], radii_x, radii_y, radii_z, geomBuffer, binningBuffer, imgBuffer)
     (SUB/voxelize_points.cu:29-98)."""
+    return voxelize_gaussians_slab(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, nVoxel_x, nVoxel_y,
+                                   nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, prefiltered, debug,
+                                   0, None)
+
+
+def voxelize_gaussians_slab(means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp, nVoxel_x, nVoxel_y,
+                            nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, prefiltered, debug,
+                            tile_x0, tile_x1):
+    """``voxelize_gaussians`` for the tile layers [tile_x0, tile_x1) along x of the grid the other arguments describe
+    (r2_voxel_forward_slab; new: the unit of the sharded query): out_volume is the slab's [x1 - x0, ny, nz] block, bit-identical
+    to those voxels of the full call."""
     if means3D.ndim != 2 or means3D.shape[1] != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    t0, t1, nxs = _slab_tiles(nVoxel_x, tile_x0, tile_x1)
     sh = _shim()
     if sh is not None:
         return _shim_call(sh.voxelize_gaussians, means3D, opacity, scales, rotations, scale_modifier, cov3D_precomp,
                           int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y), float(sVoxel_z),
-                          float(center_x), float(center_y), float(center_z), bool(prefiltered), bool(debug), _raw_stream(dev))
+                          float(center_x), float(center_y), float(center_z), bool(prefiltered), bool(debug), _raw_stream(dev),
+                          t0, t1)
     P = means3D.shape[0]
     nx, ny, nz = int(nVoxel_x), int(nVoxel_y), int(nVoxel_z)
     hk = _hooks(dev)
     if P == 0:
         z = torch.zeros((0,), dtype=torch.int32, device=dev)
-        return 0, torch.zeros((nx, ny, nz), dtype=_F32, device=dev), z, z.clone(), z.clone(), hk.empty, hk.empty, hk.empty
-    out = torch.empty((nx, ny, nz), dtype=_F32, device=dev)       # written in full by the combine kernel
+        return 0, torch.zeros((nxs, ny, nz), dtype=_F32, device=dev), z, z.clone(), z.clone(), hk.empty, hk.empty, hk.empty
+    out = torch.empty((nxs, ny, nz), dtype=_F32, device=dev)      # written in full by the combine kernel
     radii = torch.empty((3, P), dtype=torch.int32, device=dev)    # written in full by the preprocess kernel
     m3 = _dev_f32(means3D, means3D)
     op, sc, ro, cp = (_dev_f32(t, means3D) for t in (opacity, scales, rotations, cov3D_precomp))
     st = hk.begin()
     try:
         with _on_device(dev):
-            rc = _lib.lib().r2_voxel_forward(
+            rc = _lib.lib().r2_voxel_forward_slab(
                 hk.cbs[0], None, hk.cbs[1], None, hk.cbs[2], None, P, nx, ny, nz, float(sVoxel_x), float(sVoxel_y),
-                float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(op), _ptr(sc),
+                float(sVoxel_z), float(center_x), float(center_y), float(center_z), t0, t1, _ptr(m3), _ptr(op), _ptr(sc),
                 float(scale_modifier), _ptr(ro), _ptr(cp), int(bool(prefiltered)), out.data_ptr(),
                 radii[0].data_ptr(), radii[1].data_ptr(), radii[2].data_ptr(), int(bool(debug)), _stream(dev))
     finally:
         bufs = hk.finish(st)
-    rendered = _lib.check(rc, "r2_voxel_forward")
+    rendered = _lib.check(rc, "r2_voxel_forward_slab")
     return rendered, out, radii[0], radii[1], radii[2], bufs[0], bufs[1], bufs[2]
 
 
@@ -378,14 +404,26 @@ def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rota
                                 debug):
     """-> (dL_dopacity[P,1], dL_dmeans3D[P,3], dL_dcov3D[P,6], dL_dscales[P,3], dL_drotations[P,4])
     (SUB/voxelize_points.cu:102-167)."""
+    return voxelize_gaussians_backward_slab(means3D, radii_x, radii_y, radii_z, scales, rotations, scale_modifier,
+                                            cov3D_precomp, dL_dout_color, geomBuffer, R, binningBuffer, imageBuffer, nVoxel_x,
+                                            nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z,
+                                            debug, 0, None)
+
+
+def voxelize_gaussians_backward_slab(means3D, radii_x, radii_y, radii_z, scales, rotations, scale_modifier,
+                                     cov3D_precomp, dL_dout_color, geomBuffer, R, binningBuffer, imageBuffer, nVoxel_x,
+                                     nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z,
+                                     debug, tile_x0, tile_x1):
+    """Backward of ``voxelize_gaussians_slab`` (dL_dout_color = the slab's block)."""
     _require_gpu(means3D, "means3D")
     dev = means3D.device
+    t0, t1, _nxs = _slab_tiles(nVoxel_x, tile_x0, tile_x1)
     sh = _shim()
     if sh is not None:
         return _shim_call(sh.voxelize_gaussians_backward, means3D, radii_x, radii_y, radii_z, scales, rotations,
                           scale_modifier, cov3D_precomp, dL_dout_color, geomBuffer, int(R), binningBuffer, imageBuffer,
                           int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y), float(sVoxel_z),
-                          float(center_x), float(center_y), float(center_z), bool(debug), _raw_stream(dev))
+                          float(center_x), float(center_y), float(center_z), bool(debug), _raw_stream(dev), t0, t1)
     P = means3D.shape[0]
     flat = torch.empty(26 * P, dtype=_F32, device=dev)   # every row is written by the kernels (zeros where culled)
     cuts = [4, 3, 3, 6, 1, 6, 3]
@@ -406,14 +444,14 @@ def voxelize_gaussians_backward(means3D, radii_x, radii_y, radii_z, scales, rota
         g = _dev_f32(dL_dout_color, means3D)
         rx, ry, rz = radii_x.contiguous(), radii_y.contiguous(), radii_z.contiguous()
         with _on_device(dev):
-            rc = _lib.lib().r2_voxel_backward(
+            rc = _lib.lib().r2_voxel_backward_slab(
                 P, int(R), int(nVoxel_x), int(nVoxel_y), int(nVoxel_z), float(sVoxel_x), float(sVoxel_y),
-                float(sVoxel_z), float(center_x), float(center_y), float(center_z), _ptr(m3), _ptr(sc),
+                float(sVoxel_z), float(center_x), float(center_y), float(center_z), t0, t1, _ptr(m3), _ptr(sc),
                 float(scale_modifier), _ptr(ro), _ptr(cp), rx.data_ptr(), ry.data_ptr(), rz.data_ptr(),
                 _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imageBuffer), _ptr(g), dL_dmeans3D_norm.data_ptr(),
                 dL_dconic3D.data_ptr(), dL_dopacity.data_ptr(), dL_dmeans3D.data_ptr(), dL_dcov3D.data_ptr(),
                 dL_dscales.data_ptr(), dL_drot.data_ptr(), int(bool(debug)), _stream(dev))
-        _lib.check(rc, "r2_voxel_backward")
+        _lib.check(rc, "r2_voxel_backward_slab")
     return dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dscales, dL_drot
 
 

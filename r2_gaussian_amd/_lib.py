@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("R2HIP_LIB") or os.path.join(_HERE, "libr2hip.so")
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_size_t, C.c_void_p)
 
-R2_ABI_VERSION = 2
+R2_ABI_VERSION = 3
 R2_ERR_INVALID = -10001
 R2_ERR_ALLOC = -10002
 
@@ -34,6 +34,10 @@ _SIGNATURES = {
                                    _fp, _fp, _fp, _f, _fp, _fp, _i, _fp, _p, _p, _p, _i, _p]),
     "r2_voxel_backward": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _fp, _fp, _f, _fp, _fp, _p, _p, _p,
                                     _p, _p, _p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _p]),
+    "r2_voxel_forward_slab": (C.c_int, [ALLOC_FN, _p, ALLOC_FN, _p, ALLOC_FN, _p, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i,
+                                        _fp, _fp, _fp, _f, _fp, _fp, _i, _fp, _p, _p, _p, _i, _p]),
+    "r2_voxel_backward_slab": (C.c_int, [_i, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _i, _i, _fp, _fp, _f, _fp, _fp, _p, _p, _p,
+                                         _p, _p, _p, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _i, _p]),
     "r2_knn_dist2": (C.c_int, [_i, _fp, _fp, _p]),
     "r2_knn_workspace_bytes": (C.c_size_t, [_i]),
     "r2_knn_dist2_ws": (C.c_int, [_i, _fp, _fp, _p, C.c_size_t, _p]),

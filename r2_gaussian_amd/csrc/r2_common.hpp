@@ -286,7 +286,7 @@ struct WorkListOut {
     uint32_t *chunk_base;
     uint4 *work;
     uint32_t T, chunk;
-    // optional (rasterizer, fused combine): per-tile arrival counters to zero, and EMPTY tiles appended to the work list as
+    // optional (rasterizer, fused combine): arrival counters to zero ([4 T], 16-byte aligned), and EMPTY tiles appended to the work list as
     // items {tile, 0, 0, 0} behind the real ones (somebody has to write their zeros); chunk_base[T + 1] = real + empty items
     uint32_t *tile_done;
     // optional (voxelizer): tiles with fewer than min_len instances get NO work item (a light kernel renders them)
@@ -338,7 +338,7 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
     for (uint32_t base = 0; base < wo.T; base += NT) {
         const uint32_t t = base + tid;
         const uint32_t empty = (t < wo.T && counts[t] == 0u) ? 1u : 0u;
-        if (t < wo.T) wo.tile_done[t] = 0u;
+        if (t < wo.T) reinterpret_cast<uint4 *>(wo.tile_done)[t] = make_uint4(0u, 0u, 0u, 0u);   // one counter per 8x8 block
         uint32_t incl = empty;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {

@@ -272,6 +272,166 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 // needs 87-99 VGPRs for it, not ~64: 81 us at 4 waves/SIMD, 56 at 5, 52 at 6 (16 B/lane of scratch), 60 at 7, 56 at 8 (56 B of
 // scratch) against 47.7 us for this kernel -- twice the (entry, block) items to compact, stage and transpose-reduce cost more than
 // the finer culling and the extra waves return.)
+// ---- forward, round 6: ONE-WAVE work items that gather for themselves (VERDICT r5 #2a).
+// Work item = (<= FWD_CHUNK consecutive instances of one tile list) x (one 8x8 block) = one wave = one workgroup.  What the
+// four-wave kernel above spends its life on, measured in round 3 (46 % of a wave's life parked at s_waitcnt, VALU issue 0.40):
+// every 256-entry batch is a chain descriptor -> ids -> records -> LDS -> barrier -> four rounds of block tests -> steps, with the
+// next batch's ids requested only when this batch starts, and the four waves of a tile wait for each other twice per batch.
+// Here the instance list carries every entry's block mask (RasterBinning::masked, written where the list is made), so a wave
+//   1. requests ALL masked ids of its chunk at once (8 coalesced loads in flight, one round trip),
+//   2. compacts the ids whose mask holds its block into an LDS queue (ballot + rank: no record is gathered to be tested, dead
+//      instances -- 16-19 % of a list cannot reach their tile at all -- cost one bit test),
+//   3. walks the queue 64 entries per step, lane = entry as above, with the NEXT step's records (two 16-byte gathers per lane)
+//      in flight while this step computes.
+// No workgroup barrier, no record staging, three dependent round trips per work item whatever its length; a wave whose block is
+// empty leaves at once instead of idling at its siblings' barriers.  The arithmetic (fwd_item, the transposes, the combine of a
+// tile's partial sums in list order by the last arriver) is the kernel's above; the lanes that hold an entry differ (compaction over the
+// whole chunk instead of per 256-entry batch), so the two kernels' images agree to float association, not bit for bit.
+// blockIdx -> (work item, block): the four blocks of an item run on ONE XCD (block b of the grid runs on XCD b % 8), so its
+// records are pulled into one L2.
+template <bool ANY4, bool MV>
+__global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
+    const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile, uint32_t T, uint32_t NW,
+    const uint32_t *__restrict__ masked, const float4 *__restrict__ rec, int gx, int gy, float *__restrict__ partial,
+    uint32_t *__restrict__ tile_done, float *__restrict__ out_color, int W, int H, uint32_t *__restrict__ tiles, char *tf_bin_base,
+    const uint32_t *__restrict__ tf_words)
+{
+    __shared__ uint32_t sQ[FWD_CHUNK];   // ids of the chunk's entries that are live for this block, in list order
+    const uint32_t bi = blockIdx.x;
+    const uint32_t w = (bi >> 5) * 8u + (bi & 7u);
+    const int blk = (int)((bi >> 3) & 3u);
+    const int lane = threadIdx.x;
+    R2_TS_AT(render, 0);
+    const uint4 wd = work_tile[min(w, NW - 1u)];   // {tile, first instance, one past the last, items of the tile}
+    if (w >= chunk_base[T + 1]) return;
+    if (tf_bin_base != nullptr) {   // tile-first forward: the binning buffer was carved with a PREDICTED instance count (raster_state.hpp)
+        const size_t Rt = (size_t)tf_words[DW_TOTAL];
+        tiles = binning_tiles_ptr(tf_bin_base, Rt);
+        masked = binning_masked_ptr(tf_bin_base, Rt);
+    }
+    const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
+    int tx, ty, tv;
+    tile_decode<MV>(tile, gx, gy, tx, ty, tv);
+    out_color += (size_t)tv * H * W;
+    const int bx = (blk & 1) * SUB2D, by = (blk >> 1) * SUB2D;
+    const int px = tx * TILE2D + bx + (lane & 7), py = ty * TILE2D + by + (lane >> 3);
+    const bool inside = px < W && py < H;
+    if (wd.w == 0u) {   // empty tile
+        if (inside) out_color[py * W + px] = 0.f;
+        return;
+    }
+    const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
+    // the backward's per-instance tile ids (until it reads the work list itself)
+    if (tiles != nullptr && blk == 0)
+        for (uint32_t k = beg + (uint32_t)lane; k < end; k += 64u) tiles[k] = tile;
+
+    // ---- 1. the chunk's masked ids, branch-free (clamped addresses): one round trip for all of them
+    constexpr int NR = (int)FWD_CHUNK / 64;
+    const uint32_t n = end - beg;
+    uint32_t v[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = masked[beg + min((uint32_t)(r * 64 + lane), n - 1u)];
+    // ---- 2. this block's live entries, in list order
+    int cnt = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const bool keep = (uint32_t)(r * 64 + lane) < n && ((v[r] >> blk) & 1u) != 0u;
+        const unsigned long long m = __ballot(keep);
+        if (keep) sQ[cnt + (int)ballot_rank(m)] = v[r] >> MASK_BITS;
+        cnt += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    float acc[64];
+#pragma unroll
+    for (int i = 0; i < 64; ++i) acc[i] = 0.f;
+    // ---- 3. 64 entries per step, one per lane; the next step's records are gathered while this one computes (the clamp makes the
+    // last step gather an entry it does not use: cheaper than a branch around the loads, which would drain the queue)
+    float4 na = make_float4(0.f, 0.f, 0.f, 0.f), nb = na;
+    if (cnt > 0) {
+        const uint32_t id = sQ[min(lane, cnt - 1)];
+        na = rec[2 * id];
+        nb = rec[2 * id + 1];
+    }
+    for (int head = 0; head < cnt; head += 64) {
+        float4 ea = na, eb = nb;
+        {
+            const uint32_t id = sQ[min(head + 64 + lane, cnt - 1)];
+            na = rec[2 * id];
+            nb = rec[2 * id + 1];
+        }
+        const bool live = head + lane < cnt;
+        if (!live) { ea = make_float4(0.f, 0.f, 0.f, 0.f); eb = make_float4(0.f, -INFINITY, 0.f, 0.f); }   // idle lane: alpha = 0
+        const int tier = live ? row_tier(ea.z, eb.y, eb.z) : 0;
+        const bool exact = tier == 2;
+        const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
+        if (ANY4) fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc, __any(tier == 1), tier == 1);
+        else fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+        if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
+    }
+
+    // 64x64 transpose-reduction (see the kernel above)
+    if (cnt > 0) {
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i]), __float_as_uint(acc[32 + i]), false, false);
+            acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[i]), __float_as_uint(acc[16 + i]), false, false);
+            acc[i] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        }
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) {
+            const bool up = (lane & d) != 0;
+#pragma unroll
+            for (int i = 0; i < d; ++i) {
+                const float keep = up ? acc[d + i] : acc[i];
+                const float send = up ? acc[i] : acc[d + i];
+                acc[i] = keep + __shfl_xor(send, d);
+            }
+        }
+    }
+    R2_TS_AT(render, 1);
+    if (wd.w == 1u) {   // the tile's only work item: the image pixel itself
+        if (inside) out_color[py * W + px] = acc[0];
+        return;
+    }
+    // partial sums cross XCDs: agent-scope (sc1) stores / loads, the arrival counter bumped after they are acknowledged (see above)
+    __hip_atomic_store(&partial[((size_t)w * 4 + (size_t)blk) * 64 + (size_t)lane], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    uint32_t arrived = 0u;
+    if (lane == 0) arrived = atomicAdd(&tile_done[tile * 4u + (uint32_t)blk], 1u);
+    arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    if (arrived != wd.w - 1u) return;
+    const uint32_t w0 = chunk_base[tile];
+    float C = 0.f;
+    for (uint32_t i = 0; i < wd.w; ++i)   // list order: deterministic image
+        C += __hip_atomic_load(&partial[((size_t)(w0 + i) * 4 + (size_t)blk) * 64 + (size_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (inside) out_color[py * W + px] = C;
+}
+
+// the masked list for chains whose sort does not carry the masks (the general chain: first call of a size, batched views):
+// one workgroup per forward work item, one gather of the record's box per instance
+template <bool MV>
+__global__ void __launch_bounds__(256) raster_mask_fill_kernel(
+    const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile, uint32_t T, const uint32_t *__restrict__ point_list,
+    const float4 *__restrict__ rec, int gx, int gy, uint32_t *__restrict__ masked)
+{
+    const uint32_t w = blockIdx.x;
+    const uint4 wd = work_tile[w];
+    if (w >= chunk_base[T]) return;   // (the empty tiles' items lie behind the real ones)
+    int tx, ty, tv;
+    tile_decode<MV>(wd.x, gx, gy, tx, ty, tv);
+    for (uint32_t k = wd.y + threadIdx.x; k < wd.z; k += 256u) {
+        const uint32_t id = point_list[k];
+        const float4 a = rec[2 * id], b = rec[2 * id + 1];
+        masked[k] = (id << MASK_BITS) | block_mask4(a.x, a.y, b.z, b.w, tx, ty);
+    }
+}
+
 // Debug-mode kernel (pixel-parallel): also tracks n_contrib (RAS/forward.cu:381,391), which only `debug` callers read
 // back.  One lane per pixel, the wave's live entries are compacted per 256-entry batch and broadcast from LDS.
 template <bool MV>
@@ -761,8 +921,27 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
 template <bool MV>
 static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int gx, int gy, uint32_t T,
                        float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s,
-                       char *tf_bin_base, const uint32_t *tf_words)
+                       char *tf_bin_base, const uint32_t *tf_words, bool ids_below_2_28)
 {
+    // round 6: the one-wave kernel (R2_FWD_WAVE=0: the four-wave kernel of rounds 1-5, kept as the A/B reference); ids carry
+    // MASK_BITS of block mask, i.e. view instances below 2^28
+    static const bool wave_on = [] { const char *e = getenv("R2_FWD_WAVE"); return !(e && e[0] == '0'); }();
+    if (fused_combine && !write_ncontrib && im.NW > 0 && wave_on && ids_below_2_28) {
+        const uint32_t *masked = b.masked;
+        if (tf_bin_base == nullptr)   // this chain's sort did not carry the masks
+            raster_mask_fill_kernel<MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(im.chunk_base, im.work_tile, T, b.point_list, g.rec,
+                                                                                    gx, gy, b.masked);
+        const unsigned grid = (unsigned)((im.NW + 7) / 8) * 32u;   // 8 work items x 4 blocks per group of 32 workgroups
+        if (any_thin)
+            raster_render_forward_wave_kernel<true, MV><<<dim3(grid), dim3(64), 0, s>>>(
+                im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles, tf_bin_base, tf_words);
+        else
+            raster_render_forward_wave_kernel<false, MV><<<dim3(grid), dim3(64), 0, s>>>(
+                im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                fill_tiles, tf_bin_base, tf_words);
+        return;
+    }
     if (fused_combine && !write_ncontrib && im.NW > 0) {
         // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
         if (any_thin)
@@ -796,12 +975,13 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
 
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
-                                 hipStream_t s, char *tf_bin_base, const uint32_t *tf_words)
+                                 hipStream_t s, char *tf_bin_base, const uint32_t *tf_words, size_t view_instances)
 {
+    const bool ids28 = view_instances < ((size_t)1 << (32 - MASK_BITS));
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy * (uint32_t)V;   // the views' tile grids, stacked
-    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words);
-    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words);
+    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words, ids28);
+    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words, ids28);
     return 0;
 }
 

@@ -71,6 +71,26 @@ __device__ __forceinline__ bool block_live(float px, float py, float hx, float h
     return (px - hx <= x0 + (n - 1.0f)) && (px + hx >= x0) && (py - hy <= y0 + (n - 1.0f)) && (py + hy >= y0);
 }
 
+// the four 8x8 blocks of tile (tx, ty) that the bounding box touches, as a mask: bit q = block (q % 2, q / 2).  Evaluated ONCE per
+// (tile, Gaussian) instance where the instance is emitted (round 6: the tile-first scatter kernel holds the Gaussian's record in
+// registers anyway) and carried through the per-tile sort in the low bits of the id word, so that the render kernels -- forward and
+// backward -- read a block's live entries off the sorted list instead of gathering every record to test it again.
+__device__ __forceinline__ uint32_t block_mask4(float px, float py, float hx, float hy, int tx, int ty)
+{
+    const float x0 = (float)(tx * TILE2D), y0 = (float)(ty * TILE2D);
+    uint32_t m = 0u;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        if (block_live(px, py, hx, hy, x0 + (float)((q & 1) * SUB2D), y0 + (float)((q >> 1) * SUB2D), (float)SUB2D)) m |= 1u << q;
+    return m;
+}
+constexpr int MASK_BITS = 4;   // masked list entry = id << MASK_BITS | block mask (ids below 2^28)
+// number of set bits of a ballot below this lane (v_mbcnt: no 64-bit lane mask to keep in registers)
+__device__ __forceinline__ uint32_t ballot_rank(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
 // (An exact second stage -- does the ELLIPSE {alpha >= 1e-5}, not its bounding box, reach the block? 40.5 % instead of 46 %
 // of the (entry, block) pairs -- was built and measured in round 2: parity green, forward 47.5 -> 50.9 us (the test costs more
 // than the dropped entries save), backward unchanged (its rounds are quantised: 118 or 104 items per chunk are both 2 rounds).)
@@ -177,6 +197,7 @@ struct RasterBinning {
     uint32_t *tiles_unsorted; // [R]  tile id of every instance, emitted Gaussian by Gaussian in depth order
     uint32_t *tiles;          // [R]  tile id of every SORTED instance (written by the multi-pass sort, or filled from the
                               //      ranges at the start of the backward when the single-pass sort skipped the key scatter)
+    uint32_t *masked;         // [R]  round 6: point_list[k] << MASK_BITS | block_mask4 of instance k (what the render kernels read)
     uint32_t *vals_unsorted;  // [R]  Gaussian id of every instance (emission order)
     uint32_t *inv;            // [R]  sorted position of emission index u (inverse permutation of the tile sort; kept for
                               //      introspection -- the backward recomputes emission indices arithmetically)
@@ -197,6 +218,7 @@ struct RasterBinning {
         // else is scratch of one side only.
         s.point_list = b.take<uint32_t>(R);
         s.tiles = b.take<uint32_t>(R);
+        s.masked = b.take<uint32_t>(R);
         s.tiles_unsorted = b.take<uint32_t>(R);
         s.vals_unsorted = b.take<uint32_t>(R);
         s.inv = b.take<uint32_t>(R);
@@ -212,6 +234,10 @@ struct RasterBinning {
 __host__ __device__ __forceinline__ uint32_t *binning_tiles_ptr(char *base, size_t R)
 {
     return reinterpret_cast<uint32_t *>(base + (((R * sizeof(uint32_t)) + 127) & ~size_t(127)));
+}
+__host__ __device__ __forceinline__ uint32_t *binning_masked_ptr(char *base, size_t R)   // ... and bin.masked, the third array
+{
+    return reinterpret_cast<uint32_t *>(base + 2 * (((R * sizeof(uint32_t)) + 127) & ~size_t(127)));
 }
 
 constexpr uint32_t TF_SMALL_CAP = 1536;     // tile-first: tile lists beyond this many entries get a whole sort workgroup (raster_tilefirst.hip)
@@ -233,7 +259,7 @@ struct RasterImage {
     uint2 *ranges;         // [T]
     uint32_t *chunk_base;  // [T+2] exclusive scan of ceil(len/FWD_CHUNK): first work item of each tile; [T] = total,
                            //       [T+1] = total + empty tiles (appended to the work list when the combine is fused)
-    uint32_t *tile_done;   // [T]  work items of the tile that have stored their partial image (fused combine)
+    uint32_t *tile_done;   // [4T] per (tile, 8x8 block): work items that have stored their partial sums (fused combine)
     uint4 *work_tile;      // [NW]  tile of each forward work item
     float *partial;        // [NW*256] per-work-item partial pixel sums, combined in list order
     uint32_t *partial_last;// [NW*256] debug only: last contributing list position inside the chunk
@@ -252,7 +278,7 @@ struct RasterImage {
         s.NW = R / FWD_CHUNK + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 2);
-        s.tile_done = b.take<uint32_t>(T);
+        s.tile_done = b.take<uint32_t>(4 * T);
         s.work_tile = b.take<uint4>(s.NW);
         s.partial = b.take<float>(s.NW * 256);
         s.partial_last = b.take<uint32_t>(debug ? s.NW * 256 : 0);
@@ -304,7 +330,8 @@ int launch_raster_geom_backward(int P /* per view */, int V, const float *means3
 // tf_words[DW_TOTAL]) -- the binning buffer was carved with a predicted count, the backward will carve it with the true one
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
-                                 hipStream_t s, char *tf_bin_base = nullptr, const uint32_t *tf_words = nullptr);
+                                 hipStream_t s, char *tf_bin_base = nullptr, const uint32_t *tf_words = nullptr,
+                                 size_t view_instances = 0 /* P x V: ids of the masked list */);
 // raster_tilefirst.hip
 int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer,
                              void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height,

@@ -81,7 +81,7 @@ constexpr uint32_t TFS_SERVICE = 3;
 template <bool SL /* depth slabs in use */>
 __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
     int P, uint32_t per_wg, uint32_t pthreads, int gx, uint32_t T /* LISTS = tiles x slabs */, const TFSlabs slabs,
-    const uint32_t *__restrict__ rects,
+    const uint32_t *__restrict__ rects, const float4 *__restrict__ rec,
     const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff,
     const uint32_t *__restrict__ wgmm, uint32_t producers, const TFCounters *__restrict__ ctr, uint32_t *__restrict__ words,
     uint32_t *__restrict__ mailbox, uint32_t seq, uint32_t cap, uint2 *__restrict__ pairs, WorkListOut wo,
@@ -183,12 +183,15 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
     constexpr int NI = (int)TF_PER_THREAD_MAX;
     const uint32_t g0 = wg * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
     uint32_t g_idx[NI], g_tt[NI], g_rect[NI], g_key[NI];
+    float4 g_box[NI];   // {px, py, hx, hy}: the bounding box of alpha >= 1e-5, for the instances' block masks (block_mask4)
 #pragma unroll
     for (int it = 0; it < NI; ++it) {
         g_idx[it] = g0 + (uint32_t)it * pthreads + (uint32_t)tid;
         const bool own = (uint32_t)tid < pthreads && g_idx[it] < g1;
         const uint32_t idc = min(g_idx[it], (uint32_t)P - 1u);
         g_tt[it] = tiles_touched[idc]; g_rect[it] = rects[idc]; g_key[it] = depth_key[idc];
+        const float4 ra = rec[2u * idc], rb = rec[2u * idc + 1u];   // (culled Gaussians: stale words, never used -- g_tt is 0)
+        g_box[it] = make_float4(ra.x, ra.y, rb.z, rb.w);
         g_tt[it] = own ? g_tt[it] : 0u;
     }
     // ---- exclusive scan of the tile counts (every workgroup for itself: <= 16 KB, cheaper than a launch boundary)
@@ -237,11 +240,13 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
             const uint32_t rect = g_rect[it], key = g_key[it];
             const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
             const uint32_t nsl = SL ? slabs.n : 1u, sl = SL ? tf_slab_of(key, slabs) : 0u;
+            // second word: id << MASK_BITS | the instance's block mask -- sorting on (key, word) is sorting on (key, id)
+            const uint32_t idw = g_idx[it] << MASK_BITS;
             for (uint32_t r = 0; r < h; ++r) {
                 const uint32_t row = ((y0 + r) * (uint32_t)gx + x0) * nsl + sl;
                 for (uint32_t c = 0; c < w; ++c) {
                     const uint32_t pos = atomicAdd(&s_pos[row + c * nsl], 1u);
-                    pairs[pos] = make_uint2(key, g_idx[it]);
+                    pairs[pos] = make_uint2(key, idw | block_mask4(g_box[it].x, g_box[it].y, g_box[it].z, g_box[it].w, (int)(x0 + c), (int)(y0 + r)));
                 }
             }
         }
@@ -275,7 +280,8 @@ __device__ __forceinline__ void tf_group_minmax(uint32_t &kmin, uint32_t &kmax, 
 template <int NT, uint32_t PER, uint32_t BINS>
 __device__ __forceinline__ void tf_sort_group(unsigned long long (&mine)[PER], unsigned long long *s_a, uint32_t *s_bin,
                                               uint32_t *s_wsum /* workgroup's, per wave */, int gtid, int lane, int wave, int w0,
-                                              uint32_t cnt, uint32_t kmin, uint32_t kmax, uint32_t *__restrict__ dst)
+                                              uint32_t cnt, uint32_t kmin, uint32_t kmax, uint32_t *__restrict__ dst,
+                                              uint32_t *__restrict__ dst_masked)
 {
     R2_TS_AT(tilefirst, 6);
     for (uint32_t i = gtid; i <= BINS; i += NT) s_bin[i] = 0u;
@@ -350,7 +356,11 @@ __device__ __forceinline__ void tf_sort_group(unsigned long long (&mine)[PER], u
 #pragma unroll
     for (uint32_t u = 0; u < PER; ++u) {
         const uint32_t j = u * NT + (uint32_t)gtid;
-        if (j < cnt) dst[j] = s_out[j];
+        if (j < cnt) {
+            const uint32_t v = s_out[j];
+            dst[j] = v >> MASK_BITS;   // point_list: the reference's, bit for bit
+            dst_masked[j] = v;         // the render kernels' list: the same ids with their block masks
+        }
     }
 }
 
@@ -364,6 +374,8 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
     const uint32_t p = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t *__restrict__ tile_count = ctr->tile_count;
+    // the masked list sits behind point_list and the tile ids, where the TRUE instance count puts it (RasterBinning::carve)
+    uint32_t *__restrict__ masked = binning_masked_ptr(reinterpret_cast<char *>(point_list), (size_t)words[DW_TOTAL]);
     R2_TS_AT(tilefirst, 3);
     // the scalar counters have been read for the last time by the scatter kernel: ready for the next call -- unless the state was
     // too small for this one, in which case the scatter kernel will want them again
@@ -406,7 +418,8 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
             }
         }
         tf_group_minmax<256>(kmin, kmax, s_mm, lane, wave, w0);
-        tf_sort_group<256, TFK_SMALL_PER, TFK_SMALL_BINS>(mine, s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, point_list + start);
+        tf_sort_group<256, TFK_SMALL_PER, TFK_SMALL_BINS>(mine, s_a, s_bin, s_wsum, gtid, lane, wave, w0, n, kmin, kmax, point_list + start,
+                                                          masked + start);
         R2_TS_AT(tilefirst, 4);
         return;
     }
@@ -418,6 +431,7 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
     if (part == 0u && tid == 0) tile_count[tile] = 0u;
     const uint2 *__restrict__ src = pairs + start;
     uint32_t *__restrict__ dst = point_list + start;
+    uint32_t *__restrict__ dst_masked = masked + start;
     uint32_t cnt = n, out_off = 0u;
     uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
     unsigned long long mine[TFK_BIG_PER];
@@ -549,7 +563,8 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
                     const uint2 o = src[j];
                     if (s_coarse[coarse_of(o.x)] == part && tf_pack(o) < me) ++r;
                 }
-                dst[out_off + r] = e.y;
+                dst[out_off + r] = e.y >> MASK_BITS;
+                dst_masked[out_off + r] = e.y;
             }
             return;
         }
@@ -561,7 +576,8 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
         }
         __syncthreads();   // everybody holds its entries: s_a may be overwritten by the placement
     }
-    tf_sort_group<TFK_THREADS, TFK_BIG_PER, TFK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, dst + out_off);
+    tf_sort_group<TFK_THREADS, TFK_BIG_PER, TFK_BIG_BINS>(mine, s_a, s_bin, s_wsum, tid, lane, wave, 0, cnt, kmin, kmax, dst + out_off,
+                                                          dst_masked + out_off);
     R2_TS_AT(tilefirst, 4);
 }
 
@@ -784,7 +800,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW};
 #define R2_TF_SCATTER(SLB)                                                                                                        \
             raster_tf_scatter_kernel<SLB><<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), TL * sizeof(uint32_t), s>>>(         \
-                P, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
+                P, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.rec, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
                 geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,                                            \
                 (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,   \
                 ws->nparts)
@@ -799,11 +815,11 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
                 (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu)); }
             R2_HIP_TRY(hipGetLastError());
         } else {
-            R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, T * sizeof(uint32_t), s));   // the first render left its arrivals behind
+            R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, 4 * T * sizeof(uint32_t), s));   // the first render left its arrivals behind
         }
         { StageScope t(ST_RAS_RENDER_FWD, s);
         launch_raster_render_forward(geom, bin, img, width, height, 1, out_color, false, bin.tiles, any_thin, true, s,
-                                     reinterpret_cast<char *>(bin.point_list), geom.host_words); }
+                                     reinterpret_cast<char *>(bin.point_list), geom.host_words, (size_t)P); }
         R2_HIP_TRY(hipGetLastError());
         return 0;
     };

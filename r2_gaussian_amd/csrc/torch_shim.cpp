@@ -156,20 +156,24 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> rasterize_gau
 std::tuple<int64_t, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> voxelize_gaussians(
     const Tensor &means3D, const Tensor &opacity, const Tensor &scales, const Tensor &rotations, double scale_modifier,
     const Tensor &cov3D_precomp, int64_t nx, int64_t ny, int64_t nz, double sx, double sy, double sz, double cx, double cy,
-    double cz, bool prefiltered, bool debug, int64_t stream)
+    double cz, bool prefiltered, bool debug, int64_t stream, int64_t tile_x0, int64_t tile_x1)
 {
+    // tile layers [tile_x0, tile_x1) along x of the (nx, ny, nz) grid: the whole grid for the reference's call, one x-slab for the
+    // sharded query (r2_voxel_forward_slab); the volume returned is the slab's block
     if (means3D.dim() != 2 || means3D.size(1) != 3) throw std::runtime_error("means3D must have dimensions (num_points, 3)");
     require_gpu(means3D, "means3D");
+    const int64_t nxs = std::min<int64_t>(tile_x1 * 8, nx) - tile_x0 * 8;
+    if (tile_x0 < 0 || nxs <= 0) throw std::runtime_error("voxelize_gaussians: empty or invalid x-slab");
     const c10::Device dev = means3D.device();
     const int64_t P = means3D.size(0);
     const auto bytes = torch::TensorOptions().dtype(torch::kUInt8).device(dev);
     Tensor geom = torch::empty({0}, bytes), binning = torch::empty({0}, bytes), img = torch::empty({0}, bytes);
     if (P == 0) {
         const auto io = means3D.options().dtype(torch::kInt);
-        return {0, torch::zeros({nx, ny, nz}, means3D.options().dtype(torch::kFloat)), torch::zeros({0}, io), torch::zeros({0}, io),
+        return {0, torch::zeros({nxs, ny, nz}, means3D.options().dtype(torch::kFloat)), torch::zeros({0}, io), torch::zeros({0}, io),
                 torch::zeros({0}, io), geom, binning, img};
     }
-    Tensor out = torch::empty({nx, ny, nz}, means3D.options().dtype(torch::kFloat));   // written in full by the combine kernel
+    Tensor out = torch::empty({nxs, ny, nz}, means3D.options().dtype(torch::kFloat));   // written in full by the combine kernel
     Tensor radii = torch::empty({3, P}, means3D.options().dtype(torch::kInt));         // written in full by the preprocess kernel
     const Tensor m3 = dev_f32(means3D, dev), op = dev_f32(opacity, dev), sc = dev_f32(scales, dev), ro = dev_f32(rotations, dev),
                  cp = dev_f32(cov3D_precomp, dev);
@@ -178,10 +182,10 @@ std::tuple<int64_t, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> voxe
     {
         c10::DeviceGuard guard(dev);
         py::gil_scoped_release nogil;
-        rc = r2_voxel_forward(resize_state, &geom, resize_state, &binning, resize_state, &img, (int)P, (int)nx, (int)ny, (int)nz,
-                              (float)sx, (float)sy, (float)sz, (float)cx, (float)cy, (float)cz, fptr(m3), fptr(op), fptr(sc),
-                              (float)scale_modifier, fptr(ro), fptr(cp), prefiltered ? 1 : 0, out.data_ptr<float>(), r0, r0 + P,
-                              r0 + 2 * P, debug ? 1 : 0, reinterpret_cast<void *>(stream));
+        rc = r2_voxel_forward_slab(resize_state, &geom, resize_state, &binning, resize_state, &img, (int)P, (int)nx, (int)ny, (int)nz,
+                                   (float)sx, (float)sy, (float)sz, (float)cx, (float)cy, (float)cz, (int)tile_x0, (int)tile_x1, fptr(m3),
+                                   fptr(op), fptr(sc), (float)scale_modifier, fptr(ro), fptr(cp), prefiltered ? 1 : 0,
+                                   out.data_ptr<float>(), r0, r0 + P, r0 + 2 * P, debug ? 1 : 0, reinterpret_cast<void *>(stream));
     }
     if (rc < 0) fail("r2_voxel_forward", rc);
     return {rc, out, radii[0], radii[1], radii[2], geom, binning, img};
@@ -192,7 +196,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> voxelize_gaussians_backward(
     const Tensor &means3D, const Tensor &radii_x, const Tensor &radii_y, const Tensor &radii_z, const Tensor &scales,
     const Tensor &rotations, double scale_modifier, const Tensor &cov3D_precomp, const Tensor &dL_dout, const Tensor &geomBuffer,
     int64_t R, const Tensor &binningBuffer, const Tensor &imageBuffer, int64_t nx, int64_t ny, int64_t nz, double sx, double sy,
-    double sz, double cx, double cy, double cz, bool debug, int64_t stream)
+    double sz, double cx, double cy, double cz, bool debug, int64_t stream, int64_t tile_x0, int64_t tile_x1)
 {
     require_gpu(means3D, "means3D");
     const c10::Device dev = means3D.device();
@@ -214,13 +218,13 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> voxelize_gaussians_backward(
         {
             c10::DeviceGuard guard(dev);
             py::gil_scoped_release nogil;
-            rc = r2_voxel_backward((int)P, (int)R, (int)nx, (int)ny, (int)nz, (float)sx, (float)sy, (float)sz, (float)cx, (float)cy,
-                                   (float)cz, fptr(m3), fptr(sc), (float)scale_modifier, fptr(ro), fptr(cp), rx.data_ptr<int>(),
-                                   ry.data_ptr<int>(), rz.data_ptr<int>(), bptr(geomBuffer), bptr(binningBuffer),
-                                   bptr(imageBuffer), fptr(g), dL_dnorm.data_ptr<float>(), dL_dconic3D.data_ptr<float>(),
-                                   dL_dopacity.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
-                                   dL_dscales.data_ptr<float>(), dL_drot.data_ptr<float>(), debug ? 1 : 0,
-                                   reinterpret_cast<void *>(stream));
+            rc = r2_voxel_backward_slab((int)P, (int)R, (int)nx, (int)ny, (int)nz, (float)sx, (float)sy, (float)sz, (float)cx, (float)cy,
+                                        (float)cz, (int)tile_x0, (int)tile_x1, fptr(m3), fptr(sc), (float)scale_modifier, fptr(ro),
+                                        fptr(cp), rx.data_ptr<int>(), ry.data_ptr<int>(), rz.data_ptr<int>(), bptr(geomBuffer),
+                                        bptr(binningBuffer), bptr(imageBuffer), fptr(g), dL_dnorm.data_ptr<float>(),
+                                        dL_dconic3D.data_ptr<float>(), dL_dopacity.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
+                                        dL_dcov3D.data_ptr<float>(), dL_dscales.data_ptr<float>(), dL_drot.data_ptr<float>(),
+                                        debug ? 1 : 0, reinterpret_cast<void *>(stream));
         }
         if (rc < 0) fail("r2_voxel_backward", rc);
     }

@@ -4,16 +4,27 @@
 
 using namespace r2;
 
-static VoxelGrid make_grid(int nx, int ny, int nz, float sx, float sy, float sz, float cx, float cy, float cz)
+// tile layers [tile_x0, tile_x1) along x of the full grid (an ordinary call: all of them, tile_x1 < 0)
+static VoxelGrid make_grid(int nx, int ny, int nz, float sx, float sy, float sz, float cx, float cy, float cz, int tile_x0 = 0,
+                           int tile_x1 = -1)
 {
     VoxelGrid v;
-    v.nx = nx; v.ny = ny; v.nz = nz;
+    v.ny = ny; v.nz = nz;
     v.sx = sx; v.sy = sy; v.sz = sz;
     v.cx = cx; v.cy = cy; v.cz = cz;
-    v.gx = (nx + TILE3D - 1) / TILE3D;
+    v.fnx = nx;
+    v.fgx = (nx + TILE3D - 1) / TILE3D;
+    if (tile_x1 < 0) tile_x1 = v.fgx;
+    v.gx = tile_x1 - tile_x0;
+    v.ox = tile_x0 * TILE3D;
+    v.nx = (tile_x1 * TILE3D < nx ? tile_x1 * TILE3D : nx) - v.ox;   // the last layer of the full grid may be ragged
     v.gy = (ny + TILE3D - 1) / TILE3D;
     v.gz = (nz + TILE3D - 1) / TILE3D;
     return v;
+}
+static bool slab_ok(int nx, int tile_x0, int tile_x1)
+{
+    return tile_x0 >= 0 && tile_x1 > tile_x0 && tile_x1 <= (nx + TILE3D - 1) / TILE3D;
 }
 
 extern "C" int r2_voxel_forward(
@@ -24,16 +35,30 @@ extern "C" int r2_voxel_forward(
     const float *cov3D_precomp, int prefiltered, float *out_volume, int *radii_x, int *radii_y, int *radii_z,
     int debug, void *stream)
 {
+    return r2_voxel_forward_slab(geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user, P, nVoxel_x,
+                                 nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, 0,
+                                 nVoxel_x > 0 ? (nVoxel_x + TILE3D - 1) / TILE3D : 1, means3D, opacities, scales, scale_modifier,
+                                 rotations, cov3D_precomp, prefiltered, out_volume, radii_x, radii_y, radii_z, debug, stream);
+}
+
+extern "C" int r2_voxel_forward_slab(
+    r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer, void *binning_user,
+    r2_alloc_fn imageBuffer, void *image_user, int P, int nVoxel_x, int nVoxel_y, int nVoxel_z, float sVoxel_x,
+    float sVoxel_y, float sVoxel_z, float center_x, float center_y, float center_z, int tile_x0, int tile_x1,
+    const float *means3D, const float *opacities, const float *scales, float scale_modifier, const float *rotations,
+    const float *cov3D_precomp, int prefiltered, float *out_volume, int *radii_x, int *radii_y, int *radii_z,
+    int debug, void *stream)
+{
     (void)prefiltered;
     hipStream_t s = (hipStream_t)stream;
     host_mark_forward_begin();
     if (P < 0 || nVoxel_x <= 0 || nVoxel_y <= 0 || nVoxel_z <= 0 || !geometryBuffer || !binningBuffer ||
-        !imageBuffer || !out_volume) {
+        !imageBuffer || !out_volume || !slab_ok(nVoxel_x, tile_x0, tile_x1)) {
         set_error("r2_voxel_forward: invalid argument");
         return R2_ERR_INVALID;
     }
-    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
-    const size_t V = (size_t)nVoxel_x * nVoxel_y * nVoxel_z;
+    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, tile_x0, tile_x1);
+    const size_t V = (size_t)v.nx * nVoxel_y * nVoxel_z;   // the output block: the slab's voxels
     const size_t T = (size_t)v.gx * v.gy * v.gz;
     if (P == 0) {
         R2_HIP_TRY(hipMemsetAsync(out_volume, 0, V * sizeof(float), s));
@@ -145,13 +170,13 @@ extern "C" int r2_voxel_forward(
     const size_t R = num_rendered;
 
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
-    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, debug != 0).bytes, image_user);
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, debug != 0, vox_chunk_for(v.gy, v.gz)).bytes, image_user);
     if (!bchunk || !ichunk) {
         set_error("r2_voxel_forward: binning/image allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
-    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, debug != 0, vox_chunk_for(v.gy, v.gz));
     const uint32_t *tile_counts = nullptr;
     bool work_built = false;   // ranges + work list already produced by the sort's last kernel
     bool ranges_zeroed = false;   // img.ranges zero-filled by the duplicate kernel
@@ -166,7 +191,7 @@ extern "C" int r2_voxel_forward(
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)
         { StageScope t(ST_VOX_SORT, s);
         if (sort_is_single_pass(bit)) {   // block 0 of the sort's last kernel also builds tile ranges + work list
-            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(R), nullptr,
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(v.gy, v.gz), nullptr,
                                  voxel_short_list_min(debug != 0)};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo);   // inv: introspection only
@@ -183,12 +208,12 @@ extern "C" int r2_voxel_forward(
     if (work_built) {
         // nothing to do
     } else if (tile_counts) {
-        launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(R), img.ranges, img.chunk_base, img.work_tile, s,
+        launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(v.gy, v.gz), img.ranges, img.chunk_base, img.work_tile, s,
                                voxel_short_list_min(debug != 0));
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s, ranges_zeroed);
         if (rc) return rc;
-        launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(R), img.chunk_base, img.work_tile, img.work_temp, s,
+        launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(v.gy, v.gz), img.chunk_base, img.work_tile, img.work_temp, s,
                           voxel_short_list_min(debug != 0));
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");
@@ -208,16 +233,30 @@ extern "C" int r2_voxel_backward(
     float *dL_dconic3D, float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
     int debug, void *stream)
 {
+    return r2_voxel_backward_slab(P, R, nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, 0,
+                                  nVoxel_x > 0 ? (nVoxel_x + TILE3D - 1) / TILE3D : 1, means3D, scales, scale_modifier, rotations,
+                                  cov3D_precomp, radii_x, radii_y, radii_z, geom_buffer, binning_buffer, img_buffer, dL_dvol,
+                                  dL_dmean3D_norm, dL_dconic3D, dL_dopacity, dL_dmean3D, dL_dcov3D, dL_dscale, dL_drot, debug, stream);
+}
+
+extern "C" int r2_voxel_backward_slab(
+    int P, int R, int nVoxel_x, int nVoxel_y, int nVoxel_z, float sVoxel_x, float sVoxel_y, float sVoxel_z,
+    float center_x, float center_y, float center_z, int tile_x0, int tile_x1, const float *means3D, const float *scales,
+    float scale_modifier, const float *rotations, const float *cov3D_precomp, const int *radii_x, const int *radii_y,
+    const int *radii_z, char *geom_buffer, char *binning_buffer, char *img_buffer, const float *dL_dvol, float *dL_dmean3D_norm,
+    float *dL_dconic3D, float *dL_dopacity, float *dL_dmean3D, float *dL_dcov3D, float *dL_dscale, float *dL_drot,
+    int debug, void *stream)
+{
     (void)means3D;
     hipStream_t s = (hipStream_t)stream;
     if (P == 0) return 0;
     if (P < 0 || R < 0 || !radii_x || !radii_y || !radii_z || !geom_buffer || (R > 0 && !binning_buffer) || !dL_dvol ||
-        !dL_dmean3D_norm || !dL_dconic3D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D ||
-        (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
+        !dL_dmean3D_norm || !dL_dconic3D || !dL_dopacity || !dL_dmean3D || !dL_dcov3D || nVoxel_x <= 0 ||
+        !slab_ok(nVoxel_x, tile_x0, tile_x1) || (!cov3D_precomp && (!scales || !rotations || !dL_dscale || !dL_drot))) {
         set_error("r2_voxel_backward: invalid argument");
         return R2_ERR_INVALID;
     }
-    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z);
+    const VoxelGrid v = make_grid(nVoxel_x, nVoxel_y, nVoxel_z, sVoxel_x, sVoxel_y, sVoxel_z, center_x, center_y, center_z, tile_x0, tile_x1);
     const VoxelGeom geom = VoxelGeom::carve(geom_buffer, P);
     const VoxelBinning bin = VoxelBinning::carve(binning_buffer, (size_t)R);
     const size_t T = (size_t)v.gx * v.gy * v.gz;
@@ -226,7 +265,7 @@ extern "C" int r2_voxel_backward(
             set_error("r2_voxel_backward: image state required");
             return R2_ERR_INVALID;
         }
-        const VoxelImage img = VoxelImage::carve(img_buffer, T, (size_t)v.nx * v.ny * v.nz, (size_t)R, false);
+        const VoxelImage img = VoxelImage::carve(img_buffer, T, (size_t)v.nx * v.ny * v.nz, (size_t)R, false, vox_chunk_for(v.gy, v.gz));
         fill_tiles_from_ranges(img.ranges, T, bin.tiles, s);
     }
     // patches (the TV regulariser): nearly every gradient row is a zero row, and the zero-fill rides along with the render backward
@@ -252,7 +291,7 @@ extern "C" long long r2_voxel_state_offset(int which, int P, long long R, int nx
     const VoxelGrid v = make_grid(nx, ny, nz, 1, 1, 1, 0, 0, 0);
     const VoxelGeom g = VoxelGeom::carve(base, P);
     const VoxelBinning b = VoxelBinning::carve(base, (size_t)R);
-    const VoxelImage im = VoxelImage::carve(base, (size_t)v.gx * v.gy * v.gz, (size_t)nx * ny * nz, (size_t)R, true);
+    const VoxelImage im = VoxelImage::carve(base, (size_t)v.gx * v.gy * v.gz, (size_t)nx * ny * nz, (size_t)R, true, vox_chunk_for(v.gy, v.gz));
     const char *p = nullptr;
     int buf = -1;
     switch (which) {

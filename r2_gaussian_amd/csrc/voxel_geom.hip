@@ -52,6 +52,16 @@ __device__ __forceinline__ float3 voxel_position(float3 p, const VoxelGrid &v, f
 {
     return make_float3((p.x - v.cx + v.sx / 2) / dvx, (p.y - v.cy + v.sy / 2) / dvy, (p.z - v.cz + v.sz / 2) / dvz);
 }
+// An x-slab call (r2_voxel_forward_slab) runs the FULL grid's arithmetic -- (sx, cx, fnx, fgx) are the full volume's, so positions,
+// radii and the tile cube come out bit for bit as in the unsharded call -- and then keeps the slab's tile layers only, renumbered from
+// 0: everything downstream (emission, lists, ranges, the backward's emission index) sees a grid of v.gx x gy x gz tiles.  For an
+// ordinary call ox = 0 and gx = fgx: nothing is clipped.
+__device__ __forceinline__ void slab_clip(const VoxelGrid &v, int3 &lo, int3 &hi)
+{
+    const int t0 = v.ox / TILE3D;
+    lo.x = min(max(lo.x, t0), t0 + v.gx) - t0;
+    hi.x = min(max(hi.x, t0), t0 + v.gx) - t0;
+}
 
 // The preprocess in two parts (one after the other in voxel_preprocess_kernel; as two kernels in the stick-first chain,
 // voxel_sticks.hip, where the second one runs while the host sizes the binning state).
@@ -72,7 +82,7 @@ __device__ __forceinline__ uint32_t voxel_cull_one(
     radii_y[idx] = 0;
     radii_z[idx] = 0;
     tiles_touched[idx] = 0;
-    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    const float dvx = v.sx / (float)v.fnx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
     const float3 p = make_float3(means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2]);
     // low sort word of the reference: the raw bits of world z ("just give a value", VOX/forward.cu:166; as
     // unsigned ints, negative z sorts after positive -- quirk Q10).  Culled Gaussians emit nothing, so their
@@ -82,11 +92,12 @@ __device__ __forceinline__ uint32_t voxel_cull_one(
         const float ms = fmaxf(fmaxf(scales[3 * idx], scales[3 * idx + 1]), scales[3 * idx + 2]);
         const float3 rd = make_float3(ceilf((3.f * ms) / dvx), ceilf((3.f * ms) / dvy), ceilf((3.f * ms) / dvz));
         const float3 q = voxel_position(p, v, dvx, dvy, dvz);
-        if (q.x + rd.x < 0 || q.y + rd.y < 0 || q.z + rd.z < 0 || q.x - rd.x > (float)v.nx || q.y - rd.y > (float)v.ny ||
+        if (q.x + rd.x < 0 || q.y + rd.y < 0 || q.z + rd.z < 0 || q.x - rd.x > (float)v.fnx || q.y - rd.y > (float)v.ny ||
             q.z - rd.z > (float)v.nz)
             return 0u;
         int3 l0, h0;
-        tile_cube(q, rd, v.gx, v.gy, v.gz, l0, h0);
+        tile_cube(q, rd, v.fgx, v.gy, v.gz, l0, h0);
+        slab_clip(v, l0, h0);
         if ((h0.x - l0.x) * (h0.y - l0.y) * (h0.z - l0.z) == 0) return 0u;
     }
 
@@ -108,10 +119,11 @@ __device__ __forceinline__ uint32_t voxel_cull_one(
     const float3 rad = make_float3(ceilf((3.f * max_scale) / dvx), ceilf((3.f * max_scale) / dvy),
                                    ceilf((3.f * max_scale) / dvz));
     const float3 pv = voxel_position(p, v, dvx, dvy, dvz);
-    if (pv.x + rad.x < 0 || pv.y + rad.y < 0 || pv.z + rad.z < 0 || pv.x - rad.x > (float)v.nx ||
+    if (pv.x + rad.x < 0 || pv.y + rad.y < 0 || pv.z + rad.z < 0 || pv.x - rad.x > (float)v.fnx ||
         pv.y - rad.y > (float)v.ny || pv.z - rad.z > (float)v.nz)
         return 0u;
-    tile_cube(pv, rad, v.gx, v.gy, v.gz, lo, hi);
+    tile_cube(pv, rad, v.fgx, v.gy, v.gz, lo, hi);
+    slab_clip(v, lo, hi);   // (a Gaussian without a tile in this slab is culled here: radii 0, no instances)
     const uint32_t n = (uint32_t)(hi.x - lo.x) * (uint32_t)(hi.y - lo.y) * (uint32_t)(hi.z - lo.z);
     if (n == 0) return 0u;
 
@@ -365,7 +377,7 @@ __global__ void __launch_bounds__(VS_PRODUCER) voxel_scan_records_kernel(
     }
     const uint32_t wg = blockIdx.x - nscan;   // the producers' mapping (vs_grid): one workgroup per CU
     const uint32_t g0 = wg * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);
-    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    const float dvx = v.sx / (float)v.fnx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
     for (uint32_t it = 0; it < ni; ++it) {
         const uint32_t idx = g0 + it * VS_PRODUCER + threadIdx.x;
         if (idx >= g1 || tiles_touched[idx] == 0u) continue;
@@ -658,7 +670,7 @@ __global__ void __launch_bounds__(256) voxel_geom_backward_kernel(
     const int idx = (int)order[j];
     if ((uint32_t)idx >= (uint32_t)P) return;   // nothing visible at all: the list was never written (every row is a zero row)
     if (!(radii_x[idx] > 0) || !(radii_y[idx] > 0) || !(radii_z[idx] > 0)) return;
-    const float dvx = v.sx / (float)v.nx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
+    const float dvx = v.sx / (float)v.fnx, dvy = v.sy / (float)v.ny, dvz = v.sz / (float)v.nz;
 
     // ---- 1. moments: S0, (Sx,Sy,Sz), (Sxx,Sxy,Sxz,Syy,Syz,Szz)
     const uint32_t first = first_inst[idx], ninst = tiles_touched[idx];

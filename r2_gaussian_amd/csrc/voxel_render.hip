@@ -180,8 +180,10 @@ __device__ __forceinline__ void vfwd_item_body(
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = half * 4 + wave;
-    const float xc = (float)(tx * TILE3D + slab) + 0.5f, y0 = (float)(ty * TILE3D), z0 = (float)(tz * TILE3D);
-    const float xc0 = (float)(tx * TILE3D + half * 4) + 0.5f;   // the workgroup's first slab
+    // (v.ox: x offset of an x-slab call inside the full grid, 0 otherwise -- the arithmetic sees the FULL grid's voxel coordinates,
+    //  only the output index is slab-local: voxel_state.hpp)
+    const float xc = (float)(tx * TILE3D + v.ox + slab) + 0.5f, y0 = (float)(ty * TILE3D), z0 = (float)(tz * TILE3D);
+    const float xc0 = (float)(tx * TILE3D + v.ox + half * 4) + 0.5f;   // the workgroup's first slab
 
     // the workgroup stages VFWD_BATCH entries at a time (one per thread); every wave then picks the entries whose
     // bounding box touches ITS x-slab
@@ -201,7 +203,7 @@ __device__ __forceinline__ void vfwd_item_body(
         }
         __syncthreads();
         for (int sl = wave; sl < TILE3D; sl += 4) {
-            const float xs = (float)(tx * TILE3D + sl) + 0.5f;
+            const float xs = (float)(tx * TILE3D + v.ox + sl) + 0.5f;
             float sum = 0.f;
             for (int j = 0; j < n; ++j) {
                 const float4 p = s0[j], h = s3[j];
@@ -425,7 +427,7 @@ __device__ __forceinline__ void vfwd_short_body(
     if (lane < n) {
 #pragma unroll
         for (int sl = 0; sl < TILE3D; ++sl)
-            if (slab_live(ep.x, ep.y, ep.z, eh, er.w, (float)(tx * TILE3D + sl) + 0.5f, y0, z0)) mask8 |= 1u << sl;
+            if (slab_live(ep.x, ep.y, ep.z, eh, er.w, (float)(tx * TILE3D + v.ox + sl) + 0.5f, y0, z0)) mask8 |= 1u << sl;
     }
     float sum[TILE3D];
 #pragma unroll
@@ -444,7 +446,7 @@ __device__ __forceinline__ void vfwd_short_body(
 #pragma unroll
         for (int sl = 0; sl < TILE3D; ++sl) {
             if (!((m >> sl) & 1u)) continue;   // wave-uniform (scalar)
-            const float xs = (float)(tx * TILE3D + sl) + 0.5f;
+            const float xs = (float)(tx * TILE3D + v.ox + sl) + 0.5f;
             const float dx = p.x - xs;
             // same expression tree as the item kernel's voxel-parallel paths
             const float pl = dx * (q.x * dx + kx) + kyz;
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(512) voxel_render_forward_debug_kernel(
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x;
     // lane = y*8+z, wave = x: z-fastest, see the header comment
-    const float fx = (float)(tx * TILE3D + (tid >> 6)) + 0.5f, fy = (float)(ty * TILE3D + ((tid >> 3) & 7)) + 0.5f,
+    const float fx = (float)(tx * TILE3D + v.ox + (tid >> 6)) + 0.5f, fy = (float)(ty * TILE3D + ((tid >> 3) & 7)) + 0.5f,
                 fz = (float)(tz * TILE3D + (tid & 7)) + 0.5f;
 
     __shared__ float4 s0[512];
@@ -752,7 +754,7 @@ __global__ void __launch_bounds__(64) voxel_render_backward_kernel(
         }
         // ---- expand instances into slab items
         const int slot = my_slot - slot0;
-        const float tx0 = (float)((int)(tile % v.gx) * TILE3D), ty0 = (float)((int)((tile / v.gx) % v.gy) * TILE3D),
+        const float tx0 = (float)((int)(tile % v.gx) * TILE3D + v.ox), ty0 = (float)((int)((tile / v.gx) % v.gy) * TILE3D),
                     tz0 = (float)((int)(tile / gxy) * TILE3D);
         uint32_t mask = 0;
         if (mine) {
@@ -791,7 +793,7 @@ __global__ void __launch_bounds__(64) voxel_render_backward_kernel(
             const uint32_t ot = __shfl(tile, owner);   // the owner's tile (all lanes take part in the shuffle)
             if (e < total) {
                 const float4 op = s_p[owner], oq = s_q[owner], orr = s_r[owner];
-                const float ox0 = (float)((int)(ot % v.gx) * TILE3D), oy0 = (float)((int)((ot / v.gx) % v.gy) * TILE3D),
+                const float ox0 = (float)((int)(ot % v.gx) * TILE3D + v.ox), oy0 = (float)((int)((ot / v.gx) % v.gy) * TILE3D),
                             oz0 = (float)((int)(ot / gxy) * TILE3D);
                 slab_moments(op, oq, orr, s_gt + sl_t * VB_GT + sl * 64, ox0 + (float)sl + 0.5f, oy0, oz0, M);
             }

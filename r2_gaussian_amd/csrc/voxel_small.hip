@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
     // short-list kernel's launch.  (ONE item per tile -- no partial sums at all -- was measured: the 128 long-running workgroups
     // took 38 us instead of 23.)
     (void)min_len;
-    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_chunk_for(R), nullptr, 0u,
+    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_chunk_for(gy, gz), nullptr, 0u,
                                                             tmp.cap_work});
 }
 
@@ -315,7 +315,8 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
     const size_t V = (size_t)v.nx * v.ny * v.nz;
     // the preprocess packs {workgroups done : 12 | survivors : 20 | rows : 32} into one 64-bit atomic: P < 2^20 keeps every field
     // inside its bits whatever the scene (survivors <= P, workgroups = P / 1024 < 2^10, rows <= 64 tiles x P < 2^26)
-    if (T > VOX_SMALL_MAX_TILES || v.gx > 8 || v.gy > 8 || v.gz > 8 || P >= (1 << 20) || !small_enabled()) return VOX_SMALL_NOT_TAKEN;
+    // (x-slab calls: the survivor kernel below rebuilds the tile cube from the radii, without the slab's clip -- general chain)
+    if (T > VOX_SMALL_MAX_TILES || v.gx > 8 || v.gy > 8 || v.gz > 8 || P >= (1 << 20) || v.is_slab() || !small_enabled()) return VOX_SMALL_NOT_TAKEN;
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
     unsigned long long *const g_small_counter = small_counter_for(dev, s);
@@ -343,17 +344,17 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
         set_error("r2_voxel_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
         return R2_ERR_INVALID;
     }
-    const size_t NW = R / vox_chunk_for(R) + T;
+    const size_t NW = R / vox_chunk_for(v.gy, v.gz) + T;
     // rare (a patch that most Gaussians reach): the general path; the kernel above has seen the same totals and done nothing
     if (nsurv > VOX_SMALL_MAX_SURVIVORS || R > tmp.cap_R || NW > tmp.cap_work) return VOX_SMALL_NOT_TAKEN;
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
-    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false).bytes, image_user);
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false, vox_chunk_for(v.gy, v.gz)).bytes, image_user);
     if (!bchunk || !ichunk) {
         set_error("r2_voxel_forward: binning/image allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
-    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false, vox_chunk_for(v.gy, v.gz));
     { StageScope t(ST_VOX_RENDER_FWD, s);
     VoxelBinning b2 = bin;          // the render kernels read the lists where they were built ...
     VoxelImage i2 = img;

@@ -7,9 +7,16 @@ namespace r2 {
 
 constexpr uint32_t VOX_CHUNK = 1024;  // most instances of one tile list evaluated by one workgroup (load balance)
 // Small problems (the training loop's 32^3 TV patch: 64 tiles, ~5e4 instances) are cut finer, so that the forward still
-// launches a few workgroups per CU instead of ~one long-running workgroup per tile.  A pure function of R: the backward and
-// the state introspection re-derive the same layout.
-__host__ __device__ inline uint32_t vox_chunk_for(size_t R) { return R >= (size_t)1 << 20 ? VOX_CHUNK : (R >= (size_t)1 << 19 ? 512u : (R >= (size_t)1 << 17 ? 256u : 128u)); }
+// launches a few workgroups per CU instead of ~one long-running workgroup per tile.  A pure function of the grid's y-z CROSS-SECTION
+// (tiles): the backward and the state introspection re-derive the same layout, and -- round 6 -- so does every x-slab call on the
+// same volume: where a tile's list is cut decides how its partial sums associate, so the unsharded query and its slabs must cut
+// alike to be bit-identical (rounds 1-5 chose by the call's instance count R, which a slab cannot know of the full call).
+// 32^3 patch: 128; 64^3: 256; 128^3: 512; 256^3: 1024.
+__host__ __device__ inline uint32_t vox_chunk_for(int gy, int gz)
+{
+    const long long c = (long long)gy * gz;
+    return c > 256 ? VOX_CHUNK : (c > 64 ? 512u : (c > 16 ? 256u : 128u));
+}
 constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
 constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
 constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)
@@ -194,12 +201,12 @@ struct VoxelImage {
     size_t NW;
     size_t R;               // instances (host-side copy: launch sizing)
     size_t bytes;
-    static VoxelImage carve(char *chunk, size_t T, size_t V, size_t R, bool debug)
+    static VoxelImage carve(char *chunk, size_t T, size_t V, size_t R, bool debug, uint32_t list_chunk /* vox_chunk_for(gy, gz) */)
     {
         VoxelImage s;
         Bump b(chunk);
         s.R = R;
-        s.NW = R / vox_chunk_for(R) + T;
+        s.NW = R / list_chunk + T;
         s.ranges = b.take<uint2>(T);
         s.chunk_base = b.take<uint32_t>(T + 1);
         s.work_tile = b.take<uint4>(s.NW);
@@ -212,11 +219,19 @@ struct VoxelImage {
     }
 };
 
+// The grid of a call.  An ordinary call: the volume of the settings.  An x-SLAB call (r2_voxel_forward_slab: tile layers [tile_x0,
+// tile_x1) of the full grid, the unit of the sharded query): (nx, gx) describe the slab -- the output block is [nx, ny, nz], the
+// tile grid gx x gy x gz, tile and voxel indices count from the slab's first layer -- while (sx, cx, fnx, fgx) stay the FULL
+// volume's, so that every float the preprocess and the render kernels form (voxel size, voxel-space position, radii, tile cube,
+// distance to a voxel centre = position - (ox + slab-local index)) is the unsharded call's, bit for bit.
 struct VoxelGrid {
     int nx, ny, nz;
     float sx, sy, sz;
     float cx, cy, cz;
     int gx, gy, gz;
+    int ox;         // voxel x index (full grid) of the slab's first voxel: tile_x0 * TILE3D; 0 for an ordinary call
+    int fnx, fgx;   // nVoxel_x and tiles along x of the full grid (= nx, gx for an ordinary call)
+    bool is_slab() const { return ox != 0 || fgx != gx; }
 };
 
 int launch_voxel_preprocess(const VoxelGeom &g, const VoxelGrid &v, int P, const float *means3D, const float *scales,

@@ -835,18 +835,18 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     }
     const size_t R = num_rendered;
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
-    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false).bytes, image_user);
+    char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false, vox_chunk_for(v.gy, v.gz)).bytes, image_user);
     if (!bchunk || !ichunk) {
         set_error("r2_voxel_forward: binning/image allocation callback returned NULL");
         return R2_ERR_ALLOC;
     }
     const VoxelBinning bin = VoxelBinning::carve(bchunk, R);
-    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false);
+    const VoxelImage img = VoxelImage::carve(ichunk, T, V, R, false, vox_chunk_for(v.gy, v.gz));
     uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // the backward's moment scratch (48 bytes per instance), free until then
     // the render kernel's work list: for more than 4096 tiles the sort kernel leaves the work items per block of tiles behind
     // (one launch of the construction instead of two)
     const bool sums = T > 4096 && img.work_temp != nullptr && R > 0;
-    const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_chunk_for(R),
+    const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_chunk_for(v.gy, v.gz),
                     voxel_short_list_min(false)};
     const uint32_t n_partial = sums ? (uint32_t)((T + wk.block_tiles - 1) / wk.block_tiles) : 0u;
     // ... and for up to 4096 tiles (lists = tiles) the scatter kernel's second service workgroup builds ranges and work list

@@ -157,7 +157,10 @@ def assert_replicas_equal(t, what="tensor"):
 
 # ---- full-volume query sharded by x-slab (independent units, no exchange, optional gather to assemble) ----------
 # The volume array is [nx, ny, nz] with x slowest, so a slab of whole 8-voxel tiles along x is a contiguous block of
-# memory and an independent voxelizer call on a sub-volume: same voxel size, centre moved to the slab's centre.
+# memory.  A rank's call is the FULL grid's call restricted to its tile layers (r2_voxel_forward_slab): same centre, same voxel
+# size, same voxel coordinates and radii on every rank, so the concatenated slabs are bit-identical to the unsharded volume.
+# (Rounds 1-5 re-centred a sub-volume per rank: voxel coordinates were then rounded differently and a 1e-4 share of the voxels
+# differed by more than 1e-4 relative.)
 TILE3D = 8
 
 
@@ -171,17 +174,16 @@ def slab_bounds(n_voxel_x, rank_, world_):
 
 
 def slab_settings(settings, rank_=None, world_=None):
-    """``GaussianVoxelizationSettings`` of this rank's x-slab of the volume described by ``settings`` (None if the slab is
-    empty: more ranks than tile layers)."""
+    """``GaussianVoxelizationSlabSettings`` of this rank's x-slab of the volume described by ``settings``: the full volume's
+    settings + the rank's range of tile layers (None if the slab is empty: more ranks than tile layers)."""
+    from .voxelization import GaussianVoxelizationSlabSettings
     r = rank() if rank_ is None else rank_
     w = world() if world_ is None else world_
     x0, x1 = slab_bounds(settings.nVoxel_x, r, w)
     if x1 <= x0:
         return None, (x0, x1)
-    dvx = settings.sVoxel_x / settings.nVoxel_x
-    n = x1 - x0
-    centre = settings.center_x - 0.5 * settings.sVoxel_x + (x0 + 0.5 * n) * dvx
-    return settings._replace(nVoxel_x=n, sVoxel_x=dvx * n, center_x=centre), (x0, x1)
+    base = tuple(settings)[:12]
+    return GaussianVoxelizationSlabSettings(*base, tile_x0=x0 // TILE3D, tile_x1=(x1 + TILE3D - 1) // TILE3D), (x0, x1)
 
 
 def query_sharded(voxelizer_cls, settings, means3D, opacities, scales, rotations, gather=True):

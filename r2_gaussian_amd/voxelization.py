@@ -28,6 +28,33 @@ class GaussianVoxelizationSettings(NamedTuple):
     debug: bool
 
 
+class GaussianVoxelizationSlabSettings(NamedTuple):
+    """New (not in the reference): the settings of the FULL volume plus a range of 8-voxel tile layers along x.  A voxelizer
+    built on them returns the [x1 - x0, ny, nz] block of the full volume -- every rank of the sharded query evaluates the full
+    grid's arithmetic and renders only its layers, so the concatenated blocks are bit-identical to the unsharded volume
+    (``dist.slab_settings`` builds these; C ABI: r2_voxel_forward_slab)."""
+    scale_modifier: float
+    nVoxel_x: int
+    nVoxel_y: int
+    nVoxel_z: int
+    sVoxel_x: float
+    sVoxel_y: float
+    sVoxel_z: float
+    center_x: float
+    center_y: float
+    center_z: float
+    prefiltered: bool
+    debug: bool
+    tile_x0: int
+    tile_x1: int
+
+
+def _slab_of(vs):
+    """(tile_x0, tile_x1) of slab settings, None for the reference's settings."""
+    t0 = getattr(vs, "tile_x0", None)
+    return None if t0 is None else (int(t0), int(vs.tile_x1))
+
+
 class _VoxelizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, opacities, scales, rotations, cov3Ds_precomp, voxel_settings):
@@ -35,8 +62,10 @@ class _VoxelizeGaussians(torch.autograd.Function):
         args = (means3D, opacities, scales, rotations, vs.scale_modifier, cov3Ds_precomp, vs.nVoxel_x, vs.nVoxel_y,
                 vs.nVoxel_z, vs.sVoxel_x, vs.sVoxel_y, vs.sVoxel_z, vs.center_x, vs.center_y, vs.center_z,
                 vs.prefiltered, vs.debug)
+        slab = _slab_of(vs)
         (num_rendered, fields, radii_x, radii_y, radii_z, geomBuffer, binningBuffer, imgBuffer) = _guarded(
-            _C.voxelize_gaussians, args, vs.debug, "snapshot_fw.dump", "forward")
+            _C.voxelize_gaussians if slab is None else _C.voxelize_gaussians_slab, args if slab is None else args + slab,
+            vs.debug, "snapshot_fw.dump", "forward")
         ctx.voxel_settings = vs
         ctx.num_rendered = num_rendered
         ctx.save_for_backward(means3D, scales, rotations, cov3Ds_precomp, radii_x, radii_y, radii_z, geomBuffer,
@@ -55,8 +84,10 @@ class _VoxelizeGaussians(torch.autograd.Function):
         args = (means3D, radii_x, radii_y, radii_z, scales, rotations, vs.scale_modifier, cov3Ds_precomp,
                 grad_out_color, geomBuffer, ctx.num_rendered, binningBuffer, imgBuffer, vs.nVoxel_x, vs.nVoxel_y,
                 vs.nVoxel_z, vs.sVoxel_x, vs.sVoxel_y, vs.sVoxel_z, vs.center_x, vs.center_y, vs.center_z, vs.debug)
+        slab = _slab_of(vs)
         grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_scales, grad_rotations = _guarded(
-            _C.voxelize_gaussians_backward, args, vs.debug, "snapshot_bw.dump", "backward")
+            _C.voxelize_gaussians_backward if slab is None else _C.voxelize_gaussians_backward_slab,
+            args if slab is None else args + slab, vs.debug, "snapshot_bw.dump", "backward")
         if scales.numel() == 0:
             grad_scales = None
         if rotations.numel() == 0:

@@ -121,16 +121,24 @@ def oracle_voxel(O, c, nVoxel, sVoxel, center, scale_modifier=1.0, render=True):
     return O.voxel_forward(xyz, rho, sc, q, scale_modifier, None, nVoxel, sVoxel, center, render=render)
 
 
-def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0):
+def hip_voxel(c, nVoxel, sVoxel, center, dev, debug=False, scale_modifier=1.0, slab=None):
+    """slab = (tile_x0, tile_x1): the x-slab call (r2_voxel_forward_slab) on those tile layers of the grid; the state and the
+    volume read back are then the slab's ([x1 - x0, ny, nz], tiles renumbered from the slab's first layer)."""
     from r2_gaussian_amd import _C, _lib
     e = torch.empty(0)
     args = (c.xyz.to(dev), c.density.to(dev), c.scales.to(dev), c.rotations.to(dev), scale_modifier, e,
             nVoxel[0], nVoxel[1], nVoxel[2], sVoxel[0], sVoxel[1], sVoxel[2], center[0], center[1], center[2],
             False, debug)
-    R, vol, rx, ry, rz, geom, binning, img = _C.voxelize_gaussians(*args)
+    if slab is None:
+        R, vol, rx, ry, rz, geom, binning, img = _C.voxelize_gaussians(*args)
+    else:
+        R, vol, rx, ry, rz, geom, binning, img = _C.voxelize_gaussians_slab(*args, int(slab[0]), int(slab[1]))
     torch.cuda.synchronize()
     P = c.xyz.shape[0]
     nx, ny, nz = nVoxel
+    if slab is not None:
+        nx = min(8 * int(slab[1]), nx) - 8 * int(slab[0])
+        assert tuple(vol.shape) == (nx, ny, nz)
     out = dict(num_rendered=R, vol=vol.cpu().numpy(), radii_x=rx.cpu().numpy(), radii_y=ry.cpu().numpy(),
                radii_z=rz.cpu().numpy(), bufs=(geom, binning, img), args=args, radii_t=(rx, ry, rz))
     if P == 0:
