@@ -55,9 +55,16 @@ void set_error(const char *fmt, ...);
             if ((blockIdx.x & 31u) == 31u) atomicMax(&r2::g_ts_##unit[ph][2047], _t);                                                                  \
         }                                                                                                               \
     } while (0)
+// the same for kernels of many short workgroups: every 8th workgroup stamps (slot = workgroup / 8), so that 16 k of them are covered
+#define R2_TS_AT8(unit, ph)                                                                                             \
+    do {                                                                                                                \
+        if (threadIdx.x == 0 && (blockIdx.x & 7u) == 0u && (blockIdx.x >> 3) < 2047u)                                   \
+            r2::g_ts_##unit[ph][blockIdx.x >> 3] = wall_clock64();                                                      \
+    } while (0)
 #else
 #define R2_TS_DEFINE(unit)
 #define R2_TS_AT(unit, ph)
+#define R2_TS_AT8(unit, ph)
 #endif
 
 // ---- optional per-stage timing with HIP events on the caller's stream (r2_profile_* in r2hip.h)
@@ -293,51 +300,78 @@ struct WorkListOut {
     uint32_t min_len;
     // optional: capacity of `work` in items (0 = as many as needed); items beyond it are dropped (the caller checks the total)
     uint32_t work_cap;
+    // optional (rasterizer, with tile_done; round 6): the work list LONGEST FIRST -- every full item (chunk entries) in tile order,
+    // then the tiles' remainders by descending length class, then the empty tiles -- so that the kernel's last round of waves is
+    // made of its shortest items.  chunk_base[t] stays the tile-order prefix (the index space of a tile's partial sums: item
+    // chunk_base[t] + j is the tile's j-th chunk); only the ORDER of `work` changes, so a consumer must not take an item's
+    // position in `work` for that index.
+    uint32_t longest_first;
 };
+constexpr uint32_t WORK_CLASSES = 16;
 template <int NT>
 __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict__ counts, const WorkListOut wo)
 {
-    __shared__ uint32_t rw_wsum[NT / 64], rw_wsum2[NT / 64];
-    __shared__ uint32_t rw_carry, rw_carry2;
+    __shared__ uint32_t rw_wsum[NT / 64], rw_wsum2[NT / 64], rw_wsum3[NT / 64];
+    __shared__ uint32_t rw_carry, rw_carry2, rw_carry3, rw_cls[WORK_CLASSES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) { rw_carry = 0; rw_carry2 = 0; }
+    const bool lf = wo.longest_first != 0u && wo.tile_done != nullptr;   // (kernel-uniform)
+    if (tid == 0) { rw_carry = 0; rw_carry2 = 0; rw_carry3 = 0; }
+    if (tid < (int)WORK_CLASSES) rw_cls[tid] = 0u;
     __syncthreads();
+    // length class of a remainder of `rem` entries (0 < rem < chunk): 0 = the longest
+    auto cls_of = [&](uint32_t rem) { return WORK_CLASSES - 1u - min(WORK_CLASSES - 1u, (rem * WORK_CLASSES) / wo.chunk); };
     for (uint32_t base = 0; base < wo.T; base += NT) {
         const uint32_t t = base + tid;
         const uint32_t c = t < wo.T ? counts[t] : 0u;
         const uint32_t nw = c < wo.min_len ? 0u : (c + wo.chunk - 1) / wo.chunk;
-        uint32_t incl = c, incl2 = nw;
+        const uint32_t nfull = lf ? c / wo.chunk : nw;   // items placed in this sweep (longest first: the full ones)
+        uint32_t incl = c, incl2 = nw, incl3 = nfull;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d);
-            if (lane >= d) { incl += up; incl2 += up2; }
+            const uint32_t up = __shfl_up(incl, d), up2 = __shfl_up(incl2, d), up3 = __shfl_up(incl3, d);
+            if (lane >= d) { incl += up; incl2 += up2; incl3 += up3; }
         }
-        if (lane == 63) { rw_wsum[wave] = incl; rw_wsum2[wave] = incl2; }
+        if (lane == 63) { rw_wsum[wave] = incl; rw_wsum2[wave] = incl2; rw_wsum3[wave] = incl3; }
         __syncthreads();
-        uint32_t woff = 0, woff2 = 0;
-        for (int w = 0; w < wave; ++w) { woff += rw_wsum[w]; woff2 += rw_wsum2[w]; }
+        uint32_t woff = 0, woff2 = 0, woff3 = 0;
+        for (int w = 0; w < wave; ++w) { woff += rw_wsum[w]; woff2 += rw_wsum2[w]; woff3 += rw_wsum3[w]; }
         const uint32_t start = rw_carry + woff + incl - c, wstart = rw_carry2 + woff2 + incl2 - nw;
+        const uint32_t fstart = lf ? rw_carry3 + woff3 + incl3 - nfull : wstart;
         if (t < wo.T) {
             wo.ranges[t] = c ? make_uint2(start, start + c) : make_uint2(0u, 0u);
             wo.chunk_base[t] = wstart;
-            for (uint32_t j = 0; j < nw; ++j)
-                if (!wo.work_cap || wstart + j < wo.work_cap)
-                    wo.work[wstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
+            for (uint32_t j = 0; j < nfull; ++j)
+                if (!wo.work_cap || fstart + j < wo.work_cap)
+                    wo.work[fstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
+            if (lf && nw != nfull) atomicAdd(&rw_cls[cls_of(c - nfull * wo.chunk)], 1u);
         }
         __syncthreads();
-        if (tid == NT - 1) { rw_carry = start + c; rw_carry2 = wstart + nw; }
+        if (tid == NT - 1) { rw_carry = start + c; rw_carry2 = wstart + nw; rw_carry3 = fstart + nfull; }
         __syncthreads();
     }
     if (tid == 0) wo.chunk_base[wo.T] = rw_carry2;
     if (wo.tile_done == nullptr) return;
-    // second sweep: zero the arrival counters, append the empty tiles
+    // second sweep: zero the arrival counters, place the remainders (longest first), append the empty tiles
     const uint32_t nreal = rw_carry2;
     __syncthreads();
-    if (tid == 0) rw_carry = 0;
+    if (tid == 0) {
+        rw_carry = 0;
+        uint32_t run = rw_carry3;   // the remainders follow the full items, class after class
+        for (uint32_t k = 0; k < WORK_CLASSES; ++k) { const uint32_t n = rw_cls[k]; rw_cls[k] = run; run += n; }
+    }
     __syncthreads();
     for (uint32_t base = 0; base < wo.T; base += NT) {
         const uint32_t t = base + tid;
         const uint32_t empty = (t < wo.T && counts[t] == 0u) ? 1u : 0u;
+        if (lf && t < wo.T) {
+            const uint32_t c = counts[t], nfull = c / wo.chunk, rem = c - nfull * wo.chunk;
+            if (rem != 0u && c >= wo.min_len) {
+                const uint32_t pos = atomicAdd(&rw_cls[cls_of(rem)], 1u);   // (the order inside a class is immaterial)
+                const uint32_t start = wo.ranges[t].x;                      // written by this thread in the first sweep
+                if (!wo.work_cap || pos < wo.work_cap)
+                    wo.work[pos] = make_uint4(t, start + nfull * wo.chunk, start + c, nfull + 1u);
+            }
+        }
         if (t < wo.T) reinterpret_cast<uint4 *>(wo.tile_done)[t] = make_uint4(0u, 0u, 0u, 0u);   // one counter per 8x8 block
         uint32_t incl = empty;
 #pragma unroll

@@ -41,11 +41,12 @@ static int raster_forward_impl(
     }
     const int PV = P * V;   // view instances: everything between the preprocess and the render kernels works on these
 
-    // tile-first binning (raster_tilefirst.hip): single views whose instance count this thread can predict from its recent
-    // calls; everything else -- first call of a size, batched views, debug mode, huge grids -- takes the chain below
-    if (V == 1 && !debug) {
+    // tile-first binning (raster_tilefirst.hip): calls whose instance count this thread can predict from its recent calls (one
+    // view, or V stacked views of up to 4096 tiles in all); everything else -- first call of a size, debug mode, huge grids --
+    // takes the chain below
+    if (!debug) {
         const int r = raster_forward_tilefirst(what, geometryBuffer, geometry_user, binningBuffer, binning_user, imageBuffer, image_user,
-                                               P, width, height, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
+                                               P, V, width, height, means3D, opacities, scales, scale_modifier, rotations, cov3D_precomp,
                                                viewmatrices, projmatrices, tan_fovx, tan_fovy, mode, out_color, radii, s);
         if (r != TF_NOT_TAKEN) {
             if (r >= 0) host_mark_forward_end();
@@ -164,7 +165,8 @@ static int raster_forward_impl(
         { StageScope t(ST_RAS_SORT, s);
         if (sort_is_single_pass(bit)) {
             const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK,
-                                 debug ? nullptr : img.tile_done, 0u};
+                                 debug ? nullptr : img.tile_done, 0u, 0u,
+                                 (raster_forward_wave_kernel_on() && raster_ids_leave_room_for_masks((size_t)PV)) ? 1u : 0u};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo, hist_ready);   // inv: introspection only
             work_built = true;
@@ -193,7 +195,7 @@ static int raster_forward_impl(
                                  /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s, nullptr, nullptr, (size_t)PV); }
     R2_STAGE_CHECK(debug, s, "render");
     // the next call's prediction (visible keys are positive floats: their range is the P class of the host words)
-    if (V == 1) raster_tilefirst_note(P, width, height, num_rendered, hw[DW_USER] != 0, hw[DW_PMAX], ~hw[DW_PNMAX]);
+    raster_tilefirst_note(P, V, width, height, num_rendered, hw[DW_USER] != 0, hw[DW_PMAX], ~hw[DW_PNMAX]);
     host_mark_forward_end();
     return (int)num_rendered;
 }
@@ -215,7 +217,7 @@ static int raster_backward_impl(
     const RasterGeom geom = RasterGeom::carve(geom_buffer, P * V);
     const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
     { StageScope t(ST_RAS_RENDER_BWD, s);
-    launch_raster_render_backward(geom, bin, radii, width, height, V, (size_t)R, dL_dpix, s); }
+    launch_raster_render_backward(geom, bin, radii, width, height, V, (size_t)R, dL_dpix, s, (size_t)P * (size_t)V); }
     R2_STAGE_CHECK(debug, s, "render backward");
     const float *cov3D = cov3D_precomp ? cov3D_precomp : geom.cov3D;
     { StageScope t(ST_RAS_GEOM_BWD, s);

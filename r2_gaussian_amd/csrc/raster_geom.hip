@@ -205,7 +205,8 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 // 1024-thread workgroups run side by side on a CU instead of one after the other; the plain instantiation (68 VGPRs) has its CU to itself.
 template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */, bool SHARE>
 __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preprocess_tf_kernel(
-    int P, uint32_t per_wg, const TFSlabs slabs, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
+    int P /* per view */, int V /* stacked views (round 6): the kernel runs over the V * P view instances v * P + i, tile grids stacked */,
+    uint32_t per_wg, const TFSlabs slabs, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
     const float *__restrict__ rotations, const float *__restrict__ opacities, const float *__restrict__ cov3D_precomp,
     const float *__restrict__ view, const float *__restrict__ proj, int W, int H, float tan_fovx, float tan_fovy,
     float focal_x, float focal_y, int mode, int gx, int gy,
@@ -221,8 +222,9 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
     const uint32_t NT = blockDim.x;
     const int nw = (int)(NT >> 6);
     const uint32_t nsl = SL ? slabs.n : 1u;
-    const uint32_t T = (uint32_t)(gx * gy) * nsl;   // lists
-    const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, (uint32_t)P);   // this workgroup's Gaussians
+    const uint32_t T = (uint32_t)(gx * gy * V) * nsl;   // lists
+    const uint32_t PV = (uint32_t)P * (uint32_t)V;
+    const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, PV);   // this workgroup's view instances
     R2_TS_AT(geom, 0);
     for (uint32_t t = tid; t < T; t += NT) tf_hist[t] = 0u;
     if (tid == 0) s_thin = 0u;
@@ -233,10 +235,13 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
         key[it] = DEPTH_CULLED_KEY; rect[it] = 0u;
         const uint32_t idx = g0 + (uint32_t)it * NT + (uint32_t)tid;
         uint2 bt = make_uint2(0u, 0u);
-        if ((it == 0 || NT * (uint32_t)it < per_wg) && idx < g1)   // (workgroup-uniform first half: no second round for small workgroups)
-            raster_preprocess_one((int)idx, (int)idx, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W,
-                                  H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds, tiles_touched,
-                                  op_mu, &thin, noreg, key[it], bt, rect[it]);
+        if ((it == 0 || NT * (uint32_t)it < per_wg) && idx < g1) {   // (workgroup-uniform first half: no second round for small workgroups)
+            const uint32_t v = V == 1 ? 0u : idx / (uint32_t)P;   // the instance's view: its matrices, its rows of the stacked grid
+            raster_preprocess_one((int)idx, (int)(idx - v * (uint32_t)P), means3D, scales, scale_modifier, rotations, opacities,
+                                  cov3D_precomp, view + 16u * v, proj + 16u * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy,
+                                  radii, rec, depth_key, cov3Ds, tiles_touched, op_mu, &thin, noreg, key[it], bt, rect[it]);
+            if (key[it] != DEPTH_CULLED_KEY) rect[it] += (v * (uint32_t)gy) << 8;   // y0 of the rectangle in the stacked grid (< 256 rows)
+        }
     }
     R2_TS_AT(geom, 10);
     __syncthreads();                           // the histogram is clear
@@ -811,7 +816,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P, int V, const float *mea
     return 0;
 }
 
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
+int launch_raster_preprocess_tf(const RasterGeom &g, int P, int V, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
                                 const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
                                 int *radii, TFCounters *ctr, hipStream_t s)
@@ -822,13 +827,13 @@ int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, 
     const bool share = (int)grid.wgs > device_cu_count() && grid.threads > TF_THREADS_MAX / 2;
 #define R2_TF_PRE(SLB)                                                                                                            \
     if (share)                                                                                                                        \
-        raster_preprocess_tf_kernel<SLB, true><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>( \
-            P, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,    \
+        raster_preprocess_tf_kernel<SLB, true><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * V * slabs.n * sizeof(uint32_t), s>>>( \
+            P, V, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,    \
             tan_fovy, focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect,  \
             g.tf_wgoff, g.tf_wgmm, ctr);                                                                                                \
     else                                                                                                                              \
-    raster_preprocess_tf_kernel<SLB, false><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * slabs.n * sizeof(uint32_t), s>>>(   \
-        P, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, \
+    raster_preprocess_tf_kernel<SLB, false><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * V * slabs.n * sizeof(uint32_t), s>>>(   \
+        P, V, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, \
         focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,  \
         g.tf_wgmm, ctr)
     if (slabs.n > 1u) R2_TF_PRE(true);

@@ -61,6 +61,10 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
     const float dx0 = a.x - x0;
     const float k1 = a.z * (1.0f - 2.0f * dx0);                       // log2 of alpha(1)/alpha(0), minus B2*dy
     const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * a.z);   // second ratio, constant along the row
+#if defined(R2_EXP_FWD_CMPX) && !defined(R2_EXP_NO_CMPX)
+    const unsigned long long full_exec = __builtin_amdgcn_read_exec();
+    (void)full_exec;
+#endif
 #pragma unroll
     for (int r = 0; r < SUB2D; ++r) {
         const float dy = a.y - (y0 + (float)r);
@@ -94,7 +98,16 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
                 // power <= 0 holds: positive definite conic.  (The EXEC-mask form of this -- v_cmpx + add + s_mov exec, 2 VALU
                 // instead of 3 -- gains 2.7 us in the backward, which is issue-bound; here it was measured twice, rounds 1
                 // and 2: 1 us SLOWER.  This kernel waits on latency, not on the VALU.)
+#if defined(R2_EXP_FWD_CMPX) && !defined(R2_EXP_NO_CMPX)
+                asm volatile("v_cmpx_le_f32_e32 %[thr], %[g]\n\t"
+                             "v_add_f32_e32 %[a], %[a], %[g]\n\t"
+                             "s_mov_b64 exec, %[ex]"
+                             : [a] "+v"(acc[r * SUB2D + c])
+                             : [thr] "v"(ALPHA_MIN_2D), [g] "v"(g), [ex] "s"(full_exec)
+                             : "vcc");
+#else
                 acc[r * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;
+#endif
                 g *= rt;
                 rt *= rr;
             }
@@ -289,9 +302,12 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 // whole chunk instead of per 256-entry batch), so the two kernels' images agree to float association, not bit for bit.
 // blockIdx -> (work item, block): the four blocks of an item run on ONE XCD (block b of the grid runs on XCD b % 8), so its
 // records are pulled into one L2.
+#ifndef R2_EXP_FWD_OCC
+#define R2_EXP_FWD_OCC 4
+#endif
 template <bool ANY4, bool MV>
-__global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
-    const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile, uint32_t T, uint32_t NW,
+__global__ void __launch_bounds__(64, R2_EXP_FWD_OCC) raster_render_forward_wave_kernel(
+    const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile, uint32_t T, uint32_t NW,
     const uint32_t *__restrict__ masked, const float4 *__restrict__ rec, int gx, int gy, float *__restrict__ partial,
     uint32_t *__restrict__ tile_done, float *__restrict__ out_color, int W, int H, uint32_t *__restrict__ tiles, char *tf_bin_base,
     const uint32_t *__restrict__ tf_words)
@@ -301,7 +317,7 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
     const uint32_t w = (bi >> 5) * 8u + (bi & 7u);
     const int blk = (int)((bi >> 3) & 3u);
     const int lane = threadIdx.x;
-    R2_TS_AT(render, 0);
+    R2_TS_AT8(render, 4);
     const uint4 wd = work_tile[min(w, NW - 1u)];   // {tile, first instance, one past the last, items of the tile}
     if (w >= chunk_base[T + 1]) return;
     if (tf_bin_base != nullptr) {   // tile-first forward: the binning buffer was carved with a PREDICTED instance count (raster_state.hpp)
@@ -310,6 +326,7 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
         masked = binning_masked_ptr(tf_bin_base, Rt);
     }
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
+    R2_TS_AT8(render, 5);   // the descriptor is here
     int tx, ty, tv;
     tile_decode<MV>(tile, gx, gy, tx, ty, tv);
     out_color += (size_t)tv * H * W;
@@ -321,7 +338,10 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
         return;
     }
     const float x0 = (float)(tx * TILE2D + bx), y0 = (float)(ty * TILE2D + by);
-    // the backward's per-instance tile ids (until it reads the work list itself)
+    // where this item's partial sums go: the work list is ordered longest first (WorkListOut::longest_first), the index space of
+    // a tile's partial sums is the tile-order one -- chunk_base[tile] + the chunk's number inside the tile (requested now, used last)
+    const uint32_t tile_beg = ranges[tile].x, w0 = chunk_base[tile];
+    // the backward's per-instance tile ids
     if (tiles != nullptr && blk == 0)
         for (uint32_t k = beg + (uint32_t)lane; k < end; k += 64u) tiles[k] = tile;
 
@@ -342,6 +362,7 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    R2_TS_AT8(render, 6);   // the ids are here and compacted
 
     float acc[64];
 #pragma unroll
@@ -355,12 +376,22 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
         nb = rec[2 * id + 1];
     }
     for (int head = 0; head < cnt; head += 64) {
+#ifdef R2_EXP_FWD_NOPF   // experiment: no record prefetch (8 registers less: 5 waves per SIMD), the gather's round trip exposed per step
+        float4 ea, eb;
+        {
+            const uint32_t id = sQ[min(head + lane, cnt - 1)];
+            ea = rec[2 * id];
+            eb = rec[2 * id + 1];
+        }
+        (void)na; (void)nb;
+#else
         float4 ea = na, eb = nb;
         {
             const uint32_t id = sQ[min(head + 64 + lane, cnt - 1)];
             na = rec[2 * id];
             nb = rec[2 * id + 1];
         }
+#endif
         const bool live = head + lane < cnt;
         if (!live) { ea = make_float4(0.f, 0.f, 0.f, 0.f); eb = make_float4(0.f, -INFINITY, 0.f, 0.f); }   // idle lane: alpha = 0
         const int tier = live ? row_tier(ea.z, eb.y, eb.z) : 0;
@@ -394,19 +425,20 @@ __global__ void __launch_bounds__(64, 4) raster_render_forward_wave_kernel(
             }
         }
     }
-    R2_TS_AT(render, 1);
+    R2_TS_AT8(render, 7);   // steps + transposes done
     if (wd.w == 1u) {   // the tile's only work item: the image pixel itself
         if (inside) out_color[py * W + px] = acc[0];
         return;
     }
     // partial sums cross XCDs: agent-scope (sc1) stores / loads, the arrival counter bumped after they are acknowledged (see above)
-    __hip_atomic_store(&partial[((size_t)w * 4 + (size_t)blk) * 64 + (size_t)lane], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t slot = w0 + (beg - tile_beg) / FWD_CHUNK;
+    __hip_atomic_store(&partial[((size_t)slot * 4 + (size_t)blk) * 64 + (size_t)lane], acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     uint32_t arrived = 0u;
     if (lane == 0) arrived = atomicAdd(&tile_done[tile * 4u + (uint32_t)blk], 1u);
     arrived = (uint32_t)__builtin_amdgcn_readfirstlane((int)arrived);
+    R2_TS_AT8(render, 8);   // partial stored, arrival counted
     if (arrived != wd.w - 1u) return;
-    const uint32_t w0 = chunk_base[tile];
     float C = 0.f;
     for (uint32_t i = 0; i < wd.w; ++i)   // list order: deterministic image
         C += __hip_atomic_load(&partial[((size_t)(w0 + i) * 4 + (size_t)blk) * 64 + (size_t)lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -680,7 +712,9 @@ template <bool MV>
 __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_kernel(
     const uint32_t *__restrict__ tiles, const uint32_t *__restrict__ point_list, const uint32_t *__restrict__ first,
     const int *__restrict__ radii, const float4 *__restrict__ rec, uint32_t R, int W, int H, int gx, int gy,
-    uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part, const uint32_t *__restrict__ thin_flag)
+    uint32_t nchunks, const float *__restrict__ dL_dpix, float4 *__restrict__ part, const uint32_t *__restrict__ thin_flag,
+    const uint32_t *__restrict__ masked /* round 6: point_list << MASK_BITS | block mask (replaces point_list and the four
+                                           block tests per instance), or null */)
 {
     constexpr int NB = TILE2D / SUB2D;        // blocks per tile side (2)
     constexpr int NBLK = NB * NB;             // blocks per tile (4)
@@ -710,9 +744,10 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         live = chunk < nchunks && k < R;
         const uint32_t kc = min(k, R - 1u);
         tile = tiles[kc];
-        id = point_list[kc];
+        id = masked != nullptr ? masked[kc] : point_list[kc];   // (kernel-uniform; with the masks: id << MASK_BITS | mask)
     };
-    auto load2 = [&](uint32_t id, float4 &a, float4 &b, int &rad, uint32_t &first_row) {
+    auto load2 = [&](uint32_t idm, float4 &a, float4 &b, int &rad, uint32_t &first_row) {
+        const uint32_t id = masked != nullptr ? idm >> MASK_BITS : idm;
         a = rec[2 * id];
         b = rec[2 * id + 1];
         rad = radii[id];          // only needed for the final store's address
@@ -826,10 +861,14 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
         const float tx0 = (float)(ttx * TILE2D), ty0 = (float)(tty * TILE2D);
         uint32_t mask = 0;
         if (mine) {
+            if (masked != nullptr) {
+                mask = id & ((1u << MASK_BITS) - 1u);   // evaluated where the instance was emitted (block_mask4)
+            } else {
 #pragma unroll
-            for (int q = 0; q < NBLK; ++q)
-                if (block_live(a.x, a.y, b.z, b.w, tx0 + (float)((q % NB) * SUB2D), ty0 + (float)((q / NB) * SUB2D), (float)SUB2D))
-                    mask |= 1u << q;
+                for (int q = 0; q < NBLK; ++q)
+                    if (block_live(a.x, a.y, b.z, b.w, tx0 + (float)((q % NB) * SUB2D), ty0 + (float)((q / NB) * SUB2D), (float)SUB2D))
+                        mask |= 1u << q;
+            }
         }
         const int cnt = __popc(mask);
         int incl = cnt;
@@ -917,7 +956,21 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     R2_TS_AT(render, 3);
 }
 
+// (Measured and left out, round 6 -- VERDICT r5 #2c: the backward as one-wave work items on the forward's work list, lane = entry,
+// the tile's four blocks one after the other, dL/dpix of the block as SCALAR operands of the pixel sequence (s_load_dwordx8 per
+// row; or broadcast from LDS), the block masks of the list instead of per-lane tests, an entry's row accumulated in LDS, no software
+// pipeline: 54 VGPRs, 7 waves per SIMD, parity green on the whole suite -- and 85-89 us against this kernel's 55 (sub-chunks of 128
+// and 256 entries, scalar and LDS operands alike: profiles/experiments/r06_wave_backward_ab*.txt, the patch next to them).  Its
+// in-kernel stamps say why (r06_wave_kernels_stamps.txt): a step per block and sub-chunk fills 64 lanes to ~65 % where this kernel's
+// queue over all blocks of 64 instances fills its rounds to ~92 %: 57 k steps instead of 36 k rounds, at ~800 issue slots each, on
+// SIMDs that the seven resident waves keep 63 % busy -- the kernel was compute-bound on work it created itself.)
 // ------------------------------------------------------------------------------------------------ launchers
+bool raster_forward_wave_kernel_on()
+{
+    static const bool on = [] { const char *e = getenv("R2_FWD_WAVE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 template <bool MV>
 static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int gx, int gy, uint32_t T,
                        float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s,
@@ -925,20 +978,21 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
 {
     // round 6: the one-wave kernel (R2_FWD_WAVE=0: the four-wave kernel of rounds 1-5, kept as the A/B reference); ids carry
     // MASK_BITS of block mask, i.e. view instances below 2^28
-    static const bool wave_on = [] { const char *e = getenv("R2_FWD_WAVE"); return !(e && e[0] == '0'); }();
-    if (fused_combine && !write_ncontrib && im.NW > 0 && wave_on && ids_below_2_28) {
+    // the masked list for chains whose sort did not carry the masks: the forward's wave kernel and the backward read it, so every
+    // forward leaves it behind (the backward cannot ask which path ran; it chooses by the same ids_below_2_28 rule)
+    if (tf_bin_base == nullptr && im.NW > 0 && ids_below_2_28)
+        raster_mask_fill_kernel<MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(im.chunk_base, im.work_tile, T, b.point_list, g.rec,
+                                                                                gx, gy, b.masked);
+    if (fused_combine && !write_ncontrib && im.NW > 0 && raster_forward_wave_kernel_on() && ids_below_2_28) {
         const uint32_t *masked = b.masked;
-        if (tf_bin_base == nullptr)   // this chain's sort did not carry the masks
-            raster_mask_fill_kernel<MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(im.chunk_base, im.work_tile, T, b.point_list, g.rec,
-                                                                                    gx, gy, b.masked);
         const unsigned grid = (unsigned)((im.NW + 7) / 8) * 32u;   // 8 work items x 4 blocks per group of 32 workgroups
         if (any_thin)
             raster_render_forward_wave_kernel<true, MV><<<dim3(grid), dim3(64), 0, s>>>(
-                im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                im.ranges, im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
                 fill_tiles, tf_bin_base, tf_words);
         else
             raster_render_forward_wave_kernel<false, MV><<<dim3(grid), dim3(64), 0, s>>>(
-                im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+                im.ranges, im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
                 fill_tiles, tf_bin_base, tf_words);
         return;
     }
@@ -986,9 +1040,12 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
 }
 
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
-                                  const float *dL_dpix, hipStream_t s)
+                                  const float *dL_dpix, hipStream_t s, size_t view_instances)
 {
     if (R == 0) return 0;
+    // every forward leaves the masked list behind when the ids leave room for the mask bits (launch_raster_render_forward)
+    static const bool masks_on = [] { const char *e = getenv("R2_BWD_MASKS"); return !(e && e[0] == '0'); }();
+    const uint32_t *masked = (masks_on && view_instances < ((size_t)1 << (32 - MASK_BITS))) ? b.masked : nullptr;
     const int gx = (W + TILE2D - 1) / TILE2D;
     const uint32_t nchunks = (uint32_t)((R + BWD_THREADS - 1) / BWD_THREADS);
     // Grid = a whole number of "rounds" of resident waves (CUs x 4 SIMDs x BWD_OCC); the chunks beyond it are second chunks
@@ -1008,11 +1065,11 @@ int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, c
     if (V > 1)   // the view of an instance follows from its tile id
         raster_render_backward_kernel<true><<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(
             b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy, nchunks, dL_dpix,
-            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
+            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER, masked);
     else
         raster_render_backward_kernel<false><<<dim3(grid), dim3(BWD_THREADS), 0, s>>>(
             b.tiles, b.point_list, g.first, radii, g.rec, (uint32_t)R, W, H, gx, gy, nchunks, dL_dpix,
-            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER);
+            reinterpret_cast<float4 *>(b.part), g.host_words + DW_USER, masked);
     return 0;
 }
 

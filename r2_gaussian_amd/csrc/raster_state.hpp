@@ -8,7 +8,7 @@
 namespace r2 {
 
 #ifndef R2_EXP_FWD_CHUNK
-#define R2_EXP_FWD_CHUNK 512
+#define R2_EXP_FWD_CHUNK 1024
 #endif
 constexpr uint32_t FWD_CHUNK = R2_EXP_FWD_CHUNK;   // instances of one tile list rendered by one workgroup (load balance)
 constexpr int PART_STRIDE = 8;        // floats per instance in the backward moment scratch (6 used)
@@ -298,7 +298,7 @@ int launch_raster_preprocess(const RasterGeom &g, int P /* per view */, int V, c
                              int mode, int *radii, uint32_t *thin_flag, const DepthReg &reg, bool store_cov3D, hipStream_t s);
 // tile-first binning, first kernel: the preprocess + per-tile instance counts + every Gaussian's run of scratch rows.  The totals
 // stay in the counters: the scatter kernel's workgroup 0 posts them to the state's host words and to the mailbox
-int launch_raster_preprocess_tf(const RasterGeom &g, int P, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
+int launch_raster_preprocess_tf(const RasterGeom &g, int P /* per view */, int V, const TFGrid &grid, const TFSlabs &slabs, const float *means3D, const float *scales,
                                 float scale_modifier, const float *rotations, const float *opacities, const float *cov3D_precomp,
                                 const float *view, const float *proj, int W, int H, float tan_fovx, float tan_fovy, int mode,
                                 int *radii, TFCounters *ctr, hipStream_t s);
@@ -332,16 +332,20 @@ int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, co
                                  float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
                                  hipStream_t s, char *tf_bin_base = nullptr, const uint32_t *tf_words = nullptr,
                                  size_t view_instances = 0 /* P x V: ids of the masked list */);
+// the one-wave forward kernel is in use (R2_FWD_WAVE=0: the four-wave kernel of rounds 1-5); it takes its work list longest first,
+// the four-wave kernel in tile order (WorkListOut::longest_first)
+bool raster_forward_wave_kernel_on();
+inline bool raster_ids_leave_room_for_masks(size_t view_instances) { return view_instances < ((size_t)1 << (32 - MASK_BITS)); }
 // raster_tilefirst.hip
 int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer,
-                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height,
+                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int V, int width, int height,
                              const float *means3D, const float *opacities, const float *scales, float scale_modifier,
                              const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
                              float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s);
 // a finished forward's instance count and depth-key range: the next call's prediction
-void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin);
+void raster_tilefirst_note(int P, int V, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin);
 void raster_tilefirst_release();   // the calling thread's counters and predictions (r2_thread_release)
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
-                                  const float *dL_dpix, hipStream_t s);
+                                  const float *dL_dpix, hipStream_t s, size_t view_instances = ~(size_t)0 /* P x V */);
 
 }  // namespace r2

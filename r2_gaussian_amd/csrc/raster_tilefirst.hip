@@ -80,7 +80,8 @@ static_assert(TFK_SMALL_CAP == TF_SMALL_CAP && TFK_COARSE == TFK_THREADS && TFK_
 constexpr uint32_t TFS_SERVICE = 3;
 template <bool SL /* depth slabs in use */>
 __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
-    int P, uint32_t per_wg, uint32_t pthreads, int gx, uint32_t T /* LISTS = tiles x slabs */, const TFSlabs slabs,
+    int P /* view instances: views x Gaussians */, int Pv /* Gaussians per view */, int gy, uint32_t per_wg, uint32_t pthreads, int gx,
+    uint32_t T /* LISTS = tiles (of all stacked views) x slabs */, const TFSlabs slabs,
     const uint32_t *__restrict__ rects, const float4 *__restrict__ rec,
     const uint32_t *__restrict__ depth_key, const uint32_t *__restrict__ tiles_touched, const uint32_t *__restrict__ wgoff,
     const uint32_t *__restrict__ wgmm, uint32_t producers, const TFCounters *__restrict__ ctr, uint32_t *__restrict__ words,
@@ -240,13 +241,24 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
             const uint32_t rect = g_rect[it], key = g_key[it];
             const uint32_t x0 = rect & 0xFFu, y0 = (rect >> 8) & 0xFFu, w = ((rect >> 16) & 0xFFu) + 1u, h = (rect >> 24) + 1u;
             const uint32_t nsl = SL ? slabs.n : 1u, sl = SL ? tf_slab_of(key, slabs) : 0u;
-            // second word: id << MASK_BITS | the instance's block mask -- sorting on (key, word) is sorting on (key, id)
+            // second word: id << MASK_BITS | the instance's block mask -- sorting on (key, word) is sorting on (key, id).
+            // block_mask4, separated per axis (block_live is a product of an x and a y test): two bits per tile row, two per column
             const uint32_t idw = g_idx[it] << MASK_BITS;
+            const float bxl = g_box[it].x - g_box[it].z, bxh = g_box[it].x + g_box[it].z;
+            const float byl = g_box[it].y - g_box[it].w, byh = g_box[it].y + g_box[it].w;
+            // (stacked views: the rectangle's rows count from the top of the stack, the record's pixel coordinates from its view's)
+            const uint32_t yoff = Pv == P ? 0u : (g_idx[it] / (uint32_t)Pv) * (uint32_t)gy;
             for (uint32_t r = 0; r < h; ++r) {
                 const uint32_t row = ((y0 + r) * (uint32_t)gx + x0) * nsl + sl;
+                const float ty0 = (float)((y0 + r - yoff) * (uint32_t)TILE2D);
+                const uint32_t yb0 = (byl <= ty0 + (float)(SUB2D - 1) && byh >= ty0) ? 0x3u : 0u;
+                const uint32_t yb1 = (byl <= ty0 + (float)(2 * SUB2D - 1) && byh >= ty0 + (float)SUB2D) ? 0xCu : 0u;
                 for (uint32_t c = 0; c < w; ++c) {
+                    const float tx0 = (float)((x0 + c) * (uint32_t)TILE2D);
+                    const uint32_t xb0 = (bxl <= tx0 + (float)(SUB2D - 1) && bxh >= tx0) ? 0x5u : 0u;
+                    const uint32_t xb1 = (bxl <= tx0 + (float)(2 * SUB2D - 1) && bxh >= tx0 + (float)SUB2D) ? 0xAu : 0u;
                     const uint32_t pos = atomicAdd(&s_pos[row + c * nsl], 1u);
-                    pairs[pos] = make_uint2(key, idw | block_mask4(g_box[it].x, g_box[it].y, g_box[it].z, g_box[it].w, (int)(x0 + c), (int)(y0 + r)));
+                    pairs[pos] = make_uint2(key, idw | ((xb0 | xb1) & (yb0 | yb1)));
                 }
             }
         }
@@ -632,7 +644,7 @@ TFWorkspace *tf_workspace(int dev, hipStream_t s)
 
 // the thread's recent instance counts per problem size: what the prediction is made of
 struct TFHint {
-    int P, W, H;
+    int P, V, W, H;   // Gaussians, stacked views, detector
     uint32_t recent[8], n;
     bool thin;
     uint32_t kmax, kmin;    // depth-key range of the last call (the next call's slabs are laid over it)
@@ -641,10 +653,10 @@ struct TFHint {
 thread_local std::vector<TFHint> g_tf_hints;
 thread_local unsigned long long g_tf_hint_tick = 0;
 
-TFHint *tf_hint(int P, int W, int H, bool create)
+TFHint *tf_hint(int P, int V, int W, int H, bool create)
 {
     for (TFHint &h : g_tf_hints)
-        if (h.P == P && h.W == W && h.H == H) { h.used = ++g_tf_hint_tick; return &h; }
+        if (h.P == P && h.V == V && h.W == W && h.H == H) { h.used = ++g_tf_hint_tick; return &h; }
     if (!create) return nullptr;
     if (g_tf_hints.size() >= 16) {
         size_t lru = 0;
@@ -652,17 +664,17 @@ TFHint *tf_hint(int P, int W, int H, bool create)
             if (g_tf_hints[i].used < g_tf_hints[lru].used) lru = i;
         g_tf_hints.erase(g_tf_hints.begin() + (long)lru);
     }
-    g_tf_hints.push_back(TFHint{P, W, H, {0}, 0u, false, 0u, 0u, ++g_tf_hint_tick});
+    g_tf_hints.push_back(TFHint{P, V, W, H, {0}, 0u, false, 0u, 0u, ++g_tf_hint_tick});
     return &g_tf_hints.back();
 }
 
 // no call with this P yet -- every densification changes it (train.py:155-168) --: the thread's most recent call on the same
 // detector, scaled by the ratio of the Gaussian counts
-const TFHint *tf_hint_nearby(int W, int H)
+const TFHint *tf_hint_nearby(int V, int W, int H)
 {
     const TFHint *best = nullptr;
     for (const TFHint &h : g_tf_hints)
-        if (h.W == W && h.H == H && h.n != 0u && h.P > 0 && (!best || h.used > best->used)) best = &h;
+        if (h.V == V && h.W == W && h.H == H && h.n != 0u && h.P > 0 && (!best || h.used > best->used)) best = &h;
     return best;
 }
 
@@ -694,9 +706,9 @@ int tf_forced_slabs()
 
 }  // namespace
 
-void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin)
+void raster_tilefirst_note(int P, int V, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin)
 {
-    TFHint *h = tf_hint(P, W, H, true);
+    TFHint *h = tf_hint(P, V, W, H, true);
     h->recent[h->n++ & 7u] = num_rendered;
     h->thin = thin;
     h->kmax = kmax;
@@ -705,17 +717,26 @@ void raster_tilefirst_note(int P, int W, int H, uint32_t num_rendered, bool thin
 
 // -> num_rendered (>= 0), a negative error code, or TF_NOT_TAKEN: nothing was launched, run the general path
 int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void *geometry_user, r2_alloc_fn binningBuffer,
-                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int width, int height,
+                             void *binning_user, r2_alloc_fn imageBuffer, void *image_user, int P, int V, int width, int height,
                              const float *means3D, const float *opacities, const float *scales, float scale_modifier,
                              const float *rotations, const float *cov3D_precomp, const float *viewmatrix, const float *projmatrix,
                              float tan_fovx, float tan_fovy, int mode, float *out_color, int *radii, hipStream_t s)
 {
+    // V stacked views (round 6; r2_raster_forward_batch): the chain runs over the V * P view instances on the stacked tile grid
+    // (tile = (v * gy + ty) * gx + tx, raster_state.hpp) -- the three binning kernels are one round of workgroups each whatever the
+    // work, so a batch pays for them once
     const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
-    const size_t T = (size_t)gx * gy, N = (size_t)width * height;
-    const TFGrid grid = tf_grid(P, device_cu_count());
+    const size_t T = (size_t)gx * gy * (size_t)V, N = (size_t)width * height * (size_t)V;
+    const size_t PVs = (size_t)P * (size_t)V;
+    if (PVs >= ((size_t)1 << 24)) {   // ids share a word with the block mask; 32-bit instance offsets
+        g_tf_declined.fetch_add(1, std::memory_order_relaxed);
+        return TF_NOT_TAKEN;
+    }
+    const int PV = (int)PVs;
+    const TFGrid grid = tf_grid(PV, device_cu_count());
     const size_t wgs = grid.wgs;
-    // rectangles are packed into bytes (<= 256 x 256 tiles), the LDS histogram holds <= 4096 tiles, instance offsets are 32-bit
-    if (T > TF_MAX_TILES || gx > 256 || gy > 256 || wgs * T > ((size_t)1 << 25) || P >= (1 << 24) || !tf_enabled()) {
+    // rectangles are packed into bytes (<= 256 x 256 tiles of the stacked grid), the LDS histogram holds <= 4096 tiles
+    if (T > TF_MAX_TILES || gx > 256 || (size_t)gy * (size_t)V > 256 || wgs * T > ((size_t)1 << 25) || !tf_enabled()) {
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
     }
@@ -723,11 +744,11 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     // yet (the call after a densification) the most recent call on the same detector, scaled -- same scene, more Gaussians
     uint32_t rmax = 0, kmax = 0, kmin = 0;
     bool thin_guess = false;
-    if (const TFHint *hint = tf_hint(P, width, height, false); hint && hint->n != 0u) {
+    if (const TFHint *hint = tf_hint(P, V, width, height, false); hint && hint->n != 0u) {
         for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
         thin_guess = hint->thin;
         kmax = hint->kmax; kmin = hint->kmin;
-    } else if (const TFHint *near = tf_hint_nearby(width, height)) {
+    } else if (const TFHint *near = tf_hint_nearby(V, width, height)) {
         uint32_t r0 = 0;
         for (uint32_t i = 0; i < std::min(near->n, 8u); ++i) r0 = std::max(r0, near->recent[i]);
         const double f = (double)P / (double)near->P;
@@ -767,19 +788,19 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     }
     const size_t TL = T * slabs.n;   // lists
 
-    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, P, TL, wgs).bytes, geometry_user);
+    char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, PV, TL, wgs).bytes, geometry_user);
     if (!gchunk) {
         set_error("%s: state allocation callback returned NULL", what);
         return R2_ERR_ALLOC;
     }
-    const RasterGeom geom = RasterGeom::carve(gchunk, P, TL, wgs);
+    const RasterGeom geom = RasterGeom::carve(gchunk, PV, TL, wgs);
     if (ws->dirty) R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));   // first use, or a call that failed half way
     ws->dirty = true;
     uint32_t *mailbox = nullptr, mailbox_seq = 0;
     int rc = host_mailbox_arm(&mailbox, &mailbox_seq);
     if (rc) return rc;
     { StageScope t(ST_RAS_PREPROCESS, s);
-    launch_raster_preprocess_tf(geom, P, grid, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
+    launch_raster_preprocess_tf(geom, P, V, grid, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
                                 projmatrix, width, height, tan_fovx, tan_fovy, mode, radii, ws->ctr, s); }
     R2_HIP_TRY(hipGetLastError());
 
@@ -797,10 +818,11 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
             img = RasterImage::carve(ichunk, T, N, capacity, false, TL);
             uint2 *pairs = reinterpret_cast<uint2 *>(bin.part);   // backward scratch (32 bytes per instance), free until then
             { StageScope t(ST_RAS_DUPLICATE, s);
-            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW};
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, FWD_CHUNK, img.tile_done, 0u, (uint32_t)img.NW,
+                                 raster_forward_wave_kernel_on() ? 1u : 0u};
 #define R2_TF_SCATTER(SLB)                                                                                                        \
             raster_tf_scatter_kernel<SLB><<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), TL * sizeof(uint32_t), s>>>(         \
-                P, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.rec, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
+                PV, P, gy, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.rec, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
                 geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,                                            \
                 (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,   \
                 ws->nparts)
@@ -818,8 +840,8 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
             R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, 4 * T * sizeof(uint32_t), s));   // the first render left its arrivals behind
         }
         { StageScope t(ST_RAS_RENDER_FWD, s);
-        launch_raster_render_forward(geom, bin, img, width, height, 1, out_color, false, bin.tiles, any_thin, true, s,
-                                     reinterpret_cast<char *>(bin.point_list), geom.host_words, (size_t)P); }
+        launch_raster_render_forward(geom, bin, img, width, height, V, out_color, false, bin.tiles, any_thin, true, s,
+                                     reinterpret_cast<char *>(bin.point_list), geom.host_words, (size_t)PV); }
         R2_HIP_TRY(hipGetLastError());
         return 0;
     };
@@ -845,7 +867,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     }
     ws->dirty = false;
     g_tf_taken.fetch_add(1, std::memory_order_relaxed);
-    raster_tilefirst_note(P, width, height, num_rendered, thin, hw[DW_NMAX], ~hw[DW_NNMAX]);
+    raster_tilefirst_note(P, V, width, height, num_rendered, thin, hw[DW_NMAX], ~hw[DW_NNMAX]);
     return (int)num_rendered;
 }
 

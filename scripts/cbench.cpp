@@ -60,8 +60,9 @@ int main(int argc, char **argv)
     auto wait_stats = sym<decltype(&r2_sync_wait_stats)>(h, "r2_sync_wait_stats");
     auto last_error = sym<decltype(&r2_last_error)>(h, "r2_last_error");
 
-    FILE *f = fopen("scripts/_scene/scene.bin", "rb");
-    if (!f) { fprintf(stderr, "scripts/_scene/scene.bin missing: run scripts/dump_scene.py\n"); return 1; }
+    const char *scene_path = getenv("R2_SCENE") ? getenv("R2_SCENE") : "scripts/_scene/scene.bin";   // scripts/dump_scene.py writes them
+    FILE *f = fopen(scene_path, "rb");
+    if (!f) { fprintf(stderr, "%s missing: run scripts/dump_scene.py\n", scene_path); return 1; }
     int hdr[4];
     if (fread(hdr, 4, 4, f) != 4) return 1;
     const int P = hdr[0], V = hdr[1], H = hdr[2], W = hdr[3];
@@ -252,6 +253,29 @@ int main(int argc, char **argv)
                     printf("  TS %-6s %2d: n %4zu  min %7.2f  med %7.2f  max %7.2f us\n", names[k].c_str(), ph, v.size(), v.front(),
                            v[v.size() / 2], v.back());
                 }
+            // per-workgroup phase durations: for every unit, the difference between consecutive stamped phases of the SAME slot
+            for (size_t k = 0; k < tabs.size(); ++k) {
+                int prev = -1;
+                for (int ph = 0; ph < 16; ++ph) {
+                    bool has = false;
+                    for (int b = 0; b < 2047 && !has; ++b) has = tabs[k][ph * 2048 + b] >= tlo;
+                    if (!has) continue;
+                    if (prev >= 0) {
+                        std::vector<double> d;
+                        double sum = 0;
+                        for (int b = 0; b < 2047; ++b) {
+                            const unsigned long long x = tabs[k][prev * 2048 + b], y = tabs[k][ph * 2048 + b];
+                            if (x >= tlo && y >= x) { d.push_back((double)(y - x) * 0.01); sum += d.back(); }
+                        }
+                        if (!d.empty()) {
+                            std::sort(d.begin(), d.end());
+                            printf("  TSD %-6s %2d->%2d: n %4zu  mean %6.2f  med %6.2f  p90 %6.2f  max %6.2f us\n", names[k].c_str(), prev, ph,
+                                   d.size(), sum / d.size(), d[d.size() / 2], d[d.size() * 9 / 10], d.back());
+                        }
+                    }
+                    prev = ph;
+                }
+            }
         }
     }
 

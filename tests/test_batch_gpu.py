@@ -123,26 +123,67 @@ def test_autograd_module_sums_the_views(gpu):
     assert torch.equal(got[4], torch.stack(want2))
 
 
-def test_hinted_batched_call(gpu):
-    """The SECOND batched call of a size runs the hinted depth order (sorted records, emission by output range with the stacked
-    tile grids of the views): images, radii and per-view screen-space gradients stay bit-identical to single-view calls."""
-    from r2_gaussian_amd import _C
+def _tf_taken():
+    import ctypes as C
+    from r2_gaussian_amd import _lib
+    st = (C.c_longlong * 5)()
+    _lib.lib().r2_tile_first_stats(st, 0)
+    return int(st[0])
+
+
+@pytest.mark.parametrize("tile_first", [True, False], ids=["tile_first_chain", "hinted_general_chain"])
+def test_second_batched_call_of_a_size(tile_first, gpu):
+    """The SECOND batched call of a size runs the tile-first chain over the stacked tile grids of the views (round 6: V * T <= 4096
+    tiles; the three one-round binning kernels are paid once per batch) -- or, with that chain switched off, the hinted depth order
+    (sorted records, emission by output range).  Either way images, radii and per-view screen-space gradients stay bit-identical
+    to single-view calls."""
+    from r2_gaussian_amd import _C, _lib
     P, hw, V = 20000, (256, 256), 4
     c = S.make_cloud(P, seed=7)
-    _batch(c, [S.make_view(0.1 + 0.7 * k, hw) for k in range(V)], gpu)          # first call of this size: un-hinted
-    views = [S.make_view(0.4 + 0.8 * k, hw) for k in range(V)]
-    args, (R, color, radii, gb, bb, ib) = _batch(c, views, gpu)                  # hinted
+    L = _lib.lib()
+    L.r2_tile_first_control(1 if tile_first else 0)
+    try:
+        _batch(c, [S.make_view(0.1 + 0.7 * k, hw) for k in range(V)], gpu)          # first call of this size: general chain
+        views = [S.make_view(0.4 + 0.8 * k, hw) for k in range(V)]
+        before = _tf_taken()
+        args, (R, color, radii, gb, bb, ib) = _batch(c, views, gpu)                  # predicted / hinted
+        torch.cuda.synchronize()
+        assert (_tf_taken() - before == 1) == tile_first, "the batched call did not take the chain it was meant to"
+        singles = [Hh.hip_raster(c, v, gpu) for v in views]
+        assert R == sum(h["num_rendered"] for h in singles)
+        g = torch.Generator().manual_seed(5)
+        dL = ((torch.rand((V,) + hw, generator=g) * 2 - 1) / float(hw[0] * hw[1])).to(gpu)
+        res = _C.rasterize_gaussians_backward_batch(args[0], radii, args[2], args[3], 1.0, args[5], args[6], args[7], args[8],
+                                                    args[9], dL, gb, R, bb, ib, args[12], False)
+        torch.cuda.synchronize()
+        d2 = res[0].cpu().numpy()
+        # the stacked point_list is the views' lists one after the other (ids = view * P + Gaussian)
+        import ctypes as C
+        bid = C.c_int(-1)
+        off = L.r2_raster_state_offset(5, P * V, R, hw[1], hw[0] * V, C.byref(bid))
+        pl = bb.cpu().numpy()[off:off + 4 * R].view(np.uint32)
+        want = np.concatenate([h["point_list"] + np.uint32(k * P) for k, h in enumerate(singles)])
+        assert np.array_equal(pl, want), "stacked point_list differs from the single views' lists"
+        for k, (v, h) in enumerate(zip(views, singles)):
+            assert np.array_equal(radii[k].cpu().numpy(), h["radii"])
+            assert np.array_equal(color[k].cpu().numpy().view(np.uint32), h["color"][0].view(np.uint32)), "image of view %d" % k
+            gs = Hh.hip_raster_backward(h, c, v, dL[k:k + 1].cpu().numpy(), gpu)
+            assert np.array_equal(d2[k].view(np.uint32), gs["dL_dmeans2D"].view(np.uint32)), "dL_dmeans2D of view %d" % k
+    finally:
+        L.r2_tile_first_control(1)
+
+
+def test_tile_first_batch_at_the_benchmarked_size(gpu):
+    """4 views of 300k Gaussians at 512^2 = 4096 stacked tiles, 1.2 M view instances: the largest batch the chain takes."""
+    P, hw, V = 300000, (512, 512), 4
+    c = S.make_cloud(P, seed=0)
+    _batch(c, [S.make_view(0.2 + 0.5 * k, hw) for k in range(V)], gpu)
+    views = [S.make_view(0.45 + 0.5 * k, hw) for k in range(V)]
+    before = _tf_taken()
+    args, (R, color, radii, gb, bb, ib) = _batch(c, views, gpu)
     torch.cuda.synchronize()
-    singles = [Hh.hip_raster(c, v, gpu) for v in views]
-    assert R == sum(h["num_rendered"] for h in singles)
-    g = torch.Generator().manual_seed(5)
-    dL = ((torch.rand((V,) + hw, generator=g) * 2 - 1) / float(hw[0] * hw[1])).to(gpu)
-    res = _C.rasterize_gaussians_backward_batch(args[0], radii, args[2], args[3], 1.0, args[5], args[6], args[7], args[8],
-                                                args[9], dL, gb, R, bb, ib, args[12], False)
-    torch.cuda.synchronize()
-    d2 = res[0].cpu().numpy()
-    for k, (v, h) in enumerate(zip(views, singles)):
+    assert _tf_taken() - before == 1
+    for k, v in enumerate(views):
+        h = Hh.hip_raster(c, v, gpu)
         assert np.array_equal(radii[k].cpu().numpy(), h["radii"])
         assert np.array_equal(color[k].cpu().numpy().view(np.uint32), h["color"][0].view(np.uint32)), "image of view %d" % k
-        gs = Hh.hip_raster_backward(h, c, v, dL[k:k + 1].cpu().numpy(), gpu)
-        assert np.array_equal(d2[k].view(np.uint32), gs["dL_dmeans2D"].view(np.uint32)), "dL_dmeans2D of view %d" % k
