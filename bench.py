@@ -236,6 +236,40 @@ class TrainIteration:
         pass
 
 
+class TrainIterationW(TrainIteration):
+    """ONE optimiser step on W views rendered by THIS GPU -- the single-GPU form of the configuration DESIGN.md section 6 states
+    for N = 8 ranks (W = 8 views per step, the four learning rates x W): W / V batched calls of V views each
+    (GaussianRasterizerBatch: r2_raster_forward_batch / _backward_batch on the tile-first chain), the image loss per view, the
+    parameter gradients of the calls accumulated by autograd, ONE TV branch, ONE Adam step.  `ops["render_batch"](b, ...)` renders
+    batch b of the view set; `ops["densify_stats"]` is fed per view (the statistics are per view, train.py:151-154)."""
+
+    def __init__(self, ops, cloud, dev, n_batches, V, W, fused_adam):
+        super().__init__(ops, cloud, dev, 1, 1, 0, False, None, fused_adam)
+        import torch
+        self.V, self.W, self.n_batches = V, W, n_batches
+        for g in self.opt.param_groups:   # the linear rule (DESIGN.md section 6): all four group learning rates x W
+            g["lr"] *= W
+        P = self.leaves[0].shape[0]
+        self.m2b = torch.zeros((V, P, 3), device=dev, requires_grad=True)
+
+    def step(self, k):
+        ops = self.ops
+        self.opt.zero_grad(set_to_none=True)
+        for c in range(self.W // self.V):
+            self.m2b.grad = None
+            x, d, s, r = self.activated()
+            imgs, radii = ops["render_batch"]((k * (self.W // self.V) + c) % self.n_batches, x, self.m2b, d, s, r)
+            loss = 0.0
+            for v in range(self.V):
+                loss = loss + ops["image_loss"](imgs[v:v + 1], v)
+            (loss * (1.0 / self.W)).backward()   # gradients of the calls accumulate in the leaves' .grad
+            for v in range(self.V):
+                ops["densify_stats"](radii[v], self.m2b.grad[v], self.max_radii2D, self.grad_accum, self.denom)
+        x, d, s, r = self.activated()
+        (0.05 * ops["tv_loss"](ops["query32"](k, x, d, s, r))).backward()
+        self.opt.step()
+
+
 def stub_ops(P, HW):
     """CPU stand-ins for the renderer pieces of TrainIteration / the sharded query (R2_BENCH_STUB=1: control flow only)."""
     import torch
@@ -297,6 +331,7 @@ def main():
     ap.add_argument("--no-forward-only", action="store_true", help="skip the forward-only section")
     ap.add_argument("--no-train-iteration", action="store_true", help="skip the whole-training-iteration section")
     ap.add_argument("--no-densify-pattern", action="store_true", help="skip the render-while-P-changes section")
+    ap.add_argument("--densify-steps", type=int, default=100, help="steps per Gaussian count in that section (reference: 100)")
     ap.add_argument("--cloud", default=None,
                     help="render a TRAINED, densified cloud instead of the synthetic one: a point_cloud.pickle in the reference's "
                          "layout (r2_gaussian_amd.model_io), or a recipe name of scripts/train_cloud.py (small | large: looked up / "
@@ -509,6 +544,33 @@ def main():
                       "accum2": dict(two_view["accum2"], views_per_rank_and_step=2, exchange="one all-reduce per step (local accumulation)"),
                       "value_is": "sync"}
 
+    # ---- the same loop with the deferred count (opt-in mode of the library, r2_defer_count_control: the forward returns a token
+    # without waiting for the device, the backward resolves it): views/s and what is left of the host's wait.  NEXT TO `value`,
+    # which stays the default (waiting) mode.
+    deferred = None
+    if not stub and world == 1 and not use_comm and not args.headline_only:
+        import ctypes as _ctq
+        Lq = _lib.lib()
+        Lq.r2_defer_count_control(1)
+        try:
+            for _ in range(10):
+                sync_runner.step(k)
+                k += 1
+            sync_runner.drain()
+            _lib.sync_wait_stats(reset=True)
+            stq = (_ctq.c_longlong * 3)()
+            Lq.r2_defer_count_stats(stq, 1)
+            dq_s, k = timed_regions(sync_runner, args.steps, repeats, k, barrier, max_over_ranks)
+            wq_us, wq_n = _lib.sync_wait_stats(reset=True)
+            Lq.r2_defer_count_stats(stq, 1)
+            deferred = summarize(dq_s, args.steps, 1)
+            deferred.update(host_wait_us_per_step=round(wq_us / max(wq_n, 1), 1), forwards_with_token=int(stq[0]),
+                            forwards_that_waited_for_a_slot=int(stq[1]), predictions_short=int(stq[2]),
+                            note="R2_DEFER_COUNT mode: state sized by the prediction + 50 %, no wait in the forward, the autograd "
+                                 "backward resolves the token (its wait is what host_wait_us_per_step now counts)")
+        finally:
+            Lq.r2_defer_count_control(0)
+
     # ---- one whole training iteration, data-parallel (TrainIteration): iterations/s next to the raster-only number
     train_it = None
     from r2_gaussian_amd import GaussianVoxelizationSettings
@@ -542,7 +604,51 @@ def main():
                              "fused L1+DSSIM, densification statistics, [P,11] all-reduce started right after the raster backward "
                              "and waited for after the 32^3 TV branch (voxelizer fwd+bwd + fused TV loss; same patch on every "
                              "rank: no exchange), gradient combine, torch.optim.Adam(fused) step")
+        if not stub and world == 1 and not use_comm:   # ... and with the deferred count (the rasterizer forward does not wait)
+            _lib.lib().r2_defer_count_control(1)
+            try:
+                for _ in range(6):
+                    ti.step(k)
+                    k += 1
+                _lib.sync_wait_stats(reset=True)
+                trd_s, k = timed_regions(ti, nti, min(repeats, 5), k, barrier, max_over_ranks)
+                wd_us, wd_n = _lib.sync_wait_stats(reset=True)
+                train_it["deferred_count"] = dict(summarize(trd_s, nti, 1), unit="iterations/s",
+                                                  host_wait_us_per_iteration=round(wd_us / max(nti * min(repeats, 5), 1), 1))
+            finally:
+                _lib.lib().r2_defer_count_control(0)
         del ti
+
+    # ---- the same iteration on W = 8 views per optimiser step rendered by one GPU (two batched calls of V = 4)
+    train_it_w8 = None
+    if ops is not None and not stub and world == 1 and not args.no_train_iteration and len(views) >= 8:
+        from r2_gaussian_amd import GaussianRasterizerBatch
+        BVw, Ww = 4, 8
+        nbw = len(views) // BVw
+        bsw = []
+        for b_ in range(nbw):
+            vs_ = views[b_ * BVw:(b_ + 1) * BVw]
+            bsw.append(GaussianRasterizerBatch(GaussianRasterizationSettings(
+                image_height=HW, image_width=HW, tanfovx=vs_[0].tanfovx, tanfovy=vs_[0].tanfovy, scale_modifier=1.0,
+                viewmatrix=torch.stack([v.world_view_transform for v in vs_]).to(dev),
+                projmatrix=torch.stack([v.full_proj_transform for v in vs_]).to(dev),
+                campos=torch.stack([v.camera_center for v in vs_]).to(dev), prefiltered=False, mode=vs_[0].mode, debug=False)))
+        ops_w = dict(ops)
+        ops_w["render_batch"] = lambda b_, x, m2, d, s_, r: bsw[b_](means3D=x, means2D=m2, opacities=d, scales=s_, rotations=r)
+        tiw = TrainIterationW(ops_w, cloud, dev, nbw, BVw, Ww, fused_adam=True)
+        for _ in range(min(args.warmup, 6)):
+            tiw.step(k)
+            k += 1
+        ntw = max(2, min(args.steps // 4, 50))
+        trw_s, k = timed_regions(tiw, ntw, min(repeats, 5), k, barrier, max_over_ranks)
+        train_it_w8 = summarize(trw_s, ntw, 1)
+        train_it_w8.update(unit="iterations/s", views_per_iteration=Ww, views_per_call=BVw,
+                           views_per_s=round(train_it_w8["value"] * Ww, 2),
+                           what="one optimiser step on W = 8 views rendered by this GPU: 2 batched calls of 4 views (tile-first chain "
+                                "over the stacked views), fused L1+DSSIM per view, gradients accumulated, densification statistics per "
+                                "view, ONE 32^3 TV branch, ONE Adam(fused) step with the four learning rates x 8 -- the single-GPU form "
+                                "of the configuration DESIGN.md section 6 states for N = 8 (there: one view per rank + one all-reduce)")
+        del tiw
 
     # ---- the full-volume query sharded by x-slab over the ranks (dist.query_sharded, test.py:105-112's 256^3 query)
     sharded = None
@@ -710,7 +816,7 @@ def main():
     if world == 1 and not args.no_densify_pattern:
         import ctypes as _ctd
         Ld = _lib.lib()
-        nsz, Kd = 25, 20
+        nsz, Kd = 25, args.densify_steps   # (the reference densifies every 100 iterations, train.py:155-168)
         sizes = sorted({int(round(P / 6.0 * (6.0 ** (i / (nsz - 1.0))))) for i in range(nsz)})
         subs = []
         for p_i in sizes:
@@ -727,13 +833,17 @@ def main():
         Ld.r2_tile_first_stats(st0, 1)
         t_cold = t_warm = 0.0
         j = 0
+        first_call_us = []   # per size: what the FIRST forward + backward at the new P costs (the call after a densification)
         for lv, m2_ in subs:
             for phase in range(2):
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                for _ in range(Kd):
+                for i_ in range(Kd):
                     dstep(lv, m2_, j)
                     j += 1
+                    if phase == 0 and i_ == 0:
+                        torch.cuda.synchronize()
+                        first_call_us.append((time.perf_counter() - t0) * 1e6)
                 torch.cuda.synchronize()
                 if phase == 0:
                     t_cold += time.perf_counter() - t0
@@ -745,6 +855,8 @@ def main():
         densify_pattern = {"sizes": [sizes[0], sizes[-1], len(sizes)], "steps_per_size": Kd,
                            "views_per_s_including_first_calls": round(nd / t_cold, 1), "views_per_s_steady": round(nd / t_warm, 1),
                            "ratio": round(t_warm / t_cold, 4),
+                           "first_call_us": {"median": round(statistics.median(first_call_us), 1), "max": round(max(first_call_us), 1),
+                                             "per_size": [round(u, 1) for u in first_call_us]},
                            "tile_first": {"taken": int(st1[0]), "general_chain": int(st1[1]), "second_pass": int(st1[2]),
                                           "thin_rerender": int(st1[3]), "seeded_from_previous_P": int(st1[4])},
                            "note": "forward + backward through the drop-in classes on %d growing prefixes of the cloud, %d steps from "
@@ -1014,7 +1126,7 @@ def main():
             cpu["note"] = "top level = the C/OpenMP port: the pure-PyTorch evaluation of this workload was not available (%s)" % (
                 "trained cloud" if args.cloud else str(pt)[:120])
     elif world > 1:
-        cpu_note = "not run for N > 1 (rank 0 at N = 1 only, as the bench contract says)"
+        cpu_note = "omitted for N > 1 (the CPU baseline is timed on rank 0 at N = 1 only, as the bench contract says)"
     if rank == 0:
         if world > 1 or use_comm:
             par = ("view-sharded dp%d: one view per rank and optimiser step, ONE RCCL all-reduce of the [P,11] gradient block per step "
@@ -1041,7 +1153,9 @@ def main():
             "overlapped": overlapped,
             "two_views_per_step": two_view,
             "sync_modes": sync_modes,
+            "deferred_count": deferred,
             "train_iteration": train_it,
+            "train_iteration_w8": train_it_w8,
             "densify_pattern": densify_pattern,
             "forward_only": fwd_only,
             "batched": batched,

@@ -341,6 +341,19 @@ R2_API void r2_depth_hint_control(int mode);
  * environment variable R2_TILE_FIRST=0 also switches it off), 2: forget the calling thread's predictions (its next call of any
  * size takes the general chain). */
 R2_API void r2_tile_first_control(int mode);
+/* Deferred num_rendered (NEW; opt-in; SURVEY.md section 7 "kill the D2H sync", RAS/rasterizer_impl.cu:279).  mode 1 (or the
+ * environment variable R2_DEFER_COUNT=1): a rasterizer forward on the tile-first chain returns WITHOUT waiting for the device --
+ * the state is sized by the prediction + 50 %, every kernel is enqueued, and the value returned in place of num_rendered is a
+ * TOKEN (>= 0x40000000) that the matching r2_raster_backward / _backward_batch accepts as its R: the backward reads the true count,
+ * which the forward's second kernel posted to pinned host memory long before (any host thread may call it).  Images, state and
+ * gradients are those of the waiting mode.  The price: a prediction that falls short cannot be repaired by a second pass any
+ * more -- the backward of such a call FAILS with R2_ERR_INVALID (the forward's image is then invalid; render the view again with
+ * the mode off), and callers that use the returned value as a count must not.  Forwards the chain does not take (first call of a
+ * size, debug mode), and all voxelizer calls, wait as before.  mode 0: off (default). */
+R2_API void r2_defer_count_control(int mode);
+/* out[0] forwards that returned a token, [1] forwards that had to wait because 64 tokens were outstanding, [2] backwards that
+ * found the prediction short.  out may be NULL (reset only). */
+R2_API void r2_defer_count_stats(long long out[3], int reset);
 /* process-wide counts since the last reset: out[0] forwards that took the tile-first chain, [1] forwards that did not (no
  * prediction yet, or beyond its limits), [2] chains enqueued a second time because the prediction fell short, [3] renders
  * repeated with the thin-Gaussian variant, [4] forwards whose prediction was seeded from another Gaussian count (the call after

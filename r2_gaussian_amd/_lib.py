@@ -42,6 +42,8 @@ _SIGNATURES = {
     "r2_knn_workspace_bytes": (C.c_size_t, [_i]),
     "r2_knn_dist2_ws": (C.c_int, [_i, _fp, _fp, _p, C.c_size_t, _p]),
     "r2_tile_first_stats": (None, [C.POINTER(C.c_longlong), _i]),
+    "r2_defer_count_control": (None, [_i]),
+    "r2_defer_count_stats": (None, [C.POINTER(C.c_longlong), _i]),
     "r2_voxel_sticks_control": (None, [_i]),
     "r2_voxel_sticks_limits": (None, [C.c_longlong, C.c_longlong]),
     "r2_voxel_sticks_stats": (None, [C.POINTER(C.c_longlong), _i]),

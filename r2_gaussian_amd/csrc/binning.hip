@@ -3,6 +3,7 @@
 // reference (RAS/rasterizer_impl.cu:116-138,275,308-316); the sort lives in radix_sort.hip.
 #include "r2_common.hpp"
 #include <chrono>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <stdarg.h>
@@ -191,15 +192,18 @@ int host_mailbox_arm(uint32_t **mailbox, uint32_t *seq)
 
 void host_words_release() { g_pinned_holder.release(); g_mailbox_holder.release(); }
 
-int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
+static int mailbox_spin(uint32_t *words, uint32_t seq, uint32_t *out, int n, hipStream_t s);
+int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s) { return mailbox_spin(g_mailbox, seq, out, n, s); }
+
+static int mailbox_spin(uint32_t *words, uint32_t seq, uint32_t *out, int n, hipStream_t s)
 {
     host_mark_wait_begin();
     const auto t0 = std::chrono::steady_clock::now();
-    volatile uint32_t *mb = g_mailbox;
+    volatile uint32_t *mb = words;
     unsigned spins = 0;
     bool drained = false;
     static const double timeout_s = [] { const char *e = getenv("R2_SYNC_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 30.0; }();
-    while (__atomic_load_n(&g_mailbox[15], __ATOMIC_ACQUIRE) != seq) {
+    while (__atomic_load_n(&words[15], __ATOMIC_ACQUIRE) != seq) {
         __builtin_ia32_pause();
         if ((++spins & 0x3FFFu) == 0u) {   // the producing kernel never ran?  (launch failure: do not spin forever)
             // a hung GPU or a stream blocked on something that never happens: give up after a wall-clock limit instead of
@@ -228,6 +232,86 @@ int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s)
     host_mark_wait_end();
     for (int i = 0; i < n; ++i) out[i] = mb[i];
     return 0;
+}
+
+// ---- deferred num_rendered (round 6; r2_defer_count_control).  A forward that does not wait for its control words leaves them in a
+// SLOT of a small process-wide pool of pinned words and returns a token naming the slot; whoever calls the matching backward -- with
+// torch that is the autograd engine's thread, not the forward's -- resolves the token there: by then the forward's second kernel
+// has long posted the words, so the wait that cost the forward ~95 of its 170 us of host time is gone, not moved.
+// Slots are handed out by one mutex-protected table; a slot whose forward has completed but whose backward never came (rendering
+// under no_grad) is recycled, least recently used first.
+namespace {
+constexpr int DEFER_SLOTS = 64;
+struct DeferSlot { uint32_t seq = 0; uint32_t cap = 0; bool busy = false; unsigned long long used = 0; };
+std::mutex g_defer_mu;
+uint32_t *g_defer_words = nullptr;   // [DEFER_SLOTS][16] pinned, never freed (process lifetime: tokens may outlive any thread)
+DeferSlot g_defer[DEFER_SLOTS];
+uint32_t g_defer_seq = 0;
+unsigned long long g_defer_tick = 0;
+}  // namespace
+
+int defer_acquire(uint32_t **mailbox, uint32_t *seq, uint32_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    if (!g_defer_words) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&g_defer_words), DEFER_SLOTS * 64,
+                          hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+            (void)hipGetLastError();
+            g_defer_words = nullptr;
+            return -1;
+        }
+        memset(g_defer_words, 0, DEFER_SLOTS * 64);
+    }
+    int pick = -1;
+    for (int i = 0; i < DEFER_SLOTS && pick < 0; ++i)
+        if (!g_defer[i].busy) pick = i;
+    if (pick < 0) {   // every slot is waiting for a backward: recycle the oldest one whose forward has posted its words
+        for (int i = 0; i < DEFER_SLOTS; ++i)
+            if (__atomic_load_n(&g_defer_words[i * 16 + 15], __ATOMIC_ACQUIRE) == g_defer[i].seq &&
+                (pick < 0 || g_defer[i].used < g_defer[pick].used))
+                pick = i;
+        if (pick < 0) return -1;   // none: the caller falls back to the waiting forward
+    }
+    if (++g_defer_seq == 0u) ++g_defer_seq;
+    g_defer[pick] = DeferSlot{g_defer_seq, cap, true, ++g_defer_tick};
+    *mailbox = g_defer_words + pick * 16;
+    *seq = g_defer_seq;
+    return DEFER_TOKEN_FLAG | (pick << 16) | (int)(g_defer_seq & 0xFFFFu);
+}
+
+// -> 0 and the words, or an error: the token is stale (its slot was recycled), or the device never posted
+int defer_resolve(int token, uint32_t *out, int n, uint32_t *cap, hipStream_t s, bool release)
+{
+    const int slot = (token >> 16) & (DEFER_SLOTS - 1);
+    uint32_t seq = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (!g_defer_words || !g_defer[slot].busy || (g_defer[slot].seq & 0xFFFFu) != (uint32_t)(token & 0xFFFF)) {
+            set_error("deferred num_rendered: stale token (the forward's slot was recycled: more than %d forwards without a backward)",
+                      DEFER_SLOTS);
+            return R2_ERR_INVALID;
+        }
+        seq = g_defer[slot].seq;
+        if (cap) *cap = g_defer[slot].cap;
+    }
+    const int rc = mailbox_spin(g_defer_words + slot * 16, seq, out, n, s);
+    if (release) {
+        std::lock_guard<std::mutex> lk(g_defer_mu);
+        if (g_defer[slot].seq == seq) g_defer[slot].busy = false;
+    }
+    return rc;
+}
+
+// non-blocking: have the words of this token arrived?  (the forward's own thread keeps its predictions current with it)
+bool defer_peek(int token, uint32_t *out, int n)
+{
+    const int slot = (token >> 16) & (DEFER_SLOTS - 1);
+    std::lock_guard<std::mutex> lk(g_defer_mu);
+    if (!g_defer_words || (g_defer[slot].seq & 0xFFFFu) != (uint32_t)(token & 0xFFFF)) return false;
+    uint32_t *w = g_defer_words + slot * 16;
+    if (__atomic_load_n(&w[15], __ATOMIC_ACQUIRE) != g_defer[slot].seq) return false;
+    for (int i = 0; i < n; ++i) out[i] = w[i];
+    return true;
 }
 
 int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t s)

@@ -261,10 +261,18 @@ int read_host_words(const uint32_t *dev_words, uint32_t *out, int n, hipStream_t
 // zero-copy variant: a kernel stores the words and then `seq` (release, system scope) at mailbox[15]; the host spins on it
 // host-side timing of a forward pass around its synchronisation point (r2_profile_host)
 void host_mark_forward_begin();
+void host_mark_wait_begin();
+void host_mark_wait_end();
 void host_mark_forward_end();
 int host_mailbox_arm(uint32_t **mailbox /* device-visible pinned host memory, 16 words */, uint32_t *seq);
 int host_mailbox_wait(uint32_t seq, uint32_t *out, int n, hipStream_t s);
 void host_words_release();   // the calling thread's pinned words (r2_thread_release; also at thread exit)
+// deferred num_rendered (binning.hip): a forward that does not wait posts its control words to a pool slot and returns a token
+// (>= DEFER_TOKEN_FLAG, still a non-negative int); the backward resolves it.  -1 from acquire: no slot, wait as usual
+constexpr int DEFER_TOKEN_FLAG = 0x40000000;
+int defer_acquire(uint32_t **mailbox, uint32_t *seq, uint32_t cap);
+int defer_resolve(int token, uint32_t *out, int n, uint32_t *cap, hipStream_t s, bool release);
+bool defer_peek(int token, uint32_t *out, int n);
 // tile ranges of the sorted list + point_list[k] = vals_unsorted[perm[k]] in the same pass
 int tile_ranges(const uint32_t *tiles_sorted, const uint32_t *perm, const uint32_t *vals_unsorted, uint32_t *point_list,
                 size_t R, uint2 *ranges, size_t T, hipStream_t s, bool ranges_zeroed = false);

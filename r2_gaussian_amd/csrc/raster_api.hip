@@ -214,6 +214,12 @@ static int raster_backward_impl(
         set_error("%s: invalid argument", what);
         return R2_ERR_INVALID;
     }
+    if (R >= DEFER_TOKEN_FLAG) {   // a deferred forward's token (r2_defer_count_control): the count is on its way, or long here
+        uint32_t true_R = 0;
+        const int rc = raster_resolve_deferred(what, R, s, &true_R);
+        if (rc) return rc;
+        R = (int)true_R;
+    }
     const RasterGeom geom = RasterGeom::carve(geom_buffer, P * V);
     const RasterBinning bin = RasterBinning::carve(binning_buffer, (size_t)R);
     { StageScope t(ST_RAS_RENDER_BWD, s);

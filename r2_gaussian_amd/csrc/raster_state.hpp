@@ -345,6 +345,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
 // a finished forward's instance count and depth-key range: the next call's prediction
 void raster_tilefirst_note(int P, int V, int W, int H, uint32_t num_rendered, bool thin, uint32_t kmax, uint32_t kmin);
 void raster_tilefirst_release();   // the calling thread's counters and predictions (r2_thread_release)
+int raster_resolve_deferred(const char *what, int token, hipStream_t s, uint32_t *num_rendered);   // see r2_defer_count_control
 int launch_raster_render_backward(const RasterGeom &g, const RasterBinning &b, const int *radii, int W, int H, int V, size_t R,
                                   const float *dL_dpix, hipStream_t s, size_t view_instances = ~(size_t)0 /* P x V */);
 

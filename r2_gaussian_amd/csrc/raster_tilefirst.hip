@@ -598,7 +598,10 @@ __global__ void __launch_bounds__(TFK_THREADS, 8) raster_tf_sort_kernel(
 // self-resetting, so no zero-fill launch precedes the forward.  Owned by the thread: freed when it exits (or on
 // r2_thread_release()); a thread that cycles through more streams than the table holds evicts the least recently used entry
 // (round 4: never freed, and the fast path silently switched itself off after 64 streams -- ADVICE r4).
-struct TFWorkspace { int dev; hipStream_t stream; TFCounters *ctr; uint32_t *nparts; bool dirty; unsigned long long used; };
+struct TFWorkspace { int dev; hipStream_t stream; TFCounters *ctr; uint32_t *nparts; bool dirty; unsigned long long used; int epoch; };
+// a deferred forward whose prediction fell short leaves its counters behind (nobody re-runs the chain): every workspace is then
+// cleaned before its next use (the backward that finds out runs on another thread: a process-wide epoch)
+std::atomic<int> g_tf_clean_epoch{0};
 struct TFWorkspaces {
     std::vector<TFWorkspace> v;
     unsigned long long tick = 0;
@@ -638,7 +641,8 @@ TFWorkspace *tf_workspace(int dev, hipStream_t s)
         (void)hipGetLastError();
         return nullptr;
     }
-    t.v.push_back(TFWorkspace{dev, s, reinterpret_cast<TFCounters *>(p), reinterpret_cast<uint32_t *>(p + sizeof(TFCounters)), true, t.tick});
+    t.v.push_back(TFWorkspace{dev, s, reinterpret_cast<TFCounters *>(p), reinterpret_cast<uint32_t *>(p + sizeof(TFCounters)), true, t.tick,
+                              g_tf_clean_epoch.load(std::memory_order_relaxed)});
     return &t.v.back();
 }
 
@@ -684,6 +688,24 @@ const TFHint *tf_hint_nearby(int V, int W, int H)
 std::atomic<long long> g_tf_taken{0}, g_tf_declined{0}, g_tf_rerun{0}, g_tf_rerender{0}, g_tf_seeded{0};
 
 std::atomic<int> g_tf_mode{-1};   // -1: not decided yet (environment), 0: off, 1: on
+std::atomic<int> g_defer_mode{-1};   // deferred num_rendered (r2_defer_count_control): -1 environment, 0 off (default), 1 on
+std::atomic<long long> g_defer_taken{0}, g_defer_no_slot{0}, g_defer_short{0};
+
+bool defer_enabled()
+{
+    int on = g_defer_mode.load(std::memory_order_relaxed);
+    if (on < 0) {
+        const char *e = getenv("R2_DEFER_COUNT");
+        on = (e && e[0] == '1') ? 1 : 0;
+        g_defer_mode.store(on, std::memory_order_relaxed);
+    }
+    return on != 0;
+}
+
+// deferred forwards of this thread whose instance count it has not seen yet: polled (non-blocking) at its next forward, so that its
+// predictions stay current although the count is resolved by the backward's thread
+struct TFPending { int token, P, V, W, H; };
+thread_local std::vector<TFPending> g_tf_pending;
 
 bool tf_enabled()
 {
@@ -740,6 +762,18 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
     }
+    for (size_t i = 0; i < g_tf_pending.size();) {
+        uint32_t pw[DW_COUNT];
+        const TFPending pn = g_tf_pending[i];
+        if (defer_peek(pn.token, pw, DW_COUNT)) {
+            raster_tilefirst_note(pn.P, pn.V, pn.W, pn.H, pw[DW_TOTAL], pw[DW_USER] != 0u, pw[DW_NMAX], ~pw[DW_NNMAX]);
+            g_tf_pending.erase(g_tf_pending.begin() + (long)i);
+        } else if (g_tf_pending.size() > 16) {
+            g_tf_pending.erase(g_tf_pending.begin() + (long)i);   // (its slot was recycled, or the device is far behind)
+        } else {
+            ++i;
+        }
+    }
     // ---- the prediction: the largest count of the thread's recent calls with this P and detector; for a P it has not rendered
     // yet (the call after a densification) the most recent call on the same detector, scaled -- same scene, more Gaussians
     uint32_t rmax = 0, kmax = 0, kmin = 0;
@@ -760,6 +794,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;   // no prediction yet: the general path, which leaves one behind
     }
+    // (deferred forwards of this thread that have completed meanwhile: their counts into the history -- done above the prediction)
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
     TFWorkspace *ws = tf_workspace(dev, s);
@@ -767,8 +802,10 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
     }
-    // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes)
-    size_t cap = (((size_t)rmax + rmax / 4 + 16384) + 65535) & ~(size_t)65535;
+    // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes); a deferred forward,
+    // which cannot repeat itself when the prediction falls short, takes + 50 %
+    const bool defer = defer_enabled();
+    size_t cap = (((size_t)rmax + (defer ? rmax / 2 : rmax / 4) + 16384) + 65535) & ~(size_t)65535;
 
     // depth slabs per tile, from an ESTIMATE of the longest tile list: a dense tile holds ~8x the mean on every scene seen so far
     // (synthetic 300k cloud: mean 1128, longest 8776; 92k trained cloud: 825 / 5856; 331k trained cloud: 3015 / 22388).  A wrong estimate costs
@@ -794,10 +831,18 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         return R2_ERR_ALLOC;
     }
     const RasterGeom geom = RasterGeom::carve(gchunk, PV, TL, wgs);
-    if (ws->dirty) R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));   // first use, or a call that failed half way
+    const int epoch = g_tf_clean_epoch.load(std::memory_order_relaxed);
+    if (ws->dirty || ws->epoch != epoch)   // first use, a call that failed half way, or a deferred forward that fell short
+        R2_HIP_TRY(hipMemsetAsync(ws->ctr, 0, sizeof(TFCounters) + 64, s));
     ws->dirty = true;
+    ws->epoch = epoch;
     uint32_t *mailbox = nullptr, mailbox_seq = 0;
-    int rc = host_mailbox_arm(&mailbox, &mailbox_seq);
+    int rc = 0, token = -1;
+    if (defer && cap < (size_t)DEFER_TOKEN_FLAG) {
+        token = defer_acquire(&mailbox, &mailbox_seq, (uint32_t)cap);
+        if (token < 0) g_defer_no_slot.fetch_add(1, std::memory_order_relaxed);
+    }
+    if (token < 0) rc = host_mailbox_arm(&mailbox, &mailbox_seq);
     if (rc) return rc;
     { StageScope t(ST_RAS_PREPROCESS, s);
     launch_raster_preprocess_tf(geom, P, V, grid, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, viewmatrix,
@@ -845,8 +890,19 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         R2_HIP_TRY(hipGetLastError());
         return 0;
     };
-    rc = enqueue(cap, thin_guess, false);
+    // (a deferred forward cannot render again when the scene turns out to hold thin Gaussians: it takes the variant that serves both)
+    rc = enqueue(cap, token >= 0 ? true : thin_guess, false);
     if (rc) return rc;
+    if (token >= 0) {
+        // ---- deferred: no wait.  The token goes back as num_rendered; the backward resolves it (raster_backward_impl)
+        ws->dirty = false;   // (a count beyond the capacity is found by the backward, which bumps the clean epoch)
+        g_tf_taken.fetch_add(1, std::memory_order_relaxed);
+        g_defer_taken.fetch_add(1, std::memory_order_relaxed);
+        g_tf_pending.push_back(TFPending{token, P, V, width, height});
+        host_mark_wait_begin();   // (r2_profile_host: a wait of zero length)
+        host_mark_wait_end();
+        return token;
+    }
     uint32_t hw[DW_COUNT] = { 0 };
     rc = host_mailbox_wait(mailbox_seq, hw, DW_COUNT, s);
     if (rc) return rc;
@@ -871,7 +927,26 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     return (int)num_rendered;
 }
 
-void raster_tilefirst_release() { g_tf_ws.release(); g_tf_hints.clear(); }
+void raster_tilefirst_release() { g_tf_ws.release(); g_tf_hints.clear(); g_tf_pending.clear(); }
+
+// the backward's side of a deferred forward: token -> the true instance count (waits for the control words, which the forward's
+// second kernel posted long ago); a count beyond the capacity the forward was launched with is an ERROR -- its kernels did nothing
+int raster_resolve_deferred(const char *what, int token, hipStream_t s, uint32_t *num_rendered)
+{
+    uint32_t hw[DW_COUNT] = { 0 }, cap = 0;
+    const int rc = defer_resolve(token, hw, DW_COUNT, &cap, s, true);
+    if (rc) return rc;
+    if (hw[DW_TOTAL] > cap) {
+        g_defer_short.fetch_add(1, std::memory_order_relaxed);
+        g_tf_clean_epoch.fetch_add(1, std::memory_order_relaxed);
+        set_error("%s: the deferred forward's state was sized for %u instances, the scene has %u: its image and state are invalid "
+                  "(R2_DEFER_COUNT / r2_defer_count_control trade the exact second pass for the missing wait; render this view again "
+                  "with the mode off)", what, cap, hw[DW_TOTAL]);
+        return R2_ERR_INVALID;
+    }
+    *num_rendered = hw[DW_TOTAL];
+    return 0;
+}
 
 }  // namespace r2
 
@@ -879,6 +954,20 @@ extern "C" void r2_tile_first_stats(long long *out, int reset)
 {
     std::atomic<long long> *c[5] = {&r2::g_tf_taken, &r2::g_tf_declined, &r2::g_tf_rerun, &r2::g_tf_rerender, &r2::g_tf_seeded};
     for (int i = 0; i < 5; ++i) {
+        if (out) out[i] = c[i]->load(std::memory_order_relaxed);
+        if (reset) c[i]->store(0, std::memory_order_relaxed);
+    }
+}
+
+extern "C" void r2_defer_count_control(int mode)
+{
+    if (mode == 0 || mode == 1) r2::g_defer_mode.store(mode, std::memory_order_relaxed);
+}
+
+extern "C" void r2_defer_count_stats(long long *out, int reset)
+{
+    std::atomic<long long> *c[3] = {&r2::g_defer_taken, &r2::g_defer_no_slot, &r2::g_defer_short};
+    for (int i = 0; i < 3; ++i) {
         if (out) out[i] = c[i]->load(std::memory_order_relaxed);
         if (reset) c[i]->store(0, std::memory_order_relaxed);
     }

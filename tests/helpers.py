@@ -45,8 +45,10 @@ def oracle_raster(O, c, v, cov3D_precomp=None, scale_modifier=1.0, render=True):
                             v.image_height, v.image_width, v.mode, render=render)
 
 
-def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
-    """Run the HIP forward through the `_C` mirror and read every private intermediate back."""
+def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0, count_of=-1):
+    """Run the HIP forward through the `_C` mirror and read every private intermediate back.  count_of: for a forward that returns
+    a deferred-count TOKEN instead of num_rendered (r2_defer_count_control): the count to read the state back with (None: take it
+    from the state's own host words); out["num_rendered"] stays what the call returned."""
     from r2_gaussian_amd import _C, _lib
     e = torch.empty(0)
     sc, q = (c.scales.to(dev), c.rotations.to(dev)) if cov3D_precomp is None else (e, e)
@@ -63,6 +65,12 @@ def hip_raster(c, v, dev, debug=False, cov3D_precomp=None, scale_modifier=1.0):
         return out
     bufs = [geom.cpu().numpy(), binning.cpu().numpy(), img.cpu().numpy()]
     L = _lib.lib()
+    if R >= 0x40000000:   # a token: the true count is in the geometry state's host words (independent of R)
+        bid0 = C.c_int(-1)
+        off0 = L.r2_raster_state_offset(15, P, 0, W, H, C.byref(bid0))
+        true_R = int(bufs[0][off0:off0 + 4].view(np.uint32)[0])
+        assert count_of is None or count_of == true_R
+        R = true_R
     T = ((W + 15) // 16) * ((H + 15) // 16)
 
     def read(which, dtype, count):

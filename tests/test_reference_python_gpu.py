@@ -127,14 +127,19 @@ def _check_render_query(pc, cam, render, query, pipe, scanner_cfg, oracle, label
            pc.rotation_activation(raw["rotation"])]
     torch.autograd.backward(act, [torch.from_numpy(ref["dL_dmeans3D"]), torch.from_numpy(ref["dL_dopacity"]).reshape(act[1].shape),
                                   torch.from_numpy(ref["dL_dscales"]), torch.from_numpy(ref["dL_drotations"])])
+    # Gaussians WITHOUT a borderline (pixel, Gaussian) pair: the plain tolerance.  Gaussians with one (a few per cent of them): their
+    # raw sums have just passed the rigorous check above (1e-4 * sum|terms| + the attributed flip budget); a pair that this
+    # implementation decided the other way shifts their parameter gradients by one whole borderline contribution, which a relative
+    # tolerance on a small gradient cannot hold -- they only get a sanity bound here.  (Which pairs flip depends on the state the 40
+    # training iterations end in, i.e. on the float association of the kernels that ran them.)
+    flagged = (f64 > 0).any(axis=1)
+    assert flagged.mean() < 0.1, "too many Gaussians with borderline pairs for this check to mean anything: %.3f" % flagged.mean()
     for n_ in raw:
         got = getattr(pc, "_" + n_).grad.cpu().numpy()
         want = raw[n_].grad.numpy()
-        # (the raw sums above are checked with the oracle's attributed flip budgets; here a pair that fell on the other side of the
-        # alpha cut-off shows as one whole borderline contribution without a budget -- the absolute term has to hold it.  Which pairs
-        # flip depends on the state the 40 training iterations end in, i.e. on the float association of the kernels that ran them:
-        # round 6's one-wave forward moved 6 of 151 077 elements to 1.3 x the former 2e-5 term.)
-        Hh.assert_close_scaled(got, want, 2e-4, label + " d/d_%s" % n_, atol_frac=5e-5)
+        Hh.assert_close_scaled(got[~flagged], want[~flagged], 2e-4, label + " d/d_%s" % n_, atol_frac=2e-5)
+        if flagged.any():
+            Hh.assert_close_scaled(got[flagged], want[flagged], 0.5, label + " d/d_%s (rows with a borderline pair)" % n_, atol_frac=1e-3)
     pc.optimizer.zero_grad(set_to_none=True)
     return pkg
 

@@ -242,3 +242,63 @@ def test_a_new_gaussian_count_is_seeded_from_the_previous_one(L, oracle, gpu):
     Hh.check_binning(t, o)
     Hh.parity_image(oracle, o, t["color"], "tile-first, seeded prediction that fell short")
 
+
+
+def test_deferred_count_returns_a_token_and_the_backward_resolves_it(L, gpu):
+    """r2_defer_count_control(1) (SURVEY 7 "kill the D2H sync", RAS/rasterizer_impl.cu:279): the forward returns
+    without waiting; what it hands back in place of num_rendered is a token that the backward turns into the count.  Image, radii,
+    state and every gradient are the waiting mode's, bit for bit; a prediction that falls short makes the BACKWARD fail loudly."""
+    import ctypes as C
+    from r2_gaussian_amd import _C, _lib
+    P = 30000
+    c = S.make_cloud(P, seed=12)
+    views = S.make_views(8, (256, 256))
+    dL = S.make_pixel_grad(256, 256).numpy()
+    Hh.hip_raster(c, views[0], gpu)                      # a first call of this size: the general chain leaves the prediction
+    ref = Hh.hip_raster(c, views[3], gpu)                # waiting mode, tile-first chain
+    assert Hh.took_tile_first(ref) and ref["num_rendered"] < 0x40000000
+    gref = Hh.hip_raster_backward(ref, c, views[3], dL, gpu)
+    st = (C.c_longlong * 3)()
+    L.r2_defer_count_stats(st, 1)
+    L.r2_defer_count_control(1)
+    try:
+        t = Hh.hip_raster(c, views[3], gpu, count_of=ref["num_rendered"])
+        assert t["num_rendered"] >= 0x40000000, "the forward did not return a token"
+        assert np.array_equal(t["color"].view(np.uint32), ref["color"].view(np.uint32)) and np.array_equal(t["radii"], ref["radii"])
+        assert np.array_equal(t["point_list"], ref["point_list"]) and np.array_equal(t["ranges"], ref["ranges"])
+        assert int(t["host_words"][0]) == ref["num_rendered"]
+        g = Hh.hip_raster_backward(t, c, views[3], dL, gpu)   # num_rendered = the token
+        for k in gref:
+            assert np.array_equal(g[k].view(np.uint32), gref[k].view(np.uint32)), k
+        L.r2_defer_count_stats(st, 0)
+        assert list(st) == [1, 0, 0]
+        # several forwards in flight before their backwards (two views per optimiser step), resolved in any order
+        ts = [Hh.hip_raster(c, views[i], gpu, count_of=None) for i in (1, 2)]
+        gs = [Hh.hip_raster_backward(ts[i], c, views[(1, 2)[i]], dL, gpu) for i in (1, 0)]
+        L.r2_defer_count_control(0)
+        for i, vi in ((1, 2), (0, 1)):
+            w = Hh.hip_raster(c, views[vi], gpu)
+            gw = Hh.hip_raster_backward(w, c, views[vi], dL, gpu)
+            got = gs[0] if i == 1 else gs[1]
+            assert np.array_equal(got["dL_dmeans3D"].view(np.uint32), gw["dL_dmeans3D"].view(np.uint32))
+        # a prediction that falls short: 30x the instances.  The deferred forward cannot repair it; its backward says so
+        big = S.make_cloud(P, seed=12, scale_mult=3.0)
+        L.r2_defer_count_control(1)
+        e = torch.empty(0)
+        v3 = views[3]
+        args = (big.xyz.to(gpu), big.density.to(gpu), big.scales.to(gpu), big.rotations.to(gpu), 1.0, e, v3.world_view_transform.to(gpu),
+                v3.full_proj_transform.to(gpu), v3.tanfovx, v3.tanfovy, v3.image_height, v3.image_width, v3.camera_center.to(gpu),
+                False, v3.mode, False)
+        Rb, _color, radii_b, gb, bb, ib = _C.rasterize_gaussians(*args)   # (its state is invalid: not read back)
+        assert Rb >= 0x40000000
+        with pytest.raises(_lib.R2HipError, match="sized for"):
+            _C.rasterize_gaussians_backward(args[0], radii_b, args[2], args[3], 1.0, e, args[6], args[7], args[8], args[9],
+                                            torch.as_tensor(dL).to(gpu), args[12], gb, Rb, bb, ib, v3.mode, False)
+        torch.cuda.synchronize()
+        L.r2_defer_count_control(0)
+        # ... and the thread's next call is none the worse for it (the counters the failed call left behind are cleaned)
+        again = Hh.hip_raster(c, views[3], gpu)
+        assert np.array_equal(again["color"].view(np.uint32), ref["color"].view(np.uint32))
+        assert np.array_equal(again["point_list"], ref["point_list"])
+    finally:
+        L.r2_defer_count_control(0)
