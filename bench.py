@@ -932,6 +932,7 @@ def main():
             import ctypes as _ct
             vstat = (_ct.c_longlong * 3)()
             _lib.lib().r2_voxel_sticks_stats(vstat, 1)
+            paths_before_vox = _lib.path_stats()
             for _ in range(3):
                 R3 = _C.voxelize_gaussians(*va)[0]
             tvs = []
@@ -981,7 +982,10 @@ def main():
                 # which binning chain the 256^3 queries above took: csrc/voxel_sticks.hip (stick-first: no global sort) or the general
                 # one (depth order + radix passes); on the stick chain the stages are preprocess = cull + count, scan = column scan +
                 # render records (one launch), duplicate = scatter, sort = per-list sort, ranges = work list
-                "binning": {"stick_chain_calls": int(vstat[0]), "left_for_general_chain": int(vstat[1]), "general_chain_calls": int(vstat[2])},
+                "binning": {"stick_chain_calls": int(vstat[0]), "left_for_general_chain": int(vstat[1]), "general_chain_calls": int(vstat[2]),
+                            # the same from the library's dispatch table (csrc/dispatch.hpp): chain taken / reason of every hand-over
+                            "paths": {k_: v_ - paths_before_vox.get(k_, 0) for k_, v_ in _lib.path_stats().items()
+                                      if k_.startswith("voxel.") and v_ != paths_before_vox.get(k_, 0)}},
                 "tv_patch_32cube_fwd_bwd_us": round(ttv * 1e6, 1), "tv_patch_us_min": round(min(ttvs) * 1e6, 1),
                 "tv_patch_us_max": round(max(ttvs) * 1e6, 1)}
 
@@ -1148,6 +1152,7 @@ def main():
                        "ranks_in_process_group": dist.get_world_size() if use_comm else 1,
                        "comm_zero_copy": stats.get("zero_copy") if use_comm else None},
             "cloud_stats": cloud_stats,
+            "paths": {k_: v_ for k_, v_ in _lib.path_stats().items() if v_},   # every forward of this process, by chain and reason
             "timing": dict(main_t, note="median of %d regions of exactly %d steps, each between barrier + synchronize, "
                                         "max over ranks" % (repeats, args.steps)),
             "overlapped": overlapped,

@@ -367,15 +367,25 @@ R2_API void r2_tile_first_stats(long long out[5], int reset);
  * and more than 8 Mi instances in all: the part-wise sort of such lists costs more than the general chain's radix passes;
  * r2_voxel_sticks_limits) continues on the general chain after the preprocess, and the calling thread remembers that for the
  * (P, grid).  Debug mode, larger grids
- * and P >= 2^29 always take the general chain.  mode 0: never, 1: whenever applicable (default; the environment variable
- * R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes; 4 / 5 (tests): lists of more than 8192
- * instances count as unsupported / are sorted in parts (default). */
+ * and P >= 2^29 always take the general chain, and so does a device that cannot give a workgroup the chain's 77.8 KB of LDS (parts
+ * with a 64 KB limit; gfx950 has 160 KB per CU) -- r2_path_stats reports it as voxel.general.device_lds.  A (P, grid) that handed
+ * over is remembered by the calling thread for its next 64 calls, then tried again.  mode 0: never, 1: whenever applicable
+ * (default; the environment variable R2_VOXEL_STICKS=0 also switches it off), 3: forget the calling thread's notes; 4 / 5
+ * (tests): lists of more than 8192 instances count as unsupported / are sorted in parts (default). */
 R2_API void r2_voxel_sticks_control(int mode);
-/* The two limits of that rule (process-wide; <= 0: the default). */
+/* The two limits of that rule (process-wide; <= 0: the default).  Every thread's notes are dropped. */
 R2_API void r2_voxel_sticks_limits(long long longest_list, long long instances);
 /* process-wide counts since the last reset: out[0] forwards that took the chain, [1] forwards that left it after its scan for
  * the general chain, [2] forwards it declined.  out may be NULL (reset only). */
 R2_API void r2_voxel_sticks_stats(long long out[3], int reset);
+
+/* Which chain a forward took, and why the others did not (csrc/dispatch.hpp states the rules in one table): process-wide counters
+ * since the last reset.  r2_path_stat_count() counters, r2_path_stat_name(i) names them ("raster.tile_first",
+ * "raster.general.no_prediction", "voxel.stick_first", "voxel.general.long_lists", "raster.event.second_pass" ...), r2_path_stats
+ * copies min(n, count) of them to out (may be NULL) and returns the count.  Results never depend on the chain. */
+R2_API int r2_path_stat_count(void);
+R2_API const char *r2_path_stat_name(int i);
+R2_API int r2_path_stats(long long *out, int n, int reset);
 
 /* Per-thread state.  The library keeps a few KB per host thread: self-resetting device counters of the tile-first rasterizer chain
  * and of the voxelizer's small-grid path and stick-first chain (one block per (device, stream) the thread has used, at most 16 of each:

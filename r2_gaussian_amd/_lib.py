@@ -48,6 +48,9 @@ _SIGNATURES = {
     "r2_voxel_sticks_limits": (None, [C.c_longlong, C.c_longlong]),
     "r2_voxel_sticks_stats": (None, [C.POINTER(C.c_longlong), _i]),
     "r2_thread_release": (None, []),
+    "r2_path_stat_count": (C.c_int, []),
+    "r2_path_stat_name": (C.c_char_p, [_i]),
+    "r2_path_stats": (C.c_int, [C.POINTER(C.c_longlong), _i, _i]),
     "r2_densify_stats": (C.c_int, [_i, _p, _fp, _fp, _fp, _fp, _p]),
     "r2_densify_scratch_bytes": (C.c_size_t, [_i]),
     "r2_densify_classify": (C.c_int, [_i, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _f, _f, _f, _p, _f, _f, _i, _f, _f, _p, _p, _p]),
@@ -123,6 +126,15 @@ def profile_enable(stages=None):
         for s in stages:
             mask |= 1 << names.index(s)
     lib().r2_profile_enable(mask)
+
+
+def path_stats(reset=False):
+    """-> {name: count} of the chain counters (csrc/dispatch.hpp): which chain every forward took and why."""
+    L = lib()
+    n = L.r2_path_stat_count()
+    buf = (C.c_longlong * n)()
+    L.r2_path_stats(buf, n, int(reset))
+    return {L.r2_path_stat_name(i).decode(): int(buf[i]) for i in range(n)}
 
 
 def sync_wait_stats(reset=True):

@@ -41,6 +41,7 @@ SOURCES = {
     "loss_ops.hip": FAST,
     "densify_ops.hip": EXACT,
     "fdk.hip": FAST,
+    "dispatch.hip": FAST,
 }
 
 

@@ -2,6 +2,7 @@
 // Host orchestration of Rasterizer::forward / backward (RAS/rasterizer_impl.cu:196-421).
 #include "raster_state.hpp"
 #include "voxel_state.hpp"
+#include "dispatch.hpp"
 
 using namespace r2;
 
@@ -52,6 +53,8 @@ static int raster_forward_impl(
             if (r >= 0) host_mark_forward_end();
             return r;
         }
+    } else {
+        path_count(PS_RAS_GENERAL_DEBUG);
     }
 
     char *gchunk = geometryBuffer(RasterGeom::carve(nullptr, PV).bytes, geometry_user);

@@ -33,6 +33,7 @@
 // buffers exactly and enqueues them again.  Results never depend on the prediction.
 // What must survive from forward to backward sits at prediction-independent offsets (RasterBinning::carve).
 #include "raster_state.hpp"
+#include "dispatch.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -119,9 +120,11 @@ __global__ void __launch_bounds__(TFS_THREADS) raster_tf_scatter_kernel(
             const uint32_t nvis = (uint32_t)(tot >> 40), any_thin = ctr->thin;
             words[DW_TOTAL] = R; words[DW_OVERFLOW] = 0u; words[DW_USER] = any_thin; words[DW_PMAX] = TF_MARK;
             words[DW_PNMAX] = 0u; words[DW_NMAX] = gkmax; words[DW_NNMAX] = gnkmin; words[DW_NVIS] = nvis;
-            mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = any_thin; mailbox[DW_PMAX] = TF_MARK;
-            mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = gkmax; mailbox[DW_NNMAX] = gnkmin; mailbox[DW_NVIS] = nvis;
-            __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (mailbox != nullptr) {   // (null on the second pass after a short prediction: the host has the totals already)
+                mailbox[DW_TOTAL] = R; mailbox[DW_OVERFLOW] = 0u; mailbox[DW_USER] = any_thin; mailbox[DW_PMAX] = TF_MARK;
+                mailbox[DW_PNMAX] = 0u; mailbox[DW_NMAX] = gkmax; mailbox[DW_NNMAX] = gnkmin; mailbox[DW_NVIS] = nvis;
+                __hip_atomic_store(&mailbox[15], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __syncthreads();
         R2_TS_AT(tilefirst, 5);
@@ -707,7 +710,7 @@ bool defer_enabled()
 struct TFPending { int token, P, V, W, H; };
 thread_local std::vector<TFPending> g_tf_pending;
 
-bool tf_enabled()
+bool tf_switched_on()
 {
     int on = g_tf_mode.load(std::memory_order_relaxed);
     if (on < 0) {
@@ -715,8 +718,12 @@ bool tf_enabled()
         on = (e && e[0] == '0') ? 0 : 1;
         g_tf_mode.store(on, std::memory_order_relaxed);
     }
+    return on != 0;
+}
+bool tf_lds_ok()
+{
     static signed char lds_state[R2_MAX_DEVICES] = {};
-    return on && TFK_LDS <= device_lds_optin_bytes() &&
+    return TFK_LDS <= device_lds_optin_bytes() &&
            allow_dynamic_lds(reinterpret_cast<const void *>(raster_tf_sort_kernel), (int)TFK_LDS, lds_state);
 }
 
@@ -750,18 +757,17 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     const int gx = (width + TILE2D - 1) / TILE2D, gy = (height + TILE2D - 1) / TILE2D;
     const size_t T = (size_t)gx * gy * (size_t)V, N = (size_t)width * height * (size_t)V;
     const size_t PVs = (size_t)P * (size_t)V;
-    if (PVs >= ((size_t)1 << 24)) {   // ids share a word with the block mask; 32-bit instance offsets
+    const TFGrid grid = tf_grid((int)std::min<size_t>(PVs, (size_t)1 << 24), device_cu_count());
+    const size_t wgs = grid.wgs;
+    // the static rule: dispatch.hpp (debug calls never get here)
+    const bool on = tf_switched_on();
+    const RasterChoice choice = raster_forward_choice((size_t)P, (size_t)V, width, height, false, on, on && tf_lds_ok(), wgs);
+    if (!choice.tile_first) {
+        path_count(choice.why);
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
     }
     const int PV = (int)PVs;
-    const TFGrid grid = tf_grid(PV, device_cu_count());
-    const size_t wgs = grid.wgs;
-    // rectangles are packed into bytes (<= 256 x 256 tiles of the stacked grid), the LDS histogram holds <= 4096 tiles
-    if (T > TF_MAX_TILES || gx > 256 || (size_t)gy * (size_t)V > 256 || wgs * T > ((size_t)1 << 25) || !tf_enabled()) {
-        g_tf_declined.fetch_add(1, std::memory_order_relaxed);
-        return TF_NOT_TAKEN;
-    }
     for (size_t i = 0; i < g_tf_pending.size();) {
         uint32_t pw[DW_COUNT];
         const TFPending pn = g_tf_pending[i];
@@ -790,7 +796,9 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         thin_guess = near->thin;
         kmax = near->kmax; kmin = near->kmin;
         g_tf_seeded.fetch_add(1, std::memory_order_relaxed);
+        path_count(PS_RAS_EVENT_SEEDED);
     } else {
+        path_count(PS_RAS_GENERAL_NO_PREDICTION);
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;   // no prediction yet: the general path, which leaves one behind
     }
@@ -799,9 +807,11 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     R2_HIP_TRY(hipGetDevice(&dev));
     TFWorkspace *ws = tf_workspace(dev, s);
     if (!ws) {
+        path_count(PS_RAS_GENERAL_NO_WORKSPACE);
         g_tf_declined.fetch_add(1, std::memory_order_relaxed);
         return TF_NOT_TAKEN;
     }
+    path_count(PS_RAS_TILE_FIRST);
     // + 25 %, in steps of 64 K instances (the allocator behind the callbacks then sees few distinct sizes); a deferred forward,
     // which cannot repeat itself when the prediction falls short, takes + 50 %
     const bool defer = defer_enabled();
@@ -822,6 +832,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         if (kmax <= kmin) d = 1u;   // no key range to lay the slabs over
         slabs.n = d;
         slabs.scale = d > 1u ? (float)d / ((float)(kmax - kmin) + 1.0f) : 0.f;
+        if (d > 1u) path_count(PS_RAS_EVENT_DEPTH_SLABS);
     }
     const size_t TL = T * slabs.n;   // lists
 
@@ -851,6 +862,9 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
 
     RasterBinning bin{};
     RasterImage img{};
+    // (post_mailbox: only the FIRST pass posts the totals to the host's mailbox -- by the second one the host has consumed them, and
+    // a late post could land in a mailbox the thread has meanwhile armed for its next forward on another stream: ADVICE r5)
+    bool post_mailbox = true;
     auto enqueue = [&](size_t capacity, bool any_thin, bool render_only) -> int {
         if (!render_only) {
             char *bchunk = binningBuffer(RasterBinning::carve(nullptr, capacity).bytes, binning_user);
@@ -868,7 +882,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
 #define R2_TF_SCATTER(SLB)                                                                                                        \
             raster_tf_scatter_kernel<SLB><<<dim3((unsigned)wgs + TFS_SERVICE), dim3(TFS_THREADS), TL * sizeof(uint32_t), s>>>(         \
                 PV, P, gy, grid.per_wg, grid.threads, gx, (uint32_t)TL, slabs, geom.tf_rect, geom.rec, geom.depth_key, geom.tiles_touched, geom.tf_wgoff, \
-                geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, mailbox, mailbox_seq,                                            \
+                geom.tf_wgmm, (uint32_t)wgs, ws->ctr, geom.host_words, post_mailbox ? mailbox : nullptr, mailbox_seq,                   \
                 (uint32_t)std::min<size_t>(capacity, 0x7FFFFFFFu), pairs, wo, img.tf_parts, (uint32_t)img.NP, img.tf_parts + img.NP,   \
                 ws->nparts)
             if (slabs.n > 1u) R2_TF_SCATTER(true);
@@ -898,6 +912,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         ws->dirty = false;   // (a count beyond the capacity is found by the backward, which bumps the clean epoch)
         g_tf_taken.fetch_add(1, std::memory_order_relaxed);
         g_defer_taken.fetch_add(1, std::memory_order_relaxed);
+        path_count(PS_RAS_EVENT_DEFERRED);
         g_tf_pending.push_back(TFPending{token, P, V, width, height});
         host_mark_wait_begin();   // (r2_profile_host: a wait of zero length)
         host_mark_wait_end();
@@ -912,12 +927,15 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
         set_error("%s: more than 2147483647 (tile, Gaussian) instances: they do not fit the 31-bit num_rendered", what);
         return R2_ERR_INVALID;
     }
+    post_mailbox = false;
     if ((size_t)num_rendered > cap) {
         g_tf_rerun.fetch_add(1, std::memory_order_relaxed);
+        path_count(PS_RAS_EVENT_SECOND_PASS);
         rc = enqueue(num_rendered, thin, false);      // the prediction fell short: exact sizes, same kernels
         if (rc) return rc;
     } else if (thin && !thin_guess) {
         g_tf_rerender.fetch_add(1, std::memory_order_relaxed);
+        path_count(PS_RAS_EVENT_THIN_RERENDER);
         rc = enqueue(cap, true, true);                // the scene holds thin Gaussians after all: render again with that variant
         if (rc) return rc;
     }

@@ -1,6 +1,7 @@
 // voxel_api.hip -- extern "C" entry points of the voxelizer (see include/r2hip.h).
 // Host orchestration of Voxelizer::forward / backward (VOX/voxelizer_impl.cu:171-389).
 #include "voxel_state.hpp"
+#include "dispatch.hpp"
 
 using namespace r2;
 
@@ -77,27 +78,31 @@ extern "C" int r2_voxel_forward_slab(
     }
     const VoxelGeom geom = VoxelGeom::carve(gchunk, P);
 
-    // small grids (the 32^3 TV patch of the training loop): survivors only, 4 launches (voxel_small.hip)
-    if (!debug) {
+    // which chain (dispatch.hpp): small grids (the 32^3 TV patch of the training loop: survivors only, 4 launches, voxel_small.hip),
+    // grids of 65 to 32 768 tiles (64^3 ... the 256^3 query: stick-first binning, no global sort, voxel_sticks.hip), or the
+    // general chain below -- also where the other two hand over to when the CALL turns out to be beyond them
+    bool preprocessed = false;   // the stick chain left after its scan (a list too long for it): the preprocess has run, un-hinted
+    const VoxelChoice choice = voxel_forward_choice(v, (size_t)P, debug != 0, voxel_small_switched_on(), voxel_small_lds_ok(),
+                                                    voxel_sticks_switched_on(), voxel_sticks_lds_ok());
+    if (choice.chain == VOX_CHAIN_SMALL) {
         const int small = voxel_forward_small(binningBuffer, binning_user, imageBuffer, image_user, geom, v, P, means3D, opacities,
                                               scales, scale_modifier, rotations, cov3D_precomp, out_volume, radii_x, radii_y, radii_z, s);
         if (small != VOX_SMALL_NOT_TAKEN) {
             host_mark_forward_end();
             return small;
         }
-    }
-
-    // grids of 65 to 32 768 tiles (64^3 ... the 256^3 query): stick-first binning, no global sort (voxel_sticks.hip)
-    bool preprocessed = false;   // that chain left after its scan (a list too long for it): the preprocess has run, un-hinted
-    if (!debug) {
+    } else if (choice.chain == VOX_CHAIN_STICKS) {
         const int st = voxel_forward_sticks(binningBuffer, binning_user, imageBuffer, image_user, geom, v, P, means3D, opacities, scales,
-                                            scale_modifier, rotations, cov3D_precomp, out_volume, radii_x, radii_y, radii_z, s);
+                                            scale_modifier, rotations, cov3D_precomp, out_volume, radii_x, radii_y, radii_z,
+                                            choice.stick_shift, s);
         if (st == VOX_STICKS_FALLBACK) {
             preprocessed = true;
         } else if (st != VOX_STICKS_NOT_TAKEN) {
             host_mark_forward_end();
             return st;
         }
+    } else {
+        path_count(choice.why);
     }
 
     // binning, first half (see raster_api.hip): order of the Gaussians by the bits of world z (the reference's low sort

@@ -17,6 +17,7 @@
 // instead of 11, none of them over more than the survivors except the preprocess.  Totals beyond what the path holds (LDS sort,
 // temp sizes) send the call back to the general path.
 #include "voxel_state.hpp"
+#include "dispatch.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -244,7 +245,10 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
 // one 64-byte counter block per (host thread, device, stream), owned by the thread: freed when it exits or on
 // r2_thread_release(); a thread that cycles through more streams than the table holds evicts the least recently used entry
 // (round 4: never freed, and the path switched itself off for the thread after 256 streams -- ADVICE r4)
-struct SmallCounter { int dev; hipStream_t stream; unsigned long long *ptr; unsigned long long used; };
+// dirty: a chain armed the block's counters and has not yet seen them reset by its own kernels (set before the first kernel that
+// bumps them, cleared after the host has read the totals): found dirty by the next call -- one that aborted half way -- the block is
+// zero-filled first (the stick chain's counters had no such recovery)
+struct SmallCounter { int dev; hipStream_t stream; unsigned long long *ptr; unsigned long long used; bool dirty; };
 struct SmallCounters {
     std::vector<SmallCounter> v;
     unsigned long long tick = 0;
@@ -271,7 +275,14 @@ unsigned long long *small_counter_for(int dev, hipStream_t s)
     SmallCounters &t = g_small_counters;
     ++t.tick;
     for (SmallCounter &c : t.v)
-        if (c.dev == dev && c.stream == s) { c.used = t.tick; return c.ptr; }
+        if (c.dev == dev && c.stream == s) {
+            c.used = t.tick;
+            if (c.dirty) {
+                if (hipMemsetAsync(c.ptr, 0, 64, s) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            }
+            c.dirty = true;   // until voxel_counter_block_clean()
+            return c.ptr;
+        }
     if (t.v.size() >= SMALL_MAX_COUNTERS) {
         size_t lru = 0;
         for (size_t i = 1; i < t.v.size(); ++i)
@@ -289,22 +300,31 @@ unsigned long long *small_counter_for(int dev, hipStream_t s)
         (void)hipFree(p);
         return nullptr;
     }
-    t.v.push_back(SmallCounter{dev, s, p, t.tick});
+    t.v.push_back(SmallCounter{dev, s, p, t.tick, true});
     return p;
 }
 
-bool small_enabled()
+}  // namespace
+
+// the calling thread's block for (dev, s) has been through a whole call: its kernels have put the zeros back
+void voxel_counter_block_clean(int dev, hipStream_t s)
 {
-    // R2_VOXEL_SMALL=0 switches the path off; more than 64 KB of LDS per workgroup (gfx950: 160 KB per CU) has to be asked for
-    static const bool on = [] {
-        const char *e = getenv("R2_VOXEL_SMALL");
-        return !(e && e[0] == '0');
-    }();
-    static signed char lds_state[R2_MAX_DEVICES] = {};
-    return on && allow_dynamic_lds(reinterpret_cast<const void *>(voxel_small_lists_kernel), (int)SL_LDS_BYTES, lds_state);
+    for (SmallCounter &c : g_small_counters.v)
+        if (c.dev == dev && c.stream == s) c.dirty = false;
 }
 
-}  // namespace
+bool voxel_small_switched_on()
+{
+    static const bool on = [] { const char *e = getenv("R2_VOXEL_SMALL"); return !(e && e[0] == '0'); }();   // R2_VOXEL_SMALL=0: off
+    return on;
+}
+bool voxel_small_lds_ok()
+{
+    // more than 64 KB of LDS per workgroup (gfx950: 160 KB per CU) has to be asked for
+    static signed char lds_state[R2_MAX_DEVICES] = {};
+    return SL_LDS_BYTES <= device_lds_optin_bytes() &&
+           allow_dynamic_lds(reinterpret_cast<const void *>(voxel_small_lists_kernel), (int)SL_LDS_BYTES, lds_state);
+}
 
 int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                         const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
@@ -316,11 +336,14 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
     // the preprocess packs {workgroups done : 12 | survivors : 20 | rows : 32} into one 64-bit atomic: P < 2^20 keeps every field
     // inside its bits whatever the scene (survivors <= P, workgroups = P / 1024 < 2^10, rows <= 64 tiles x P < 2^26)
     // (x-slab calls: the survivor kernel below rebuilds the tile cube from the radii, without the slab's clip -- general chain)
-    if (T > VOX_SMALL_MAX_TILES || v.gx > 8 || v.gy > 8 || v.gz > 8 || P >= (1 << 20) || v.is_slab() || !small_enabled()) return VOX_SMALL_NOT_TAKEN;
+    // (whether a call comes here at all: voxel_forward_choice, dispatch.hpp)
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
     unsigned long long *const g_small_counter = small_counter_for(dev, s);
-    if (!g_small_counter) return VOX_SMALL_NOT_TAKEN;
+    if (!g_small_counter) {
+        path_count(PS_VOX_GENERAL_NO_WORKSPACE);
+        return VOX_SMALL_NOT_TAKEN;
+    }
     uint4 *surv = depth_order_slots(geom.dorder_temp, (size_t)P);
     const SmallTmp tmp = SmallTmp::carve(geom.psort_temp, geom.psort_bytes);
     uint32_t *mailbox = nullptr, seq = 0;
@@ -346,7 +369,12 @@ int voxel_forward_small(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_
     }
     const size_t NW = R / vox_chunk_for(v.gy, v.gz) + T;
     // rare (a patch that most Gaussians reach): the general path; the kernel above has seen the same totals and done nothing
-    if (nsurv > VOX_SMALL_MAX_SURVIVORS || R > tmp.cap_R || NW > tmp.cap_work) return VOX_SMALL_NOT_TAKEN;
+    voxel_counter_block_clean(dev, s);   // (the preprocess's last workgroup has reset the counter; the lists kernel resets its own)
+    if (nsurv > VOX_SMALL_MAX_SURVIVORS || R > tmp.cap_R || NW > tmp.cap_work) {
+        path_count(PS_VOX_GENERAL_SMALL_OVERFLOW);
+        return VOX_SMALL_NOT_TAKEN;
+    }
+    path_count(PS_VOX_SMALL_GRID);
     char *bchunk = binningBuffer(VoxelBinning::carve(nullptr, R).bytes, binning_user);
     char *ichunk = imageBuffer(VoxelImage::carve(nullptr, T, V, R, false, vox_chunk_for(v.gy, v.gz)).bytes, image_user);
     if (!bchunk || !ichunk) {

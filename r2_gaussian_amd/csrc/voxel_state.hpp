@@ -265,6 +265,12 @@ constexpr uint32_t VOX_STICKS_MARK = 0x571Cu;   // DW_USER word of a state produ
 void voxel_sticks_release();   // the calling thread's notes about that chain (r2_thread_release)
 // 64 bytes of device memory, zero between calls, owned by the calling thread for (current device, stream); nullptr: none to be had
 unsigned long long *voxel_small_counter_block(int dev, hipStream_t s);
+void voxel_counter_block_clean(int dev, hipStream_t s);   // ... and its kernels have put the zeros back (else the next call zero-fills it)
+// switches and device requirements of the two fast chains, for voxel_forward_choice (dispatch.hpp)
+bool voxel_small_switched_on();
+bool voxel_small_lds_ok();
+bool voxel_sticks_switched_on();
+bool voxel_sticks_lds_ok();
 // the preprocess as two kernels: (1) everything the binning needs + the per-(workgroup, list) instance counts of the stick-first
 // chain (lists = tile id >> shift; H[workgroup][stride], wgtot[workgroup], the call's totals into ctr), (2) the render records,
 // in one launch with the column scan of H (whose last workgroup posts the totals to the host mailbox)
@@ -277,7 +283,7 @@ int launch_voxel_scan_records(const VoxelGeom &g, const VoxelGrid &v, int P, con
 int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                          const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                          const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s);
+                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, uint32_t stick_shift, hipStream_t s);
 int launch_voxel_duplicate(const VoxelGeom &g, const VoxelBinning &b, const VoxelGrid &v, int P, const int *radii_x,
                            const int *radii_y, const int *radii_z, const uint32_t *nvis, hipStream_t s, uint2 *zero_ranges = nullptr, size_t zero_T = 0);
 // the seven gradient arrays of the voxelizer backward, for a kernel that zero-fills them

@@ -36,6 +36,7 @@
 //     5. vox_stick_sort_kernel                       per-list sort, point_list, tiles, ranges
 //     6. launch_build_work (binning.hip)             the render kernel's work list from the ranges, as in the general chain
 #include "voxel_state.hpp"
+#include "dispatch.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -705,12 +706,21 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
 
 // ---- host side
 // what the thread has learnt about a (P, grid): a stick list too long for the sort kernel -> the general chain from then on
-struct VSNote { int P, nx, ny, nz; bool bad; unsigned long long used; };
+// The note ages: after VS_NOTE_RETRY declined calls the chain is tried again -- the cloud behind a (P, grid) changes
+// while it trains -- and r2_voxel_sticks_limits drops every thread's notes (a process-wide epoch).
+struct VSNote { int P, nx, ny, nz; bool bad; unsigned long long used; uint32_t declined; };
 thread_local std::vector<VSNote> g_vs_notes;
 thread_local unsigned long long g_vs_tick = 0;
+thread_local int g_vs_notes_epoch = 0;
+std::atomic<int> g_vs_epoch{0};
+constexpr uint32_t VS_NOTE_RETRY = 64;
 
 VSNote *vs_note(int P, const VoxelGrid &v, bool create)
 {
+    if (const int e = g_vs_epoch.load(std::memory_order_relaxed); e != g_vs_notes_epoch) {   // the limits changed: start over
+        g_vs_notes.clear();
+        g_vs_notes_epoch = e;
+    }
     for (VSNote &n : g_vs_notes)
         if (n.P == P && n.nx == v.nx && n.ny == v.ny && n.nz == v.nz) { n.used = ++g_vs_tick; return &n; }
     if (!create) return nullptr;
@@ -720,7 +730,7 @@ VSNote *vs_note(int P, const VoxelGrid &v, bool create)
             if (g_vs_notes[i].used < g_vs_notes[lru].used) lru = i;
         g_vs_notes.erase(g_vs_notes.begin() + (long)lru);
     }
-    g_vs_notes.push_back(VSNote{P, v.nx, v.ny, v.nz, false, ++g_vs_tick});
+    g_vs_notes.push_back(VSNote{P, v.nx, v.ny, v.nz, false, ++g_vs_tick, 0u});
     return &g_vs_notes.back();
 }
 
@@ -730,20 +740,26 @@ std::atomic<long long> g_vs_taken{0}, g_vs_fallback{0}, g_vs_declined{0};
 constexpr long long VS_LONG_LIST = 4 * 5120, VS_LONG_SCENE = 8ll << 20;
 std::atomic<long long> g_vs_long_list{VS_LONG_LIST}, g_vs_long_scene{VS_LONG_SCENE};
 std::atomic<int> g_vs_no_parts{0};   // tests: treat a list beyond one workgroup's capacity as unsupported (the fallback's path)
-std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1 (or 2): every grid it can serve
+std::atomic<int> g_vs_mode{-1};   // -1: not decided yet (environment), 0: off, 1: every grid it can serve
 
 int vs_mode()
 {
     int m = g_vs_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char *e = getenv("R2_VOXEL_STICKS");
-        m = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+        m = (e && e[0] == '0') ? 0 : 1;
         g_vs_mode.store(m, std::memory_order_relaxed);
     }
     return m;
 }
 
-bool vs_lds_ok()
+}  // namespace
+
+bool voxel_sticks_switched_on() { return vs_mode() != 0; }
+
+// The sort kernel needs VSK_LDS = 77.8 KB of dynamic LDS per workgroup: a device whose opt-in limit is below that (64 KB parts)
+// cannot run the chain -- voxel_forward_choice then reports voxel.general.device_lds (r2_path_stats) and the general chain serves.
+bool voxel_sticks_lds_ok()
 {
     static signed char lds_state[R2_MAX_DEVICES] = {}, lds_state2[R2_MAX_DEVICES] = {};
     return VSK_LDS <= device_lds_optin_bytes() &&
@@ -751,27 +767,25 @@ bool vs_lds_ok()
            allow_dynamic_lds(reinterpret_cast<const void *>(vox_stick_sort_kernel<true>), (int)VSK_LDS, lds_state2);
 }
 
-}  // namespace
-
 int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc_fn imageBuffer, void *image_user,
                          const VoxelGeom &geom, const VoxelGrid &v, int P, const float *means3D, const float *opacities,
                          const float *scales, float scale_modifier, const float *rotations, const float *cov3D_precomp,
-                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, hipStream_t s)
+                         float *out_volume, int *radii_x, int *radii_y, int *radii_z, uint32_t sh /* tiles per stick = 2^sh */,
+                         hipStream_t s)
 {
     const size_t T = (size_t)v.gx * v.gy * v.gz;
     const size_t V = (size_t)v.nx * v.ny * v.nz;
-    const int mode = vs_mode();
-    uint32_t sh = 0;
-    while (sh <= VS_MAX_SHIFT && ((T + ((size_t)1 << sh) - 1) >> sh) > VS_MAX_LISTS) ++sh;
-    // ids share a word with the tile-in-stick bits; the cube packs tile coordinates into 16 bits; 32-bit instance offsets
-    if (mode == 0 || T <= VOX_SMALL_MAX_TILES || sh > VS_MAX_SHIFT || P >= (1 << VS_ID_BITS) ||
-        v.gx > 65535 || v.gy > 65535 || v.gz > 65535 || !vs_lds_ok()) {
-        g_vs_declined.fetch_add(1, std::memory_order_relaxed);
-        return VOX_STICKS_NOT_TAKEN;
-    }
-    if (const VSNote *n = vs_note(P, v, false); n && n->bad) {
-        g_vs_declined.fetch_add(1, std::memory_order_relaxed);
-        return VOX_STICKS_NOT_TAKEN;
+    // (whether a call comes here at all, and its stick width: voxel_forward_choice, dispatch.hpp)
+    static_assert(VS_MAX_SHIFT == DISPATCH_VOX_STICK_MAX_SHIFT && VS_MAX_LISTS == DISPATCH_VOX_STICK_LISTS &&
+                  ((size_t)1 << VS_ID_BITS) == DISPATCH_VOX_STICK_P, "dispatch.hpp states this chain's limits");
+    if (VSNote *n = vs_note(P, v, false); n && n->bad) {
+        if (++n->declined < VS_NOTE_RETRY) {
+            path_count(PS_VOX_GENERAL_REMEMBERED);
+            g_vs_declined.fetch_add(1, std::memory_order_relaxed);
+            return VOX_STICKS_NOT_TAKEN;
+        }
+        n->bad = false;   // try again: the cloud behind this (P, grid) may have changed
+        n->declined = 0u;
     }
     const uint32_t NL = (uint32_t)((T + ((size_t)1 << sh) - 1) >> sh);
     uint32_t stride = 32;
@@ -781,8 +795,9 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     const uint32_t NW = grid.wgs;   // <= st.NW rows
     int dev = 0;
     R2_HIP_TRY(hipGetDevice(&dev));
-    VSCounters *ctr = reinterpret_cast<VSCounters *>(voxel_small_counter_block(dev, s));
+    VSCounters *ctr = reinterpret_cast<VSCounters *>(voxel_small_counter_block(dev, s));   // (zero-filled first if a call left it dirty)
     if (!ctr) {
+        path_count(PS_VOX_GENERAL_NO_WORKSPACE);
         g_vs_declined.fetch_add(1, std::memory_order_relaxed);
         return VOX_STICKS_NOT_TAKEN;
     }
@@ -808,6 +823,7 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     uint32_t hw[DW_COUNT] = { 0 };
     rc = host_mailbox_wait(seq, hw, DW_COUNT, s);
     if (rc) return rc;
+    voxel_counter_block_clean(dev, s);   // the scan's last workgroup has posted the totals and put the zeros back
     const uint32_t num_rendered = hw[DW_TOTAL], longest = hw[DW_PMAX];
     if (num_rendered > 0x7FFFFFFFu) {
         set_error("r2_voxel_forward: %u (tile, Gaussian) instances do not fit the 31-bit num_rendered", num_rendered);
@@ -829,7 +845,10 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     const bool large = (long long)longest > g_vs_long_list.load(std::memory_order_relaxed) &&
                        (long long)num_rendered > g_vs_long_scene.load(std::memory_order_relaxed);
     if (large || parts_bound > st.bigcap || (g_vs_no_parts.load(std::memory_order_relaxed) && longest > VSK_BIG_CAP)) {
-        vs_note(P, v, true)->bad = true;
+        VSNote *n = vs_note(P, v, true);
+        n->bad = true;
+        n->declined = 0u;
+        path_count(PS_VOX_GENERAL_LONG_LISTS);
         g_vs_fallback.fetch_add(1, std::memory_order_relaxed);
         return VOX_STICKS_FALLBACK;
     }
@@ -877,6 +896,7 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     launch_voxel_render_forward(geom, bin, img, v, out_volume, false, s); }
     R2_HIP_TRY(hipGetLastError());
     g_vs_taken.fetch_add(1, std::memory_order_relaxed);
+    path_count(PS_VOX_STICK_FIRST);
     return (int)num_rendered;
 }
 
@@ -897,11 +917,12 @@ extern "C" void r2_voxel_sticks_limits(long long longest_list, long long instanc
 {
     r2::g_vs_long_list.store(longest_list > 0 ? longest_list : r2::VS_LONG_LIST, std::memory_order_relaxed);
     r2::g_vs_long_scene.store(instances > 0 ? instances : r2::VS_LONG_SCENE, std::memory_order_relaxed);
+    r2::g_vs_epoch.fetch_add(1, std::memory_order_relaxed);   // what the threads remember was decided under the old limits
 }
 
 extern "C" void r2_voxel_sticks_control(int mode)
 {
-    if (mode >= 0 && mode <= 2) r2::g_vs_mode.store(mode, std::memory_order_relaxed);
+    if (mode == 0 || mode == 1) r2::g_vs_mode.store(mode, std::memory_order_relaxed);
     if (mode == 3) r2::g_vs_notes.clear();   // the calling thread's notes
     if (mode == 4 || mode == 5) r2::g_vs_no_parts.store(mode == 4 ? 1 : 0, std::memory_order_relaxed);   // tests
 }

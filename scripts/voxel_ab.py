@@ -1,6 +1,6 @@
 """256^3 query of the benchmark cloud on the general binning chain and on the stick-first chain (csrc/voxel_sticks.hip), alternating
 on ONE box: ms per call (median of 5 x n calls, as bench.py times it), per-stage times of the same call, and the two volumes compared
-bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000 | small | large] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes; 2 = every grid)"""
+bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000 | small | large] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes)"""
 import ctypes as C
 import statistics
 import sys

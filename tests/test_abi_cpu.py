@@ -108,3 +108,16 @@ def test_compiled_torch_boundary_loads_and_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         sh.rasterize_gaussians(torch.zeros(4, 3), torch.ones(4, 1), torch.zeros(4, 3), torch.zeros(4, 4), 1.0,
                                torch.Tensor([]), torch.eye(4), torch.eye(4), 1.0, 1.0, 8, 8, torch.zeros(3), False, 0, False, 0)
+
+
+def test_path_stat_names_cover_every_counter():
+    """r2_path_stats (csrc/dispatch.hpp): every counter has a distinct name of the form operator.chain[.reason]."""
+    from r2_gaussian_amd import _lib
+    L = _lib.lib()
+    n = L.r2_path_stat_count()
+    names = [L.r2_path_stat_name(i) for i in range(n)]
+    assert n > 20 and all(names) and len(set(names)) == n
+    assert all(nm.decode().split(".")[0] in ("raster", "voxel") for nm in names)
+    assert L.r2_path_stat_name(n) is None
+    st = _lib.path_stats()
+    assert set(st) == {nm.decode() for nm in names} and all(v >= 0 for v in st.values())
