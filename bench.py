@@ -52,7 +52,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 # stage (r2_profile_* name) -> kernel name in the rocprofv3 / PMC summaries
 STAGE_KERNEL = {
     "raster.render_bwd": "r2::raster_render_backward_kernel<false>",
-    "raster.render_fwd": "r2::raster_render_forward_kernel<false, true, false>",
+    "raster.render_fwd": "r2::raster_render_forward_wave_kernel<false, false>",   # round 6: the one-wave kernel
     "raster.geom_bwd": "r2::raster_geom_backward_kernel<false>",
     # (tile-first binning chain, rounds 4-5; the general chain's kernels are r2::raster_preprocess_kernel / raster_emit_hist_kernel)
     "raster.preprocess": "r2::raster_preprocess_tf_kernel",
