@@ -11,7 +11,7 @@ std::atomic<long long> g_path[PS_COUNT];
 const char *const PATH_NAMES[PS_COUNT] = {
     "raster.tile_first", "raster.general.debug", "raster.general.switched_off", "raster.general.grid", "raster.general.instances",
     "raster.general.device_lds", "raster.general.no_prediction", "raster.general.no_workspace", "raster.event.seeded",
-    "raster.event.second_pass", "raster.event.thin_rerender", "raster.event.depth_slabs", "raster.event.deferred",
+    "raster.event.second_pass", "raster.event.depth_slabs", "raster.event.deferred",
     "voxel.small_grid", "voxel.stick_first", "voxel.general.debug", "voxel.general.switched_off", "voxel.general.grid",
     "voxel.general.slab", "voxel.general.instances", "voxel.general.device_lds", "voxel.general.no_workspace",
     "voxel.general.remembered", "voxel.general.long_lists", "voxel.general.small_overflow",

@@ -31,7 +31,6 @@ enum PathStat {
     PS_RAS_GENERAL_NO_WORKSPACE,    //   the per-(thread, device, stream) counter block could not be had
     PS_RAS_EVENT_SEEDED,            // events of the tile-first chain: prediction seeded from another Gaussian count
     PS_RAS_EVENT_SECOND_PASS,       //   prediction short: chain enqueued again with the exact size
-    PS_RAS_EVENT_THIN_RERENDER,     //   thin Gaussians found after the render variant was chosen: rendered again
     PS_RAS_EVENT_DEPTH_SLABS,       //   lists cut into depth slabs (long lists expected)
     PS_RAS_EVENT_DEFERRED,          //   returned a token instead of waiting (r2_defer_count_control)
     // voxelizer forward

@@ -195,7 +195,7 @@ static int raster_forward_impl(
     { StageScope t(ST_RAS_RENDER_FWD, s);
     // single-pass sort: the tile's last work item (or the combine kernel) also writes tiles[k] for the backward
     launch_raster_render_forward(geom, bin, img, width, height, V, out_color, debug != 0, tile_counts ? bin.tiles : nullptr,
-                                 /*any_thin=*/hw[DW_USER] != 0, /*fused_combine=*/work_built && debug == 0, s, nullptr, nullptr, (size_t)PV); }
+                                 /*fused_combine=*/work_built && debug == 0, s, nullptr, nullptr, (size_t)PV); }
     R2_STAGE_CHECK(debug, s, "render");
     // the next call's prediction (visible keys are positive floats: their range is the P class of the host words)
     raster_tilefirst_note(P, V, width, height, num_rendered, hw[DW_USER] != 0, hw[DW_PMAX], ~hw[DW_PNMAX]);

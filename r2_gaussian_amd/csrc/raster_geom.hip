@@ -171,12 +171,17 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
     R2_TS_AT(geom, 0);
     uint32_t key = DEPTH_CULLED_KEY;
     uint2 bt = make_uint2(0u, 0u);
-    uint32_t rect = 0u;
+    uint32_t rect = 0u, thin = 0u;
     if (idx < P * V) {
         const int v = V == 1 ? 0 : idx / P;
         raster_preprocess_one(idx, idx - v * P, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, views + 16 * v,
                               projs + 16 * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy, radii, rec, depth_key, cov3Ds,
-                              tiles_touched, op_mu, thin_flag, reg, key, bt, rect);
+                              tiles_touched, op_mu, &thin, reg, key, bt, rect);
+    }
+    // how many Gaussians need the re-anchored row recurrence: a COUNT (one atomic per wave that holds any), like the tile-first chain's
+    if (thin_flag != nullptr) {
+        const uint32_t nthin = (uint32_t)__popcll(__ballot(thin != 0u));
+        if (nthin != 0u && (threadIdx.x & 63) == 0) atomicAdd(thin_flag, nthin);
     }
     R2_TS_AT(geom, 1);
     depth_register_end(reg, (uint32_t)idx, key, bt, rect);
@@ -278,7 +283,12 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
         nkmn = max(nkmn, (uint32_t)__shfl_xor(nkmn, d));
     }
     if (lane == 63) { s_wv[wave] = nvis; s_kmx[wave] = kmx; s_nkmn[wave] = nkmn; }
-    if (__any(thin != 0u) && lane == 0) s_thin = 1u;   // benign race: everybody stores 1
+    // how many Gaussians need the re-anchored row recurrence (round 6: a COUNT -- the forward's plain variant serves a few of them
+    // through its exact path; only a scene with many takes the re-anchoring variant, see raster_forward_tilefirst)
+    {
+        const uint32_t nthin = (uint32_t)__popcll(__ballot(thin != 0u));
+        if (nthin != 0u && lane == 0) atomicAdd(&s_thin, nthin);
+    }
     R2_TS_AT(geom, 11);
     __syncthreads();                           // the histogram is complete; wave sums are in place
     R2_TS_AT(geom, 12);
@@ -297,7 +307,7 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
         // (its result is consumed at the very end: the round trip of this same-address atomic -- every workgroup bumps it --
         // runs behind the per-tile atomics below)
         base_old = atomicAdd(&ctr->total, ((unsigned long long)tv << 40) | (unsigned long long)tn);
-        if (s_thin) __hip_atomic_store(&ctr->thin, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (s_thin) atomicAdd(&ctr->thin, s_thin);
         // the workgroup's key range: one slot per workgroup, reduced by the next kernel (atomicMax on ONE word from every
         // workgroup was measured: +5 us on the kernel, same-address atomics retire at ~90 per microsecond)
         uint32_t a = 0u, b = 0u;

@@ -51,12 +51,14 @@ namespace r2 {
 // without a finite culling box (conic not safely positive definite), are evaluated exactly, pixel by pixel.
 constexpr int FWD_BATCH = 256;          // list entries staged per round: one per thread of the workgroup
 
-// any4 (wave-uniform) / need4 (per lane): re-anchor the recurrence at pixel 4 for lanes whose Gaussian is too thin for 7
-// steps.  The re-anchor sits inside the row and does not touch the accumulators, so the three variants (8-step, 4-step,
-// exact) cost one shared code body + one exact body instead of three 64-accumulator bodies.
+// Two bodies: the 8-step row recurrence, and the exact per-pixel evaluation for entries the recurrence is not safe for (row_tier >= 1).
+// (Rounds 1-5 had a third, the recurrence re-anchored at pixel 4 for row_tier == 1, compiled into a second kernel variant that the host
+// chose when the previous call had seen a thin Gaussian -- and rendered AGAIN with when it had guessed wrong: 430 of 29 000 forwards of a
+// bench run.  A choice made from a count over the call cannot be the same for a batch of views and for its single views, whose images
+// must agree bit for bit.  Round 6: one variant; thin Gaussians -- a handful per view on the synthetic scene, none on the trained clouds
+// -- take the exact path.  The backward keeps its re-anchored tier: there the choice follows the call's device-side flag.)
 template <bool EXACT>
-__device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64],
-                                         bool any4 = false, bool need4 = false)
+__device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, float x0, float y0, float (&acc)[64])
 {
     const float dx0 = a.x - x0;
     const float k1 = a.z * (1.0f - 2.0f * dx0);                       // log2 of alpha(1)/alpha(0), minus B2*dy
@@ -83,18 +85,8 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
         } else {
             float g = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdl);
             float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
-            float g4 = 0.f, rt4 = 0.f;
-            if (any4) {   // wave-uniform branch, outside the pixel loop (which stays one basic block)
-                const float dxs = dx0 - (float)(SUB2D / 2);
-                g4 = __builtin_amdgcn_exp2f(dxs * (a.z * dxs + bdy) + cdl);
-                rt4 = __builtin_amdgcn_exp2f(fminf(k1 + (float)SUB2D * a.z - bdy, 120.0f));
-            }
 #pragma unroll
             for (int c = 0; c < SUB2D; ++c) {
-                if (c == SUB2D / 2) {   // compile-time: two selects per row
-                    g = need4 ? g4 : g;
-                    rt = need4 ? rt4 : rt;
-                }
                 // power <= 0 holds: positive definite conic.  (The EXEC-mask form of this -- v_cmpx + add + s_mov exec, 2 VALU
                 // instead of 3 -- gains 2.7 us in the backward, which is issue-bound; here it was measured twice, rounds 1
                 // and 2: 1 us SLOWER.  This kernel waits on latency, not on the VALU.)
@@ -116,12 +108,10 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
     }
 }
 
-// ANY4: the scene holds Gaussians that need the re-anchored recurrence (flag raised by the preprocess kernel, read by
-// the host at the forward's synchronisation point); scenes without them run the variant without re-anchoring code.
 // FUSED: the work item that is the LAST of its tile to finish adds the tile's partial images in list order and writes the
 // image (and the backward's per-instance tile ids), instead of a separate combine launch; empty tiles are extra work items
 // {tile, 0, 0, 0} that just write zeros.
-template <bool ANY4, bool FUSED, bool MV>
+template <bool FUSED, bool MV>
 __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile,
     uint32_t T, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, int gx, int gy,
@@ -207,10 +197,9 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
             // such an entry pay for the two extra exps per row).  Tier 2 (exact) entries contribute 0
             // here (L = -inf) and are evaluated by a second in-place pass, only if the wave holds any.
             const int tier = (head + lane < cnt) ? row_tier(ea.z, eb.y, eb.z) : 0;
-            const bool exact = tier == 2;
+            const bool exact = tier >= 1;   // (see fwd_item)
             const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
-            if (ANY4) fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc, __any(tier == 1), tier == 1);
-            else fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+            fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
             if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
         }
     }
@@ -305,7 +294,7 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
 #ifndef R2_EXP_FWD_OCC
 #define R2_EXP_FWD_OCC 4
 #endif
-template <bool ANY4, bool MV>
+template <bool MV>
 __global__ void __launch_bounds__(64, R2_EXP_FWD_OCC) raster_render_forward_wave_kernel(
     const uint2 *__restrict__ ranges, const uint32_t *__restrict__ chunk_base, const uint4 *__restrict__ work_tile, uint32_t T, uint32_t NW,
     const uint32_t *__restrict__ masked, const float4 *__restrict__ rec, int gx, int gy, float *__restrict__ partial,
@@ -395,10 +384,9 @@ __global__ void __launch_bounds__(64, R2_EXP_FWD_OCC) raster_render_forward_wave
         const bool live = head + lane < cnt;
         if (!live) { ea = make_float4(0.f, 0.f, 0.f, 0.f); eb = make_float4(0.f, -INFINITY, 0.f, 0.f); }   // idle lane: alpha = 0
         const int tier = live ? row_tier(ea.z, eb.y, eb.z) : 0;
-        const bool exact = tier == 2;
+        const bool exact = tier >= 1;   // (an entry the 8-step recurrence is not safe for: the exact path, see fwd_item)
         const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
-        if (ANY4) fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc, __any(tier == 1), tier == 1);
-        else fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+        fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
         if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
     }
 
@@ -973,7 +961,7 @@ bool raster_forward_wave_kernel_on()
 
 template <bool MV>
 static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int gx, int gy, uint32_t T,
-                       float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine, hipStream_t s,
+                       float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool fused_combine, hipStream_t s,
                        char *tf_bin_base, const uint32_t *tf_words, bool ids_below_2_28)
 {
     // round 6: the one-wave kernel (R2_FWD_WAVE=0: the four-wave kernel of rounds 1-5, kept as the A/B reference); ids carry
@@ -986,37 +974,24 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
     if (fused_combine && !write_ncontrib && im.NW > 0 && raster_forward_wave_kernel_on() && ids_below_2_28) {
         const uint32_t *masked = b.masked;
         const unsigned grid = (unsigned)((im.NW + 7) / 8) * 32u;   // 8 work items x 4 blocks per group of 32 workgroups
-        if (any_thin)
-            raster_render_forward_wave_kernel<true, MV><<<dim3(grid), dim3(64), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles, tf_bin_base, tf_words);
-        else
-            raster_render_forward_wave_kernel<false, MV><<<dim3(grid), dim3(64), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles, tf_bin_base, tf_words);
+        raster_render_forward_wave_kernel<MV><<<dim3(grid), dim3(64), 0, s>>>(
+            im.ranges, im.chunk_base, im.work_tile, T, (uint32_t)im.NW, masked, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+            fill_tiles, tf_bin_base, tf_words);
         return;
     }
     if (fused_combine && !write_ncontrib && im.NW > 0) {
         // im.NW = R / FWD_CHUNK + T bounds the real work items plus one item per empty tile
-        if (any_thin)
-            raster_render_forward_kernel<true, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles, tf_bin_base, tf_words);
-        else
-            raster_render_forward_kernel<false, true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
-                fill_tiles, tf_bin_base, tf_words);
+        raster_render_forward_kernel<true, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+            im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.tile_done, out_color, W, H,
+            fill_tiles, tf_bin_base, tf_words);
         return;
     }
     if (im.NW > 0) {
         if (write_ncontrib)
             raster_render_forward_debug_kernel<MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, im.partial_last);
-        else if (any_thin)
-            raster_render_forward_kernel<true, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
-                im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr, nullptr, nullptr);
         else
-            raster_render_forward_kernel<false, false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
+            raster_render_forward_kernel<false, MV><<<dim3((unsigned)im.NW), dim3(256), 0, s>>>(
                 im.ranges, im.chunk_base, im.work_tile, T, b.point_list, g.rec, gx, gy, im.partial, nullptr, nullptr, W, H, nullptr, nullptr, nullptr);
     }
     if (write_ncontrib)
@@ -1028,14 +1003,14 @@ static void launch_fwd(const RasterGeom &g, const RasterBinning &b, const Raster
 }
 
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool fused_combine,
                                  hipStream_t s, char *tf_bin_base, const uint32_t *tf_words, size_t view_instances)
 {
     const bool ids28 = view_instances < ((size_t)1 << (32 - MASK_BITS));
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
     const uint32_t T = (uint32_t)gx * gy * (uint32_t)V;   // the views' tile grids, stacked
-    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words, ids28);
-    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, any_thin, fused_combine, s, tf_bin_base, tf_words, ids28);
+    if (V > 1) launch_fwd<true>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, fused_combine, s, tf_bin_base, tf_words, ids28);
+    else launch_fwd<false>(g, b, im, W, H, gx, gy, T, out_color, write_ncontrib, fill_tiles, fused_combine, s, tf_bin_base, tf_words, ids28);
     return 0;
 }
 

@@ -329,7 +329,7 @@ int launch_raster_geom_backward(int P /* per view */, int V, const float *means3
 // tf_bin_base / tf_words (tile-first forward only): fill_tiles is then computed ON THE DEVICE as binning_tiles_ptr(tf_bin_base,
 // tf_words[DW_TOTAL]) -- the binning buffer was carved with a predicted count, the backward will carve it with the true one
 int launch_raster_render_forward(const RasterGeom &g, const RasterBinning &b, const RasterImage &im, int W, int H, int V,
-                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool any_thin, bool fused_combine,
+                                 float *out_color, bool write_ncontrib, uint32_t *fill_tiles, bool fused_combine,
                                  hipStream_t s, char *tf_bin_base = nullptr, const uint32_t *tf_words = nullptr,
                                  size_t view_instances = 0 /* P x V: ids of the masked list */);
 // the one-wave forward kernel is in use (R2_FWD_WAVE=0: the four-wave kernel of rounds 1-5); it takes its work list longest first,

@@ -794,17 +794,14 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     // ---- the prediction: the largest count of the thread's recent calls with this P and detector; for a P it has not rendered
     // yet (the call after a densification) the most recent call on the same detector, scaled -- same scene, more Gaussians
     uint32_t rmax = 0, kmax = 0, kmin = 0;
-    bool thin_guess = false;
     if (const TFHint *hint = tf_hint(P, V, width, height, false); hint && hint->n != 0u) {
         for (uint32_t i = 0; i < std::min(hint->n, 8u); ++i) rmax = std::max(rmax, hint->recent[i]);
-        thin_guess = hint->thin;
         kmax = hint->kmax; kmin = hint->kmin;
     } else if (const TFHint *near = tf_hint_nearby(V, width, height)) {
         uint32_t r0 = 0;
         for (uint32_t i = 0; i < std::min(near->n, 8u); ++i) r0 = std::max(r0, near->recent[i]);
         const double f = (double)P / (double)near->P;
         rmax = (uint32_t)std::min<double>((double)r0 * f * 1.1, 2.0e9);
-        thin_guess = near->thin;
         kmax = near->kmax; kmin = near->kmin;
         g_tf_seeded.fetch_add(1, std::memory_order_relaxed);
         path_count(PS_RAS_EVENT_SEEDED);
@@ -876,7 +873,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     // (post_mailbox: only the FIRST pass posts the totals to the host's mailbox -- by the second one the host has consumed them, and
     // a late post could land in a mailbox the thread has meanwhile armed for its next forward on another stream: ADVICE r5)
     bool post_mailbox = true;
-    auto enqueue = [&](size_t capacity, bool any_thin, bool render_only) -> int {
+    auto enqueue = [&](size_t capacity, bool render_only) -> int {
         if (!render_only) {
             char *bchunk = binningBuffer(RasterBinning::carve(nullptr, capacity).bytes, binning_user);
             char *ichunk = imageBuffer(RasterImage::carve(nullptr, T, N, capacity, false, TL).bytes, image_user);
@@ -910,13 +907,13 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
             R2_HIP_TRY(hipMemsetAsync(img.tile_done, 0, 4 * T * sizeof(uint32_t), s));   // the first render left its arrivals behind
         }
         { StageScope t(ST_RAS_RENDER_FWD, s);
-        launch_raster_render_forward(geom, bin, img, width, height, V, out_color, false, bin.tiles, any_thin, true, s,
+        launch_raster_render_forward(geom, bin, img, width, height, V, out_color, false, bin.tiles, true, s,
                                      reinterpret_cast<char *>(bin.point_list), geom.host_words, (size_t)PV); }
         R2_HIP_TRY(hipGetLastError());
         return 0;
     };
-    // (a deferred forward cannot render again when the scene turns out to hold thin Gaussians: it takes the variant that serves both)
-    rc = enqueue(cap, token >= 0 ? true : thin_guess, false);
+    // (one render variant since round 6 -- thin Gaussians take its exact path, raster_render.hip: fwd_item -- so no render is ever repeated)
+    rc = enqueue(cap, false);
     if (rc) return rc;
     if (token >= 0) {
         // ---- deferred: no wait.  The token goes back as num_rendered; the backward resolves it (raster_backward_impl)
@@ -942,12 +939,7 @@ int raster_forward_tilefirst(const char *what, r2_alloc_fn geometryBuffer, void 
     if ((size_t)num_rendered > cap) {
         g_tf_rerun.fetch_add(1, std::memory_order_relaxed);
         path_count(PS_RAS_EVENT_SECOND_PASS);
-        rc = enqueue(num_rendered, thin, false);      // the prediction fell short: exact sizes, same kernels
-        if (rc) return rc;
-    } else if (thin && !thin_guess) {
-        g_tf_rerender.fetch_add(1, std::memory_order_relaxed);
-        path_count(PS_RAS_EVENT_THIN_RERENDER);
-        rc = enqueue(cap, true, true);                // the scene holds thin Gaussians after all: render again with that variant
+        rc = enqueue(num_rendered, false);      // the prediction fell short: exact sizes, same kernels
         if (rc) return rc;
     }
     ws->dirty = false;
