@@ -20,8 +20,10 @@ LIB = os.path.join(HERE, "libr2hip.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function"]
 EXACT = ["-ffp-contract=off"]
-# -fno-slp-vectorize: hipcc would otherwise pack adjacent scalar f32 ops into v_pk_*_f32, which issue ~8x slower
-# than plain VALU ops on gfx950 (measured: render_bwd 532 -> see profiles/)
+# -fno-slp-vectorize: hipcc's SLP pass would otherwise pack adjacent scalar f32 ops into v_pk_*_f32 -- with the register
+# shuffling it adds around them the render backward ran ~7x slower (532 us against 75, round 1).  The packed instructions
+# themselves, placed by hand on operands that already sit in register pairs, issue ~1.7x slower than the plain forms
+# ("v_pk"): two numbers for two different things -- the pass, and the instruction.
 FAST = ["-ffp-contract=fast", "-fno-slp-vectorize"]
 
 SOURCES = {
