@@ -17,6 +17,17 @@
 //           run in a fixed order (bit-reproducible gradients).
 #include "voxel_state.hpp"
 
+// experiment builds (-DR2_EXP_TS): stamps inside the item workgroups of the forward kernel, read by scripts/cbench (phase durations of
+// the first 2047 work items by item length: profiles/r06_voxel_render_stamps.txt).  15 holds the item's length, not a time.
+R2_TS_DEFINE(vrender)
+#ifdef R2_EXP_TS
+#define VR_TS(ph) do { if (hb < 2047u * 2u && (hb & 1u) == 0u && threadIdx.x == 0) r2::g_ts_vrender[ph][hb >> 1] = wall_clock64(); } while (0)
+#define VR_TSV(ph, val) do { if (hb < 2047u * 2u && (hb & 1u) == 0u && threadIdx.x == 0) r2::g_ts_vrender[ph][hb >> 1] = (unsigned long long)(val); } while (0)
+#else
+#define VR_TS(ph)
+#define VR_TSV(ph, val)
+#endif
+
 namespace r2 {
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -175,8 +186,11 @@ __device__ __forceinline__ void vfwd_item_body(
     // overlap on a CU
     const uint32_t w = hb >> 1;
     const int half = (int)(hb & 1u);
+    VR_TS(0);
     const uint4 wd = work_tile[w];   // {tile, first instance, one past the last, items of the tile}
     const uint32_t tile = wd.x, beg = wd.y, end = wd.z;
+    VR_TSV(15, end - beg);
+    VR_TS(1);   // the descriptor is here
     const int tx = tile % v.gx, ty = (tile / v.gx) % v.gy, tz = tile / (v.gx * v.gy);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slab = half * 4 + wave;
@@ -257,6 +271,7 @@ __device__ __forceinline__ void vfwd_item_body(
             // the 128 VGPRs that four waves per SIMD allow and spilled three of them around this barrier: 12 bytes written
             // and read back per staged entry, 96 MB of scratch writes per 256^3 query in the round-4 counters.)
             s3[tid] = nq;
+            if (base == beg) VR_TS(2); else VR_TS(8);   // ids -> records -> slab tests of the first / of the latest batch
             __syncthreads();   // the previous batch has been consumed
             s0[tid] = np; s1[tid] = s3[tid]; s2[tid] = nr;
             if (lane == 0) {
@@ -269,6 +284,7 @@ __device__ __forceinline__ void vfwd_item_body(
         // the step body -- 2 x 500 instructions)
         int flush_pass = __builtin_amdgcn_readfirstlane(flush ? 1 : 0);
         asm volatile("" : "+s"(flush_pass));
+        if (base == beg) VR_TS(3); else if (!flush_pass) VR_TS(9);   // staged
         // compaction: entries that may use the row recurrences queue up from the front of sQ, the few that need the exact
         // evaluation (needs_exact_slab3: very thin along y or z, or no finite culling box) from the back -- they are evaluated
         // voxel-parallel, so that the lane-per-entry step is straight-line code (the exact variant of the step cost 24 VGPRs
@@ -302,6 +318,7 @@ __device__ __forceinline__ void vfwd_item_body(
             head += 64 - ncarry;
             ncarry = 0;
         }
+        if (base == beg) VR_TS(4); else if (!flush_pass) VR_TS(10);   // the batch's steps are done
         if (flush_pass) {
             // fewer than VFWD_STEP_MIN entries left: voxel-parallel (a step would be mostly idle)
             for (int t = 0; t < ncarry; ++t) tail += vfwd_voxel_parallel(s0[carry0 + t], s1[carry0 + t], s2[carry0 + t], xc, y0, z0, lane);
@@ -325,6 +342,7 @@ __device__ __forceinline__ void vfwd_item_body(
         }
     }
 
+    VR_TS(5);   // the flush pass is done
     // 64x64 transpose-reduction (see raster_render.hip): acc[0] ends up as the slab's voxel number `lane` = y*8 + z.
     // Skipped when the (short) list was handled entirely by the voxel-parallel tail -- most tiles at 256^3.
     if (stepped) {
@@ -351,6 +369,7 @@ __device__ __forceinline__ void vfwd_item_body(
         }
     }
     const float value = acc[0] + tail;
+    VR_TS(6);
     if (wd.w == 1u) {
         // the tile's only work item (almost every tile at 256^3): write the volume directly, no partial + combine pass
         const int vx = tx * TILE3D + slab, vy = ty * TILE3D + (lane >> 3), vz = tz * TILE3D + (lane & 7);

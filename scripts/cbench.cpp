@@ -439,6 +439,37 @@ int main(int argc, char **argv)
         const char *path = getenv("R2_TS_DUMP") ? getenv("R2_TS_DUMP") : "gpurun_out/ts_sticks.bin";
         if (FILE *f = fopen(path, "wb")) { fwrite(ts.data(), 8, ts.size(), f); fclose(f); printf("stamps of the stick chain -> %s\n", path); }
     }
+    // experiment builds: stamps inside the item workgroups of the voxel render kernel (voxel_render.hip, VR_TS): phase durations of
+    // the first 2047 work items (their first half-item), by item length
+    if (void *pt = dlsym(h, "r2_debug_ts_vrender")) {
+        CHECK(hipStreamSynchronize(s));
+        vox();
+        CHECK(hipStreamSynchronize(s));
+        std::vector<unsigned long long> ts(16 * 2048);
+        reinterpret_cast<int (*)(unsigned long long *)>(pt)(ts.data());
+        auto at = [&](int ph, int b) { return ts[(size_t)ph * 2048 + b]; };
+        const int edges[] = {0, 256, 512, 768, 1025};
+        const int pairs[][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 4}, {4, 8}, {8, 9}, {9, 10}, {4, 5}, {10, 5}, {5, 6}, {0, 6}};
+        for (int e = 0; e + 1 < 5; ++e) {
+            int n = 0;
+            for (int b = 0; b < 2047; ++b)
+                if (at(0, b) && (int)at(15, b) >= edges[e] && (int)at(15, b) < edges[e + 1]) ++n;
+            printf("  vrender items of %d..%d entries: %d\n", edges[e], edges[e + 1] - 1, n);
+            for (const auto &pr : pairs) {
+                std::vector<double> d;
+                double sum = 0;
+                for (int b = 0; b < 2047; ++b) {
+                    if (!at(0, b) || (int)at(15, b) < edges[e] || (int)at(15, b) >= edges[e + 1]) continue;
+                    const unsigned long long x = at(pr[0], b), y = at(pr[1], b);
+                    if (x >= at(0, b) && y >= x && y - x < 100000ull) { d.push_back((double)(y - x) * 0.01); sum += d.back(); }
+                }
+                if (d.empty()) continue;
+                std::sort(d.begin(), d.end());
+                printf("    VR %2d->%2d: n %4zu  mean %6.2f  med %6.2f  p90 %6.2f us\n", pr[0], pr[1], d.size(), sum / d.size(), d[d.size() / 2],
+                       d[d.size() * 9 / 10]);
+            }
+        }
+    }
     // the training loop's TV regulariser: forward + backward on a 32^3 sub-volume (train.py, tv_vol_size = 32)
     {
         float *dLv;

@@ -178,6 +178,37 @@ __global__ void k_thr_cmpx_norestore(float *out, float a, float b)
     for (int i = 0; i < 8; ++i) s += acc[i] + G[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
+// round 6: the threshold as a flush -- the wave runs with f32 denormals flushed (MODE.FP_DENORM), t = G * k lands below 2^-126
+// exactly when G is below the threshold (k = 2^-126 / threshold), acc += t.  No compare, no EXEC or VCC dependency, no SALU.
+__global__ void k_thr_ftz(float *out, float a, float b)
+{
+    float G[8], acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { G[i] = a + i + threadIdx.x * 1e-6f; acc[i] = 0.f; }
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 0");
+    float t;
+    for (int it = 0; it < ITER; ++it) {
+#define S(i) asm volatile("v_mul_f32 %2, %0, %3\n v_add_f32 %1, %1, %2\n v_mul_f32 %0, %0, %4" : "+v"(G[i]), "+v"(acc[i]), "=&v"(t) : "v"(b), "v"(a));
+        REP8(S)
+#undef S
+    }
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 3");
+    float s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += acc[i] + G[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+// does the flush do what the trick needs?  out[0..3] = {flushed product, kept product, flushed sum input, reference}
+__global__ void k_ftz_check(float *out)
+{
+    const float thr = __uint_as_float(0x358637bdu);          // the voxelizer's 1e-6
+    const float kinv = thr * 8.507059173023462e37f;           // thr * 2^126: exact
+    const float k = 1.0f / kinv;
+    float below = __uint_as_float(0x358637bcu), at = thr, r0, r1, r2;
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 0\n v_mul_f32 %0, %3, %5\n v_mul_f32 %1, %4, %5\n v_add_f32 %2, %0, %1\n"
+                 "s_setreg_imm32_b32 hwreg(HW_REG_MODE, 4, 2), 3" : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(below), "v"(at), "v"(k));
+    if (threadIdx.x == 0) { out[0] = r0; out[1] = r1; out[2] = r2 * kinv; out[3] = thr; out[4] = below * k; }
+}
 // v_exp_f32 issue cost
 __global__ void k_exp(float *out, float a, float b)
 {
@@ -222,6 +253,13 @@ int main()
 {
     float *out;
     CHECK(hipMalloc(&out, sizeof(float) * 256 * 8 * 256));
+    {
+        k_ftz_check<<<1, 64>>>(out);
+        float h[5];
+        CHECK(hipMemcpy(h, out, sizeof(h), hipMemcpyDeviceToHost));
+        printf("ftz check: below*k -> %g (want 0), at*k -> %g (want 2^-126 = 1.17549e-38), sum*kinv %.9g (want thr %.9g), unflushed below*k %g\n",
+               h[0], h[1], h[2], h[3], h[4]);
+    }
     for (int w : { 1, 2, 4 }) {
         run("v_fma_f32", k_fma, w, 8, 16, out);
         run("v_mul_f32", k_mul, w, 8, 8, out);
@@ -233,6 +271,7 @@ int main()
         run("thr select (4 VALU+nop)", k_thr_select, w, 32, 8, out);
         run("thr cmpx (3 VALU+SALU)", k_thr_cmpx, w, 24, 8, out);
         run("thr cmpx, no restore", k_thr_cmpx_norestore, w, 24, 8, out);
+        run("thr ftz (3 VALU)", k_thr_ftz, w, 24, 8, out);
         run("v_exp_f32", k_exp, w, 8, 8, out);
     }
     return 0;
