@@ -48,11 +48,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+VALU_SIMDS, VALU_CYCLES_PER_INST, VALU_CLOCK_GHZ = 1024, 2.8, 2.4   # 256 CUs x 4; profiles/r06_ubench_valu.txt
 
 # stage (r2_profile_* name) -> kernel name in the rocprofv3 / PMC summaries
 STAGE_KERNEL = {
     "raster.render_bwd": "r2::raster_render_backward_kernel<false>",
-    "raster.render_fwd": "r2::raster_render_forward_wave_kernel<false, false>",   # round 6: the one-wave kernel
+    "raster.render_fwd": "r2::raster_render_forward_wave_kernel<false>",   # round 6: the one-wave kernel
     "raster.geom_bwd": "r2::raster_geom_backward_kernel<false>",
     # (tile-first binning chain, rounds 4-5; the general chain's kernels are r2::raster_preprocess_kernel / raster_emit_hist_kernel)
     "raster.preprocess": "r2::raster_preprocess_tf_kernel",
@@ -1092,7 +1093,7 @@ def main():
     # HBM traffic of the dominant kernel from the TCC counters (FETCH_SIZE / WRITE_SIZE, one counter per rocprofv3 pass:
     # scripts/gpu_pmc.sh; the summary it writes is committed under profiles/).  bench.py cannot collect PMCs itself; the
     # summary is accepted only when it was collected on the kernel sources this library was built from.
-    traffic, traffic_note = None, None
+    traffic, traffic_note, valu = None, None, None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
@@ -1108,6 +1109,15 @@ def main():
                     str(have)[:12], want[:12])
             elif "FETCH_SIZE" in kq and "WRITE_SIZE" in kq:
                 traffic = int((kq["FETCH_SIZE"] + kq["WRITE_SIZE"]) * 1024)   # counters are in KB, per launch
+                if "SQ_INSTS_VALU" in kq:
+                    # what actually bounds this kernel: its VALU instruction stream against the rate the chip
+                    # retires independent f32 instructions at with four waves per SIMD (scripts/ubench_valu.hip,
+                    # profiles/r06_ubench_valu.txt: 2.8 cycles per wave-instruction per SIMD at 2.4 GHz)
+                    floor_us = kq["SQ_INSTS_VALU"] / VALU_SIMDS * VALU_CYCLES_PER_INST / VALU_CLOCK_GHZ / 1e3
+                    valu = {"insts_per_launch": int(kq["SQ_INSTS_VALU"]), "cycles_per_inst_floor": VALU_CYCLES_PER_INST,
+                            "clock_ghz": VALU_CLOCK_GHZ, "simds": VALU_SIMDS, "floor_us": round(floor_us, 2),
+                            "note": "SQ_INSTS_VALU per launch (profiles/pmc_latest.json) x measured issue floor; frac = floor_us / "
+                                    "us_per_launch is filled in below"}
                 traffic_note = "FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes (profiles/pmc_latest.json, " \
                                "sources %s); gfx950 FETCH_SIZE under-reports 16 B/lane streaming reads by 2x (uncorrected " \
                                "here: the kernel gathers)" % want[:12]
@@ -1173,7 +1183,8 @@ def main():
                          "instrumented_regions": dom_regions,
                          "alg_bytes_per_launch": dom_bytes,
                          "pipeline_frac": round(total_bytes / dt_step / 1e9 / HBM_PEAK_GBS, 4),
-                         "pipeline_alg_bytes": total_bytes},
+                         "pipeline_alg_bytes": total_bytes,
+                         "valu": (dict(valu, frac=round(valu["floor_us"] / dom_us, 3)) if valu and dom_us > 0 else None)},
             "cpu_baseline": cpu,
             "cpu_baseline_note": cpu_note,
             "parity_checked": parity,

@@ -1,6 +1,6 @@
 """256^3 query of the benchmark cloud on the general binning chain and on the stick-first chain (csrc/voxel_sticks.hip), alternating
 on ONE box: ms per call (median of 5 x n calls, as bench.py times it), per-stage times of the same call, and the two volumes compared
-bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000 | small | large] [grid=256] [modes=0,1]   (r2_voxel_sticks_control modes)"""
+bit for bit.   python scripts/voxel_ab.py [n=20] [P=300000 | small | large] [grid=256] [modes=0,1] [nolimit]   (r2_voxel_sticks_control modes)"""
 import ctypes as C
 import statistics
 import sys
@@ -29,6 +29,8 @@ e = torch.empty(0)
 a = (c.xyz.to(dev), c.density.to(dev), c.scales.to(dev), c.rotations.to(dev), 1.0, e, G, G, G, 2.0, 2.0, 2.0, 0.0, 0.0, 0.0,
      False, False)
 L = _lib.lib()
+if len(sys.argv) > 5 and sys.argv[5] == "nolimit":   # keep scenes with very long lists on the stick chain (r2_voxel_sticks_limits)
+    L.r2_voxel_sticks_limits(C.c_longlong(1 << 40), C.c_longlong(1 << 40))
 vols = {}
 for rep in range(2):
     for mode in MODES:
