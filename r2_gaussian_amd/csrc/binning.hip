@@ -493,7 +493,8 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
         uint32_t n = 0;
         if (t < T) {
             const uint2 r = ranges[t];
-            n = (r.y - r.x) < min_len ? 0u : (r.y - r.x + chunk - 1) / chunk;
+            const uint32_t ch = work_tile_chunk(chunk, r.y - r.x);
+            n = (r.y - r.x) < min_len ? 0u : (r.y - r.x + ch - 1) / ch;
         }
         // inclusive scan inside the wave, then across the 16 waves
         uint32_t incl = n;
@@ -510,8 +511,9 @@ __global__ void __launch_bounds__(1024) build_work_kernel(const uint2 *__restric
         if (t < T) {
             chunk_base[t] = excl;
             const uint2 r = ranges[t];
+            const uint32_t ch = work_tile_chunk(chunk, r.y - r.x);
             for (uint32_t j = 0; j < n; ++j)   // work descriptor: {tile, first instance, one past the last, items of the tile}
-                work_tile[excl + j] = make_uint4(t, r.x + j * chunk, min(r.y, r.x + (j + 1) * chunk), n);
+                work_tile[excl + j] = make_uint4(t, r.x + j * ch, min(r.y, r.x + (j + 1) * ch), n);
         }
         __syncthreads();
         if (tid == 1023) carry = excl + n;
@@ -530,7 +532,8 @@ __global__ void __launch_bounds__(256) work_count_kernel(const uint2 *__restrict
     const uint32_t t = blockIdx.x * 256u + threadIdx.x;
     if (t >= T) return;
     const uint2 r = ranges[t];
-    nw[t] = (r.y - r.x) < min_len ? 0u : (r.y - r.x + chunk - 1) / chunk;
+    const uint32_t ch = work_tile_chunk(chunk, r.y - r.x);
+    nw[t] = (r.y - r.x) < min_len ? 0u : (r.y - r.x + ch - 1) / ch;
 }
 __global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict__ ranges, uint32_t chunk,
                                                         const uint32_t *__restrict__ nw, const uint32_t *__restrict__ incl,
@@ -542,8 +545,9 @@ __global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict_
     const uint32_t n = nw[t], start = incl[t] - n;
     chunk_base[t] = start;
     const uint2 r = ranges[t];
+    const uint32_t ch = work_tile_chunk(chunk, r.y - r.x);
     for (uint32_t j = 0; j < n; ++j)
-        work_tile[start + j] = make_uint4(t, r.x + j * chunk, min(r.y, r.x + (j + 1) * chunk), n);
+        work_tile[start + j] = make_uint4(t, r.x + j * ch, min(r.y, r.x + (j + 1) * ch), n);
     if (t == T - 1) chunk_base[T] = incl[t];
 }
 
@@ -551,8 +555,8 @@ __global__ void __launch_bounds__(256) work_fill_kernel(const uint2 *__restrict_
 // one writes bases and work items on the way (count + scan-reduce, scan-apply + fill): two ~5 us launches less per 256^3 query.
 __device__ __forceinline__ uint32_t work_items_of(const uint2 r, uint32_t chunk, uint32_t min_len)
 {
-    const uint32_t len = r.y - r.x;
-    return len < min_len ? 0u : (len + chunk - 1) / chunk;
+    const uint32_t len = r.y - r.x, ch = work_tile_chunk(chunk, len);
+    return len < min_len ? 0u : (len + ch - 1) / ch;
 }
 __global__ void __launch_bounds__(SC_THREADS) work_reduce_kernel(const uint2 *__restrict__ ranges, uint32_t T, uint32_t chunk,
                                                                  uint32_t min_len, uint32_t *__restrict__ partial)
@@ -600,8 +604,9 @@ __global__ void __launch_bounds__(SC_THREADS) work_apply_fill_kernel(const uint2
         const uint32_t t = base + i;
         if (t < T) {
             chunk_base[t] = run;
+            const uint32_t ch = work_tile_chunk(chunk, r[i].y - r[i].x);
             for (uint32_t j = 0; j < x[i]; ++j)   // work descriptor: {tile, first instance, one past the last, items of the tile}
-                work_tile[run + j] = make_uint4(t, r[i].x + j * chunk, min(r[i].y, r[i].x + (j + 1) * chunk), x[i]);
+                work_tile[run + j] = make_uint4(t, r[i].x + j * ch, min(r[i].y, r[i].x + (j + 1) * ch), x[i]);
             run += x[i];
             if (t == T - 1) chunk_base[T] = run;
         }

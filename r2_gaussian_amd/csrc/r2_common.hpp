@@ -100,6 +100,25 @@ struct Bump {
     size_t total() const { return off + 128; }
 };
 
+// Work items of a tile list: `chunk` instances each -- or, with WORK_CHUNK_ADAPT set on the chunk argument (round 6, the voxelizer),
+// a chunk the LIST chooses: at least the base chunk, and long lists are cut into about eight pieces (a power of two, at most 1024).
+// What a list is cut into then depends on the grid's base chunk and on its own length only: the partial sums of a tile associate the
+// same way in an x-slab call and in the unsharded one (bit-identical volumes, voxel_state.hpp), while a dense small grid (the 32^3
+// TV patch of a trained cloud: 3 100 instances per tile) no longer pays for 25 items per tile because a sparse one wants 128.
+constexpr uint32_t WORK_CHUNK_ADAPT = 0x80000000u;
+__host__ __device__ inline uint32_t work_tile_chunk(uint32_t chunk, uint32_t len)
+{
+    if (!(chunk & WORK_CHUNK_ADAPT)) return chunk;
+    const uint32_t base = chunk & ~WORK_CHUNK_ADAPT;
+#ifndef R2_WORK_CHUNK_SHIFT
+#define R2_WORK_CHUNK_SHIFT 3   /* pieces of a long list: 2^3 (measured against 4 and 16: profiles/r06e_voxel_adaptive_chunk_ab.txt) */
+#endif
+    const uint32_t eighth = (len + (1u << R2_WORK_CHUNK_SHIFT) - 1u) >> R2_WORK_CHUNK_SHIFT;
+    if (eighth <= base) return base;   // (every list of a 256^3 query: no further arithmetic)
+    const uint32_t want = eighth >= 1024u ? 1024u : 1u << (32 - __builtin_clz(eighth - 1u));   // the next power of two
+    return want > base ? want : base;
+}
+
 // ---- binning.hip: scan / stable radix sort / tile ranges (shared by rasterizer and voxelizer)
 size_t scan_temp_bytes(int P);
 int inclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int P, hipStream_t s);
@@ -327,12 +346,13 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
     if (tid < (int)WORK_CLASSES) rw_cls[tid] = 0u;
     __syncthreads();
     // length class of a remainder of `rem` entries (0 < rem < chunk): 0 = the longest
-    auto cls_of = [&](uint32_t rem) { return WORK_CLASSES - 1u - min(WORK_CLASSES - 1u, (rem * WORK_CLASSES) / wo.chunk); };
+    auto cls_of = [&](uint32_t rem) { return WORK_CLASSES - 1u - min(WORK_CLASSES - 1u, (rem * WORK_CLASSES) / (wo.chunk & ~WORK_CHUNK_ADAPT)); };
     for (uint32_t base = 0; base < wo.T; base += NT) {
         const uint32_t t = base + tid;
         const uint32_t c = t < wo.T ? counts[t] : 0u;
-        const uint32_t nw = c < wo.min_len ? 0u : (c + wo.chunk - 1) / wo.chunk;
-        const uint32_t nfull = lf ? c / wo.chunk : nw;   // items placed in this sweep (longest first: the full ones)
+        const uint32_t ch = work_tile_chunk(wo.chunk, c);   // (the adaptive rule and the longest-first order do not meet: voxelizer / rasterizer)
+        const uint32_t nw = c < wo.min_len ? 0u : (c + ch - 1) / ch;
+        const uint32_t nfull = lf ? c / ch : nw;   // items placed in this sweep (longest first: the full ones)
         uint32_t incl = c, incl2 = nw, incl3 = nfull;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -350,8 +370,8 @@ __device__ __forceinline__ void ranges_and_work_block(const uint32_t *__restrict
             wo.chunk_base[t] = wstart;
             for (uint32_t j = 0; j < nfull; ++j)
                 if (!wo.work_cap || fstart + j < wo.work_cap)
-                    wo.work[fstart + j] = make_uint4(t, start + j * wo.chunk, min(start + c, start + (j + 1) * wo.chunk), nw);
-            if (lf && nw != nfull) atomicAdd(&rw_cls[cls_of(c - nfull * wo.chunk)], 1u);
+                    wo.work[fstart + j] = make_uint4(t, start + j * ch, min(start + c, start + (j + 1) * ch), nw);
+            if (lf && nw != nfull) atomicAdd(&rw_cls[cls_of(c - nfull * ch)], 1u);
         }
         __syncthreads();
         if (tid == NT - 1) { rw_carry = start + c; rw_carry2 = wstart + nw; rw_carry3 = fstart + nfull; }

@@ -196,7 +196,7 @@ extern "C" int r2_voxel_forward_slab(
                                                                      // sorts getHigherMsb(T) bits: one more for T = 2^k)
         { StageScope t(ST_VOX_SORT, s);
         if (sort_is_single_pass(bit)) {   // block 0 of the sort's last kernel also builds tile ranges + work list
-            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_chunk_for(v.gy, v.gz), nullptr,
+            const WorkListOut wo{img.ranges, img.chunk_base, img.work_tile, (uint32_t)T, vox_work_chunk(v.gy, v.gz), nullptr,
                                  voxel_short_list_min(debug != 0)};
             rc = sort_by_tile_single_pass(bin.sort_temp, bin.sort_bytes, bin.tiles_unsorted, bin.vals_unsorted, bin.point_list,
                                           debug ? bin.inv : nullptr, R, bit, &tile_counts, s, &wo);   // inv: introspection only
@@ -213,12 +213,12 @@ extern "C" int r2_voxel_forward_slab(
     if (work_built) {
         // nothing to do
     } else if (tile_counts) {
-        launch_ranges_and_work(tile_counts, (uint32_t)T, vox_chunk_for(v.gy, v.gz), img.ranges, img.chunk_base, img.work_tile, s,
+        launch_ranges_and_work(tile_counts, (uint32_t)T, vox_work_chunk(v.gy, v.gz), img.ranges, img.chunk_base, img.work_tile, s,
                                voxel_short_list_min(debug != 0));
     } else {
         rc = tile_ranges(bin.tiles, nullptr, nullptr, nullptr, R, img.ranges, T, s, ranges_zeroed);
         if (rc) return rc;
-        launch_build_work(img.ranges, (uint32_t)T, vox_chunk_for(v.gy, v.gz), img.chunk_base, img.work_tile, img.work_temp, s,
+        launch_build_work(img.ranges, (uint32_t)T, vox_work_chunk(v.gy, v.gz), img.chunk_base, img.work_tile, img.work_temp, s,
                           voxel_short_list_min(debug != 0));
     } }
     R2_STAGE_CHECK(debug, s, "identifyTileRanges");

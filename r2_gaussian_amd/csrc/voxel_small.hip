@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(SL_THREADS) voxel_small_lists_kernel(
     // short-list kernel's launch.  (ONE item per tile -- no partial sums at all -- was measured: the 128 long-running workgroups
     // took 38 us instead of 23.)
     (void)min_len;
-    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_chunk_for(gy, gz), nullptr, 0u,
+    ranges_and_work_block<SL_THREADS>(s_counts, WorkListOut{tmp.ranges, tmp.chunk_base, tmp.work, T, vox_work_chunk(gy, gz), nullptr, 0u,
                                                             tmp.cap_work});
 }
 

@@ -11,12 +11,18 @@ constexpr uint32_t VOX_CHUNK = 1024;  // most instances of one tile list evaluat
 // (tiles): the backward and the state introspection re-derive the same layout, and -- round 6 -- so does every x-slab call on the
 // same volume: where a tile's list is cut decides how its partial sums associate, so the unsharded query and its slabs must cut
 // alike to be bit-identical (rounds 1-5 chose by the call's instance count R, which a slab cannot know of the full call).
-// 32^3 patch: 128; 64^3: 256; 128^3: 512; 256^3: 1024.
+// 32^3 patch: 128; 64^3: 256; 128^3: 512; 256^3: 1024.  This is the BASE chunk: the work-list builders are handed vox_work_chunk()
+// below, under which a long list chooses a larger one for itself (work_tile_chunk) -- the round-5 rule gave a dense patch (the TV
+// patch of the 331k trained cloud: 3 100 instances per tile) chunks of 256, the cross-section rule alone 128: 259 -> 295 us; with the
+// list's own choice 239 us, a million Gaussians at 64^3 534 -> 413 us (profiles/r06e_voxel_adaptive_chunk_ab.txt).
 __host__ __device__ inline uint32_t vox_chunk_for(int gy, int gz)
 {
     const long long c = (long long)gy * gz;
     return c > 256 ? VOX_CHUNK : (c > 64 ? 512u : (c > 16 ? 256u : 128u));
 }
+// what the work-list builders are handed: the base chunk + "a long list chooses a larger one" (work_tile_chunk, r2_common.hpp) -- a
+// function of the grid and of the list itself, so still the same in a slab call and in the unsharded one
+__host__ __device__ inline uint32_t vox_work_chunk(int gy, int gz) { return vox_chunk_for(gy, gz) | WORK_CHUNK_ADAPT; }
 constexpr int VPART_STRIDE = 12;      // floats per instance in the backward moment scratch (10 used)
 constexpr float ALPHA_MIN_3D = 0.000001f;                 // VOX/forward.cu:293
 constexpr float LOG2_ALPHA_MIN_3D = -19.931568569324174f;   // log2(1e-6)

@@ -394,7 +394,8 @@ __device__ __forceinline__ void vs_sort_group(unsigned long long (&mine)[PER], u
         if (tile < T) {
             const uint32_t a = s_wb ? s_wb[gtid] : s_bin[(uint32_t)gtid * BPS], b = s_wb ? s_wb[gtid + 1] : s_bin[((uint32_t)gtid + 1u) * BPS];
             ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
-            items = (b - a) < wk.min_len ? 0u : (b - a + wk.chunk - 1u) / wk.chunk;
+            const uint32_t ch = work_tile_chunk(wk.chunk, b - a);
+            items = (b - a) < wk.min_len ? 0u : (b - a + ch - 1u) / ch;
         }
         if (wk.partial != nullptr) {
             for (uint32_t d = 1; d < (1u << sh); d <<= 1) items += (uint32_t)__shfl_xor(items, (int)d);   // lanes 0 .. 2^sh - 1: all here
@@ -675,7 +676,8 @@ __global__ void __launch_bounds__(VSK_THREADS, 8) vox_stick_sort_kernel(
             if (tile < T) {
                 const uint32_t a = s_wb[tid], b = s_wb[tid + 1];
                 ranges[tile] = b > a ? make_uint2(start + a, start + b) : make_uint2(0u, 0u);
-                const uint32_t items = (b - a) < wk.min_len ? 0u : (b - a + wk.chunk - 1u) / wk.chunk;
+                const uint32_t ch = work_tile_chunk(wk.chunk, b - a);
+                const uint32_t items = (b - a) < wk.min_len ? 0u : (b - a + ch - 1u) / ch;
                 if (wk.partial != nullptr && items != 0u) atomicAdd(&wk.partial[(list << sh) / wk.block_tiles], items);
             }
         }
@@ -865,7 +867,7 @@ int voxel_forward_sticks(r2_alloc_fn binningBuffer, void *binning_user, r2_alloc
     // the render kernel's work list: for more than 4096 tiles the sort kernel leaves the work items per block of tiles behind
     // (one launch of the construction instead of two)
     const bool sums = T > 4096 && img.work_temp != nullptr && R > 0;
-    const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_chunk_for(v.gy, v.gz),
+    const VSWork wk{sums ? reinterpret_cast<uint32_t *>(img.work_temp) : nullptr, build_work_block_tiles(), vox_work_chunk(v.gy, v.gz),
                     voxel_short_list_min(false)};
     const uint32_t n_partial = sums ? (uint32_t)((T + wk.block_tiles - 1) / wk.block_tiles) : 0u;
     // ... and for up to 4096 tiles (lists = tiles) the scatter kernel's second service workgroup builds ranges and work list

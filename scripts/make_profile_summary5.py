@@ -54,20 +54,23 @@ if os.path.exists(os.path.join(P, "%s_kernel_stats.csv" % tag)):   # (a voxel-on
                 "pmc_latest.json, which bench.py reads for `roofline.traffic` when its source hash matches); KB in the json, MB here.  "
                 "Bench lines of the same build: %s_bench.json (default run), %s_bench_driver.json (--steps 20 --warmup 5), "
                 "%s_bench_{B,C,E}.json (BASELINE configs B 50k/512^2, C 300k/560^2, E 1M/1024^2/360 views).\n\n" % (tag, tag, tag, tag, tag))
-        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) | VALU issue |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("| kernel | calls | avg us | % | FETCH MB | WRITE MB | VALU inst (M) | VALU floor frac |\n|---|---|---|---|---|---|---|---|\n")
         for r in rows[:30]:
             k = short(r['Name']); p = pmc.get(k, {})
             us = float(r['AverageNs']) / 1e3
-            # share of the VALU issue slots: SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel cycles at the nominal 2.4 GHz)
-            issue = (p['SQ_INSTS_VALU'] * 2.0 / (1024.0 * us * 2400.0)) if ('SQ_INSTS_VALU' in p and us > 0) else None
+            # fraction of the VALU floor: SQ_INSTS_VALU x 2.8 cycles / (1024 SIMDs x kernel cycles at the nominal 2.4 GHz)
+            issue = (p['SQ_INSTS_VALU'] * 2.8 / (1024.0 * us * 2400.0)) if ('SQ_INSTS_VALU' in p and us > 0) else None
             f.write("| `%s` | %s | %.1f | %s | %s | %s | %s | %s |\n" % (
                 k, r['Calls'], us, r['Percentage'],
                 ("%.1f" % (p['FETCH_SIZE'] / 1024)) if 'FETCH_SIZE' in p else "",
                 ("%.1f" % (p['WRITE_SIZE'] / 1024)) if 'WRITE_SIZE' in p else "",
                 ("%.1f" % (p['SQ_INSTS_VALU'] / 1e6)) if 'SQ_INSTS_VALU' in p else "",
                 ("%.2f" % issue) if issue is not None else ""))
-        f.write("\nVALU issue = SQ_INSTS_VALU x 2 cycles / (1024 SIMDs x kernel time x 2.4 GHz): the share of the vector issue slots the "
-                "kernel uses (DESIGN.md section 4: a wave issues one VALU instruction per ~5 cycles whatever its ILP, a SIMD one per 2).\n")
+        f.write("\nVALU floor frac = SQ_INSTS_VALU x 2.8 cycles / (1024 SIMDs x kernel time x 2.4 GHz): the kernel's vector instruction stream "
+                "at the rate the chip retires independent f32 instructions with four waves per SIMD (scripts/ubench_valu.hip, "
+                "profiles/r06_ubench_valu.txt: 5.8-6.3 cycles per wave-instruction with one wave per SIMD, 3.0-3.3 with two, 2.8 with four), "
+                "over its measured time -- the roofline that applies to the render kernels (DESIGN.md section 4, round 6).  Earlier "
+                "rounds' summaries priced an instruction at 2 cycles (the data-sheet rate): multiply their column by 1.4.\n")
         f.write("\nNotes: FETCH_SIZE on gfx950 under-reports wide (16 B/lane) streaming reads by 2x (MI355X_MICROARCH.md, HBM); the "
                 "render kernels gather 16-byte records, so their true fetch lies between the reported value and twice it.  Kernels named "
                 "bucket_* / minmax / scan_reduce / scan_apply belong to the un-hinted depth order (the first call for a given number of "
