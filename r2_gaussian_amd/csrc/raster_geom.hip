@@ -208,7 +208,9 @@ __global__ void __launch_bounds__(256) raster_preprocess_kernel(
 // holds only a handful of such rectangles and each costs three v_readlane + a division-free index computation per step.)
 // SHARE: more producer workgroups than CUs (clouds beyond 524k Gaussians): compiled for <= 64 VGPRs (four spilled), so that two
 // 1024-thread workgroups run side by side on a CU instead of one after the other; the plain instantiation (68 VGPRs) has its CU to itself.
-template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */, bool SHARE>
+// MV: stacked views.  A single view is compiled without the view index and its division (round 6: with them in the SHARE
+// instantiation, the 64-register cap spilled 35 registers instead of 4 and the preprocess of 1M Gaussians took 80 us instead of 52).
+template <bool SL /* depth slabs in use (TFSlabs): the plain instantiation carries none of their arithmetic */, bool SHARE, bool MV>
 __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preprocess_tf_kernel(
     int P /* per view */, int V /* stacked views (round 6): the kernel runs over the V * P view instances v * P + i, tile grids stacked */,
     uint32_t per_wg, const TFSlabs slabs, const float *__restrict__ means3D, const float *__restrict__ scales, float scale_modifier,
@@ -227,8 +229,8 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
     const uint32_t NT = blockDim.x;
     const int nw = (int)(NT >> 6);
     const uint32_t nsl = SL ? slabs.n : 1u;
-    const uint32_t T = (uint32_t)(gx * gy * V) * nsl;   // lists
-    const uint32_t PV = (uint32_t)P * (uint32_t)V;
+    const uint32_t T = (uint32_t)(gx * gy * (MV ? V : 1)) * nsl;   // lists
+    const uint32_t PV = (uint32_t)P * (uint32_t)(MV ? V : 1);
     const uint32_t g0 = blockIdx.x * per_wg, g1 = min(g0 + per_wg, PV);   // this workgroup's view instances
     R2_TS_AT(geom, 0);
     for (uint32_t t = tid; t < T; t += NT) tf_hist[t] = 0u;
@@ -241,11 +243,11 @@ __global__ void __launch_bounds__(TF_THREADS_MAX, SHARE ? 8 : 4) raster_preproce
         const uint32_t idx = g0 + (uint32_t)it * NT + (uint32_t)tid;
         uint2 bt = make_uint2(0u, 0u);
         if ((it == 0 || NT * (uint32_t)it < per_wg) && idx < g1) {   // (workgroup-uniform first half: no second round for small workgroups)
-            const uint32_t v = V == 1 ? 0u : idx / (uint32_t)P;   // the instance's view: its matrices, its rows of the stacked grid
+            const uint32_t v = MV ? idx / (uint32_t)P : 0u;   // the instance's view: its matrices, its rows of the stacked grid
             raster_preprocess_one((int)idx, (int)(idx - v * (uint32_t)P), means3D, scales, scale_modifier, rotations, opacities,
                                   cov3D_precomp, view + 16u * v, proj + 16u * v, W, H, tan_fovx, tan_fovy, focal_x, focal_y, mode, gx, gy,
                                   radii, rec, depth_key, cov3Ds, tiles_touched, op_mu, &thin, noreg, key[it], bt, rect[it]);
-            if (key[it] != DEPTH_CULLED_KEY) rect[it] += (v * (uint32_t)gy) << 8;   // y0 of the rectangle in the stacked grid (< 256 rows)
+            if (MV && key[it] != DEPTH_CULLED_KEY) rect[it] += (v * (uint32_t)gy) << 8;   // y0 of the rectangle in the stacked grid (< 256 rows)
         }
     }
     R2_TS_AT(geom, 10);
@@ -834,20 +836,23 @@ int launch_raster_preprocess_tf(const RasterGeom &g, int P, int V, const TFGrid 
     const float focal_y = H / (2.0f * tan_fovy);
     const float focal_x = W / (2.0f * tan_fovx);
     const int gx = (W + TILE2D - 1) / TILE2D, gy = (H + TILE2D - 1) / TILE2D;
-    const bool share = (int)grid.wgs > device_cu_count() && grid.threads > TF_THREADS_MAX / 2;
-#define R2_TF_PRE(SLB)                                                                                                            \
-    if (share)                                                                                                                        \
-        raster_preprocess_tf_kernel<SLB, true><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * V * slabs.n * sizeof(uint32_t), s>>>( \
-            P, V, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx,    \
-            tan_fovy, focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect,  \
-            g.tf_wgoff, g.tf_wgmm, ctr);                                                                                                \
-    else                                                                                                                              \
-    raster_preprocess_tf_kernel<SLB, false><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * V * slabs.n * sizeof(uint32_t), s>>>(   \
+    bool share = (int)grid.wgs > device_cu_count() && grid.threads > TF_THREADS_MAX / 2;
+    {   // stacked views: the view arithmetic does not fit the 64-register instantiation (35 spilled registers); one workgroup per CU
+        // at a time measured 1.5 % (V = 2) and 0.7 % (V = 4) faster per call than two spilling ones (R2_TF_MV_SHARE=1: the other way)
+        static const int mv_share = [] { const char *e = getenv("R2_TF_MV_SHARE"); return e ? atoi(e) : 0; }();
+        if (V > 1 && !mv_share) share = false;
+    }
+#define R2_TF_PRE(SLB, SHR, MVW)                                                                                                       \
+    raster_preprocess_tf_kernel<SLB, SHR, MVW><<<dim3(grid.wgs), dim3(grid.threads), (size_t)gx * gy * V * slabs.n * sizeof(uint32_t), s>>>( \
         P, V, grid.per_wg, slabs, means3D, scales, scale_modifier, rotations, opacities, cov3D_precomp, view, proj, W, H, tan_fovx, tan_fovy, \
-        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,  \
+        focal_x, focal_y, mode, gx, gy, radii, g.rec, g.depth_key, g.cov3D, g.tiles_touched, g.op_mu, g.first, g.tf_rect, g.tf_wgoff,      \
         g.tf_wgmm, ctr)
-    if (slabs.n > 1u) R2_TF_PRE(true);
-    else R2_TF_PRE(false);
+#define R2_TF_PRE2(SLB)                                                                                                                \
+    if (share) { if (V > 1) R2_TF_PRE(SLB, true, true); else R2_TF_PRE(SLB, true, false); }                                             \
+    else { if (V > 1) R2_TF_PRE(SLB, false, true); else R2_TF_PRE(SLB, false, false); }
+    if (slabs.n > 1u) { R2_TF_PRE2(true) }
+    else { R2_TF_PRE2(false) }
+#undef R2_TF_PRE2
 #undef R2_TF_PRE
     return 0;
 }
