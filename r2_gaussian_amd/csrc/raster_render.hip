@@ -67,6 +67,51 @@ __device__ __forceinline__ void fwd_item(const float4 a, float C2, float L, floa
     const unsigned long long full_exec = __builtin_amdgcn_read_exec();
     (void)full_exec;
 #endif
+#ifndef R2_EXP_NO_YRECUR
+    if (!EXACT) {
+        // Round 6: a second recurrence ACROSS the rows (the voxelizer's, voxel_render.hip vfwd_item, round 4).  Until now every row
+        // paid two v_exp_f32 (start value, first ratio) and the arithmetic of their arguments: 14 of a row's 54 issue slots.  The
+        // row starts E(r) = log2 alpha(column 0, row r) are a parabola in r as well:
+        //   rows 4..7: g(4) = 2^E(4), g(r+1) = g(r) rho(r), rho(r+1) = rho(r) kappa     rho(4) = 2^(E(5) - E(4))
+        //   rows 3..0: g(3) = 2^E(3), g(r-1) = g(r) rho'(r), rho'(r-1) = rho'(r) kappa  rho'(3) = 2^(E(2) - E(3))
+        //   first ratio along the row: rt(4) = 2^(k1 - B2 dy4), rt(r+1) = rt(r) chi, rt(r-1) = rt(r) / chi
+        // with kappa = 2^(2 C2), chi = 2^B2: nine exponentials per entry instead of seventeen, three multiplications per row.  The
+        // walks start in the middle of the block (three steps each way); item_exact (raster_state.hpp) keeps out the entries for
+        // which three steps down a column and seven along a row could start from an underflowed value and climb above the cut-off.
+        const float bdx = a.w * dx0, adl = dx0 * (a.z * dx0) + L;
+        const float dy4 = a.y - (y0 + 4.0f), dy3 = a.y - (y0 + 3.0f);
+        float gu = __builtin_amdgcn_exp2f(dy4 * (C2 * dy4 + bdx) + adl), gd = __builtin_amdgcn_exp2f(dy3 * (C2 * dy3 + bdx) + adl);
+        float ru = __builtin_amdgcn_exp2f(fminf(C2 * (1.0f - 2.0f * dy4) - bdx, 100.0f));
+        float rd = __builtin_amdgcn_exp2f(fminf(C2 * (1.0f + 2.0f * dy3) + bdx, 100.0f));
+        const float kap = __builtin_amdgcn_exp2f(2.0f * C2);
+        const float chi = __builtin_amdgcn_exp2f(a.w), chii = __builtin_amdgcn_exp2f(-a.w);
+        float rtu = __builtin_amdgcn_exp2f(fminf(k1 - a.w * dy4, 120.0f));
+        float rtd = rtu * chii;
+#define R2_FWD_ROW(ROW, G0, RT0)                                                                \
+        {                                                                                       \
+            float g = (G0), rt = (RT0);                                                         \
+            _Pragma("unroll") for (int c = 0; c < SUB2D; ++c) {                                 \
+                acc[(ROW) * SUB2D + c] += (g >= ALPHA_MIN_2D) ? g : 0.f;                        \
+                g *= rt;                                                                        \
+                rt *= rr;                                                                       \
+            }                                                                                   \
+        }
+#pragma unroll
+        for (int j = 0; j < SUB2D / 2; ++j) {
+            R2_FWD_ROW(SUB2D / 2 + j, gu, rtu)
+            gu *= ru; ru *= kap; rtu *= chi;
+            __builtin_amdgcn_sched_barrier(0);   // one row at a time: keeps the 64 accumulators + one row of temporaries live
+        }
+#pragma unroll
+        for (int j = 0; j < SUB2D / 2; ++j) {
+            R2_FWD_ROW(SUB2D / 2 - 1 - j, gd, rtd)
+            gd *= rd; rd *= kap; rtd *= chii;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#undef R2_FWD_ROW
+        return;
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < SUB2D; ++r) {
         const float dy = a.y - (y0 + (float)r);
@@ -196,10 +241,10 @@ __global__ void __launch_bounds__(256, 4) raster_render_forward_kernel(
             // tier 0 / 1: row recurrence over 8 pixels, or re-anchored at pixel 4 (thin Gaussians; only waves holding
             // such an entry pay for the two extra exps per row).  Tier 2 (exact) entries contribute 0
             // here (L = -inf) and are evaluated by a second in-place pass, only if the wave holds any.
-            const int tier = (head + lane < cnt) ? row_tier(ea.z, eb.y, eb.z) : 0;
+            const int tier = (head + lane < cnt) ? item_tier(ea.z, ea.w, eb.x, eb.y, eb.z, eb.w) : 0;
             const bool exact = tier >= 1;   // (see fwd_item)
             const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
-            fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+            fwd_item<false>(ra, exact ? 0.f : eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
             if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
         }
     }
@@ -383,10 +428,10 @@ __global__ void __launch_bounds__(64, R2_EXP_FWD_OCC) raster_render_forward_wave
 #endif
         const bool live = head + lane < cnt;
         if (!live) { ea = make_float4(0.f, 0.f, 0.f, 0.f); eb = make_float4(0.f, -INFINITY, 0.f, 0.f); }   // idle lane: alpha = 0
-        const int tier = live ? row_tier(ea.z, eb.y, eb.z) : 0;
-        const bool exact = tier >= 1;   // (an entry the 8-step recurrence is not safe for: the exact path, see fwd_item)
+        const int tier = live ? item_tier(ea.z, ea.w, eb.x, eb.y, eb.z, eb.w) : 0;
+        const bool exact = tier >= 1;   // (an entry the recurrences are not safe for: the exact path, see fwd_item)
         const float4 ra = exact ? make_float4(0.f, 0.f, 0.f, 0.f) : ea;
-        fwd_item<false>(ra, eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
+        fwd_item<false>(ra, exact ? 0.f : eb.x, exact ? -INFINITY : eb.y, x0, y0, acc);
         if (__any(exact)) fwd_item<true>(ea, eb.x, exact ? eb.y : -INFINITY, x0, y0, acc);
     }
 

@@ -63,6 +63,26 @@ __device__ __forceinline__ int row_tier(float A2, float L, float hx)
     return a <= s8 * s8 ? 0 : (a <= s4 * s4 ? 1 : 2);
 }
 __device__ __forceinline__ bool needs_exact_row(float A2, float L, float hx) { return row_tier(A2, L, hx) == 2; }
+// Round 6, the tier with the recurrence across the rows (fwd_item): the walks start at (row 4 | 3, column 0) of the block, go up to
+// three steps along the column and then seven along a row.  With q = -d^T M d (M positive definite), sqrt(-q) is the norm
+// |M^(1/2) d|: between the anchor and a pixel at displacement v it changes by at most sqrt(v^T M v) <= sqrt(49 |A2| + 9 |C2| +
+// 21 |B2|), so an underflowed anchor cannot hide a pixel above the cut-off if that stays below row_tier's `room` (for an isotropic
+// Gaussian: sigma >= 0.92 px, against 0.85 px for the seven row steps alone; the bound 7 sqrt|A2| + 3 sqrt|C2| that ignores how
+// the two displacements combine sent sigma < 1.2 px -- a third of the benchmark cloud's entries -- down the exact path).  A row
+// start the column walk underflowed is covered by the row criterion, which this implies.  0: both recurrences; 2: exact
+// per-pixel evaluation.  (Without the row recurrence -- R2_EXP_NO_YRECUR -- this is row_tier.)
+__device__ __forceinline__ int item_tier(float A2, float B2, float C2, float L, float hx, float hy)
+{
+#ifdef R2_EXP_NO_YRECUR
+    (void)B2; (void)C2; (void)hy;
+    return row_tier(A2, L, hx);
+#else
+    const float room = __builtin_amdgcn_sqrtf(fmaxf(125.5f + fminf(L, 0.f), 0.f)) - __builtin_amdgcn_sqrtf(fmaxf(L - LOG2_ALPHA_MIN_2D, 0.f) + 1.0f);
+    if (!(hx < 3.0e38f) || !(hy < 3.0e38f) || !(room > 0.f)) return 2;
+    const float reach2 = 49.0f * fabsf(A2) + 9.0f * fabsf(C2) + 21.0f * fabsf(B2);
+    return reach2 <= room * room ? 0 : 2;
+#endif
+}
 
 // does the bounding box (px +- hx, py +- hy) of a Gaussian's alpha >= 1e-5 region touch the pixel block
 // [x0, x0+n) x [y0, y0+n)?  (pixel centres are the integers; +-inf half-extents mean never / always)
