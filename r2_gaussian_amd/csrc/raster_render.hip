@@ -644,13 +644,113 @@ __device__ __forceinline__ void pixel_moments(float A2, float lthr, float dx, fl
 // kernel): two v_exp_f32 per row instead of one per pixel.
 template <int N, bool EXACT>
 __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b, const float *__restrict__ gt,
-                                                  float bx0, float by0, float *S, bool any4 = false, bool need4 = false)
+                                                  float bx0, float by0, float *S)
 {
     const float dx0 = a.x - bx0;
     const float lthr = LOG2_ALPHA_MIN_2D - b.y;                         // alpha >= 1e-5 <=> log2 G >= lthr
     const float gthr = EXACT ? 0.f : __builtin_amdgcn_exp2f(lthr);
     const float k1 = a.z * (1.0f - 2.0f * dx0);
     const float rr = EXACT ? 0.f : __builtin_amdgcn_exp2f(2.0f * a.z);
+    // column moments t_k = sum_c (c - mid)^k w_c about the block's centre column (the (c - mid)^k are literals: one
+    // FMA each), turned into moments of dx = (dx0 - mid) - (c - mid) once per row; centring halves |dx0 - mid| and
+    // with it the cancellation in r3
+    constexpr float mid = 0.5f * (float)(N - 1);
+    const float dm = dx0 - mid;
+#ifndef R2_EXP_NO_CMPX
+    static_assert(N == 8, "the pixel macro below is written for 8-pixel rows");
+    // the EXEC save / restore below is written for wave64 on gfx9-family ISA (64-bit exec, v_cmpx writing EXEC); the
+    // plain-C++ body under R2_EXP_NO_CMPX is the portable statement of the same arithmetic (tests build and compare it)
+#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
+#error "the inline asm below assumes a 64-lane EXEC mask (wave64)"
+#endif
+    const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
+    (void)full_exec;
+#endif
+    // one row of the block with the row recurrence: G = alpha / amplitude at column 0, rt = its first ratio
+    auto recur_row = [&](int r, float G, float rt) {
+        const float dy = a.y - (by0 + (float)r);
+        float g[N];
+#pragma unroll
+        for (int c4 = 0; c4 < N / 4; ++c4) {
+            const float4 v = *reinterpret_cast<const float4 *>(gt + r * GT_STRIDE + 4 * c4);
+            g[4 * c4 + 0] = v.x; g[4 * c4 + 1] = v.y; g[4 * c4 + 2] = v.z; g[4 * c4 + 3] = v.w;
+        }
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#ifndef R2_EXP_NO_CMPX
+        // power <= 0 holds for a positive definite conic; the cut-off is applied as an EXEC mask: v_cmpx narrows EXEC
+        // to the lanes whose pixel passes, the product and the three moment updates run under it (a masked lane keeps
+        // its sums: the same as adding 0), s_mov restores EXEC on the scalar unit -- 5 VALU instead of the 6 of compare +
+        // select + multiply + 3 updates (this kernel is VALU-issue-bound).  (c - mid)^k enter as literal operands.
+#define R2_BWD_K(x) "n"(__builtin_bit_cast(int, (float)(x)))   /* literals: SGPR operands measured 1 us slower */
+#define R2_BWD_PX(c)                                                                                                      \
+        {                                                                                                                 \
+            float w;                                                                                                      \
+            asm volatile("v_cmpx_le_f32_e32 %[thr], %[G]\n\t"                                                             \
+                         "v_mul_f32_e32 %[w], %[G], %[g]\n\t"                                                             \
+                         "v_add_f32_e32 %[t0], %[t0], %[w]\n\t"                                                           \
+                         "v_fmac_f32_e32 %[t1], %[k1], %[w]\n\t"                                                          \
+                         "v_fmac_f32_e32 %[t2], %[k2], %[w]\n\t"                                                          \
+                         "s_mov_b64 exec, %[ex]"                                                                          \
+                         : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [w] "=&v"(w)                                      \
+                         : [thr] "v"(gthr), [G] "v"(G), [g] "v"(g[c]), [k1] R2_BWD_K((float)(c) - mid),                   \
+                           [k2] R2_BWD_K(((float)(c) - mid) * ((float)(c) - mid)), [ex] "s"(full_exec)                      \
+                         : "vcc");                                                                                        \
+            G *= rt;                                                                                                      \
+            rt *= rr;                                                                                                     \
+        }
+        R2_BWD_PX(0) R2_BWD_PX(1) R2_BWD_PX(2) R2_BWD_PX(3) R2_BWD_PX(4) R2_BWD_PX(5) R2_BWD_PX(6) R2_BWD_PX(7)
+#undef R2_BWD_PX
+#undef R2_BWD_K
+#else
+#pragma unroll
+        for (int c = 0; c < N; ++c) {
+            const float w = (G >= gthr) ? G * g[c] : 0.f;   // power <= 0 holds for a positive definite conic
+            t0 += w;
+            t1 = fmaf(w, (float)c - mid, t1);
+            t2 = fmaf(w, ((float)c - mid) * ((float)c - mid), t2);
+            G *= rt;
+            rt *= rr;
+        }
+#endif
+        const float r0 = t0, r1 = dm * t0 - t1, r3 = dm * (dm * t0 - 2.0f * t1) + t2;
+        S[0] += r0; S[1] += r1; S[3] += r3;
+        S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
+    };
+    if (!EXACT) {
+#ifndef R2_EXP_NO_YRECUR
+        // Round 6: the row starts by a recurrence across the rows, as in the forward (fwd_item has the derivation; G carries
+        // no amplitude here, the cut-off is gthr): nine exponentials per item instead of eighteen, three multiplications per row
+        // instead of two exponentials and their arguments.  item_tier keeps out the entries the walks are not safe for.
+        const float bdx = a.w * dx0, adx = dx0 * (a.z * dx0);
+        const float dy4 = a.y - (by0 + (float)(N / 2)), dy3 = dy4 + 1.0f;
+        float gu = __builtin_amdgcn_exp2f(dy4 * (b.x * dy4 + bdx) + adx), gd = __builtin_amdgcn_exp2f(dy3 * (b.x * dy3 + bdx) + adx);
+        float ru = __builtin_amdgcn_exp2f(fminf(b.x * (1.0f - 2.0f * dy4) - bdx, 100.0f));
+        float rd = __builtin_amdgcn_exp2f(fminf(b.x * (1.0f + 2.0f * dy3) + bdx, 100.0f));
+        const float kap = __builtin_amdgcn_exp2f(2.0f * b.x);
+        const float chi = __builtin_amdgcn_exp2f(a.w), chii = __builtin_amdgcn_exp2f(-a.w);
+        float rtu = __builtin_amdgcn_exp2f(fminf(k1 - a.w * dy4, 120.0f));
+        float rtd = rtu * chii;
+#pragma unroll 2
+        for (int j = 0; j < N / 2; ++j) {
+            recur_row(N / 2 + j, gu, rtu);
+            gu *= ru; ru *= kap; rtu *= chi;
+        }
+#pragma unroll 2
+        for (int j = 0; j < N / 2; ++j) {
+            recur_row(N / 2 - 1 - j, gd, rtd);
+            gd *= rd; rd *= kap; rtd *= chii;
+        }
+#else
+#pragma unroll 2
+        for (int r = 0; r < N; ++r) {
+            const float dy = a.y - (by0 + (float)r);
+            const float bdy = a.w * dy;           // B2*dy
+            const float cdy2 = (b.x * dy) * dy;   // C2*dy^2
+            recur_row(r, __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdy2), __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f)));
+        }
+#endif
+        return;
+    }
 #pragma unroll 2
     for (int r = 0; r < N; ++r) {
         const float dy = a.y - (by0 + (float)r);
@@ -663,79 +763,8 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             g[4 * c4 + 0] = v.x; g[4 * c4 + 1] = v.y; g[4 * c4 + 2] = v.z; g[4 * c4 + 3] = v.w;
         }
         float r0 = 0.f, r1 = 0.f, r3 = 0.f;
-        if (EXACT) {
 #pragma unroll
-            for (int c = 0; c < N; ++c) pixel_moments(a.z, lthr, dx0 - (float)c, bdy, cdy2, g[c], r0, r1, r3);
-        } else {
-            float G = __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdy2);
-            float rt = __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f));
-            float G4 = 0.f, rt4 = 0.f;
-            if (any4) {   // wave-uniform: re-anchor values for the thin Gaussians of this wave
-                const float dxs = dx0 - (float)(N / 2);
-                G4 = __builtin_amdgcn_exp2f(dxs * (a.z * dxs + bdy) + cdy2);
-                rt4 = __builtin_amdgcn_exp2f(fminf(k1 + (float)N * a.z - bdy, 120.0f));
-            }
-            // column moments t_k = sum_c (c - mid)^k w_c about the block's centre column (the (c - mid)^k are literals: one
-            // FMA each), turned into moments of dx = (dx0 - mid) - (c - mid) once per row; centring halves |dx0 - mid| and
-            // with it the cancellation in r3
-            constexpr float mid = 0.5f * (float)(N - 1);
-            float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#ifndef R2_EXP_NO_CMPX
-            // power <= 0 holds for a positive definite conic; the cut-off is applied as an EXEC mask: v_cmpx narrows EXEC
-            // to the lanes whose pixel passes, the product and the three moment updates run under it (a masked lane keeps
-            // its sums: the same as adding 0), s_mov restores EXEC on the scalar unit -- 5 VALU instead of the 6 of compare +
-            // select + multiply + 3 updates (this kernel is VALU-issue-bound).  (c - mid)^k enter as literal operands.
-            static_assert(N == 8, "the pixel macro below is written for 8-pixel rows");
-            // the EXEC save / restore below is written for wave64 on gfx9-family ISA (64-bit exec, v_cmpx writing EXEC); the
-            // plain-C++ body under R2_EXP_NO_CMPX is the portable statement of the same arithmetic (tests build and compare it)
-#if defined(__AMDGCN_WAVEFRONT_SIZE) && __AMDGCN_WAVEFRONT_SIZE != 64
-#error "the inline asm below assumes a 64-lane EXEC mask (wave64)"
-#endif
-            const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
-#define R2_BWD_K(x) "n"(__builtin_bit_cast(int, (float)(x)))   /* literals: SGPR operands measured 1 us slower */
-#define R2_BWD_PX(c)                                                                                                      \
-            {                                                                                                             \
-                if (c == N / 2) {                                                                                         \
-                    G = need4 ? G4 : G;                                                                                   \
-                    rt = need4 ? rt4 : rt;                                                                                \
-                }                                                                                                         \
-                float w;                                                                                                  \
-                asm volatile("v_cmpx_le_f32_e32 %[thr], %[G]\n\t"                                                         \
-                             "v_mul_f32_e32 %[w], %[G], %[g]\n\t"                                                         \
-                             "v_add_f32_e32 %[t0], %[t0], %[w]\n\t"                                                       \
-                             "v_fmac_f32_e32 %[t1], %[k1], %[w]\n\t"                                                      \
-                             "v_fmac_f32_e32 %[t2], %[k2], %[w]\n\t"                                                      \
-                             "s_mov_b64 exec, %[ex]"                                                                      \
-                             : [t0] "+v"(t0), [t1] "+v"(t1), [t2] "+v"(t2), [w] "=&v"(w)                                  \
-                             : [thr] "v"(gthr), [G] "v"(G), [g] "v"(g[c]), [k1] R2_BWD_K((float)(c) - mid),               \
-                               [k2] R2_BWD_K(((float)(c) - mid) * ((float)(c) - mid)), [ex] "s"(full_exec)                  \
-                             : "vcc");                                                                                    \
-                G *= rt;                                                                                                  \
-                rt *= rr;                                                                                                 \
-            }
-            R2_BWD_PX(0) R2_BWD_PX(1) R2_BWD_PX(2) R2_BWD_PX(3) R2_BWD_PX(4) R2_BWD_PX(5) R2_BWD_PX(6) R2_BWD_PX(7)
-#undef R2_BWD_PX
-#undef R2_BWD_K
-#else
-#pragma unroll
-            for (int c = 0; c < N; ++c) {
-                if (c == N / 2) {
-                    G = need4 ? G4 : G;
-                    rt = need4 ? rt4 : rt;
-                }
-                const float w = (G >= gthr) ? G * g[c] : 0.f;   // power <= 0 holds for a positive definite conic
-                t0 += w;
-                t1 = fmaf(w, (float)c - mid, t1);
-                t2 = fmaf(w, ((float)c - mid) * ((float)c - mid), t2);
-                G *= rt;
-                rt *= rr;
-            }
-#endif
-            const float dm = dx0 - mid;
-            r0 = t0;
-            r1 = dm * t0 - t1;
-            r3 = dm * (dm * t0 - 2.0f * t1) + t2;
-        }
+        for (int c = 0; c < N; ++c) pixel_moments(a.z, lthr, dx0 - (float)c, bdy, cdy2, g[c], r0, r1, r3);
         S[0] += r0; S[1] += r1; S[3] += r3;
         S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
     }
@@ -756,7 +785,7 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
     __shared__ uint16_t s_q[BWD_WAVES][64 * NBLK];                // item queue: (owner lane << 4) | (tile slot << 2) | block
     __shared__ float4 s_r0[BWD_WAVES][64];                        // moment rows of the current round of 64 items
     __shared__ float2 s_r1[BWD_WAVES][64];
-    const bool scene_thin = *thin_flag != 0u;   // raised by the preprocess kernel (see row_tier)
+    (void)thin_flag;   // (rounds 1-5: selected the re-anchoring variant of the step; the count is still reported to the host)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *const gt = s_gt[wave];
 
@@ -935,14 +964,10 @@ __global__ void __launch_bounds__(BWD_THREADS, BWD_OCC) raster_render_backward_k
             const float by0 = oty0 + (float)((q / NB) * SUB2D);
             const float *gq = gt + sl * GT_TILE + (q / NB) * SUB2D * GT_STRIDE + (q % NB) * SUB2D;
             // exact per-pixel path for thin / not safely positive definite Gaussians, the row recurrence for the rest
-            const int tier = e < total ? row_tier(oa.z, ob.y, ob.z) : 0;
-            const bool exact = tier == 2;
-            if (scene_thin) {   // scene-uniform: only scenes with thin Gaussians carry the re-anchoring code path
-                const bool any4 = __any(tier == 1);
-                if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M, any4, tier == 1);
-            } else {
-                if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M);
-            }
+            // (round 6: an item the recurrences are not safe for takes the exact path, as in the forward; rounds 1-5 re-anchored
+            //  the row recurrence at pixel 4 for the in-between tier, in scenes whose preprocess had seen such a Gaussian)
+            const bool exact = e < total && item_tier(oa.z, oa.w, ob.x, ob.y, ob.z, ob.w) != 0;
+            if (e < total && !exact) block_moments_lds<SUB2D, false>(oa, ob, gq, bx0, by0, M);
             if (__any(e < total && exact)) {
                 if (e < total && exact) block_moments_lds<SUB2D, true>(oa, ob, gq, bx0, by0, M);
             }
