@@ -666,6 +666,7 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
     const unsigned long long full_exec = __builtin_amdgcn_read_exec();   // this function runs inside divergent code
     (void)full_exec;
 #endif
+    float U[6] = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };   // sums over the rows of t0, t1, t2, dy t0, dy t1, dy^2 t0
     // one row of the block with the row recurrence: G = alpha / amplitude at column 0, rt = its first ratio
     auto recur_row = [&](int r, float G, float rt) {
         const float dy = a.y - (by0 + (float)r);
@@ -712,9 +713,10 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             rt *= rr;
         }
 #endif
-        const float r0 = t0, r1 = dm * t0 - t1, r3 = dm * (dm * t0 - 2.0f * t1) + t2;
-        S[0] += r0; S[1] += r1; S[3] += r3;
-        S[2] += dy * r0; S[4] += dy * r1; S[5] += dy * dy * r0;
+        // the rows' column moments are summed as they are (with the row's dy where the moment wants it) and turned into moments of
+        // dx ONCE per item, below: seven instructions per row instead of twelve
+        U[0] += t0; U[1] += t1; U[2] += t2;
+        U[3] = fmaf(dy, t0, U[3]); U[4] = fmaf(dy, t1, U[4]); U[5] = fmaf(dy * dy, t0, U[5]);
     };
     if (!EXACT) {
 #ifndef R2_EXP_NO_YRECUR
@@ -749,6 +751,8 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
             recur_row(r, __builtin_amdgcn_exp2f(dx0 * (a.z * dx0 + bdy) + cdy2), __builtin_amdgcn_exp2f(fminf(k1 - bdy, 120.0f)));
         }
 #endif
+        S[0] += U[0]; S[1] += dm * U[0] - U[1]; S[3] += dm * (dm * U[0] - 2.0f * U[1]) + U[2];
+        S[2] += U[3]; S[4] += dm * U[3] - U[4]; S[5] += U[5];
         return;
     }
 #pragma unroll 2
