@@ -153,8 +153,9 @@ __device__ __forceinline__ void raster_preprocess_one(
     rec[2 * idx] = make_float4(px, py, (-0.5f * LOG2E) * conA, (-LOG2E) * conB);
     rec[2 * idx + 1] = make_float4((-0.5f * LOG2E) * conC, L, hx, hy);
     op_mu[idx] = make_float2(op, mu);
-    // tell the render kernels whether any Gaussian needs the re-anchored row recurrence (benign race: everybody stores 1)
-    if (thin_flag && row_tier((-0.5f * LOG2E) * conA, L, hx) == 1) *thin_flag = 1u;
+    // counted for the host (DW_USER): the visible Gaussians the render kernels evaluate exactly, pixel by pixel, because the
+    // recurrences are not safe for them (item_tier; rounds 1-5: the flag that selected the re-anchoring kernel variant)
+    if (thin_flag && hx > 0.f && item_tier((-0.5f * LOG2E) * conA, (-LOG2E) * conB, (-0.5f * LOG2E) * conC, L, hx, hy) != 0) *thin_flag = 1u;
 }
 
 __global__ void __launch_bounds__(256) raster_preprocess_kernel(
