@@ -132,7 +132,7 @@ def test_a_prediction_that_falls_short_costs_a_second_pass_only(L, oracle, gpu):
 
 
 def test_thin_gaussians_need_no_second_render(L, oracle, gpu):
-    """One forward variant since round 6: Gaussians too thin for the 8-step row recurrence take the kernel's exact path, whatever
+    """One forward variant since round 6: Gaussians too thin for the recurrences (item_tier) take the kernels' exact path, whatever
     the thread saw before (rounds 4-5 chose between two variants from the previous call's flag and rendered AGAIN after a wrong guess).
     Image and every gradient are, bit for bit, what the general chain produces."""
     import ctypes as C
@@ -140,15 +140,16 @@ def test_thin_gaussians_need_no_second_render(L, oracle, gpu):
     plain = S.make_cloud(P, seed=9)
     v = S.make_views(8, (192, 192))[5]
     h0 = Hh.hip_raster(plain, v, gpu)
-    assert int(h0["host_words"][2]) == 0
+    n0 = int(h0["host_words"][2])                # Gaussians on the exact path (item_tier), as the preprocess counts them: few here
+    assert n0 < 500, n0
     sc = plain.scales.clone()
     sc[:8000] *= 0.12                            # sub-pixel Gaussians: conditional sigma ~0.4 px
     thin = S.Cloud(plain.xyz, sc, plain.rotations, plain.density)
     st = (C.c_longlong * 5)()
     L.r2_tile_first_stats(st, 1)
     t = Hh.hip_raster(thin, v, gpu)
-    nthin = int(t["host_words"][2])              # Gaussians on the re-anchored tier, as the preprocess counted them
-    assert Hh.took_tile_first(t) and nthin > 20, "the scene was meant to hold thin Gaussians: %d" % nthin
+    nthin = int(t["host_words"][2])
+    assert Hh.took_tile_first(t) and nthin > n0 + 1000, "the scene was meant to hold thin Gaussians: %d (plain cloud: %d)" % (nthin, n0)
     L.r2_tile_first_stats(st, 0)
     assert list(st)[2:4] == [0, 0], "no second pass, no repeated render"
     o = Hh.oracle_raster(oracle, thin, v)
