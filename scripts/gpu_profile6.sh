@@ -2,7 +2,7 @@
 # Round-6 profile set (the round-5 set on the round-6 tree): bench lines (driver-style, default, trained clouds, configs B / C / E, one-rank collective path), rocprofv3
 # kernel stats and TCC / SQ counter passes of the HEADLINE STEP ONLY (bench.py --headline-only) and of the 256^3 voxel query alone,
 # the C harness with in-kernel stamps, the HIP-only trainer.  scripts/make_profile_summary5.py TAG turns them into profiles/TAG_*.
-#   gpurun -- bash scripts/gpu_profile5.sh r06c
+#   gpurun -- bash scripts/gpu_profile6.sh r06g
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 TAG=${1:-r06c}

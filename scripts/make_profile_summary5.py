@@ -1,4 +1,4 @@
-"""profiles/<tag>_* from what scripts/gpu_profile5.sh left under gpurun_out/ (rounds 4-5: rocprofv3 passes over
+"""profiles/<tag>_* from what scripts/gpu_profile6.sh (rounds 4-5: gpu_profile5.sh, now in scripts/attic) left under gpurun_out/ (rounds 4-5: rocprofv3 passes over
 `bench.py --headline-only`, so every kernel row is the single-view forward + backward step, + the same for the 256^3 voxel
 query alone, + the bench lines of the trained clouds and of the one-rank collective path):
     python scripts/make_profile_summary5.py r05f "title"
