@@ -309,3 +309,23 @@ def test_deferred_count_returns_a_token_and_the_backward_resolves_it(L, gpu):
         assert np.array_equal(again["point_list"], ref["point_list"])
     finally:
         L.r2_defer_count_control(0)
+
+
+def test_gaussians_on_both_sides_of_the_recurrence_tier_match_the_oracle(L, oracle, gpu):
+    """Round 6: the render kernels walk a block's rows by a second recurrence; item_tier (csrc/raster_state.hpp) sends the entries the
+    two walks are not safe for down the exact path.  A cloud whose projected sigmas straddle that boundary (~0.5 to 2 px: both
+    paths well populated, and the recurrence path at the thin end of what it accepts, where its error is largest): image and
+    every gradient against the oracle at the usual tolerance, lists bit-exact."""
+    c = S.make_cloud(20000, seed=33, scale_mult=0.55)
+    v = S.make_views(8, (192, 192))[2]
+    Hh.hip_raster(c, v, gpu)
+    t = Hh.hip_raster(c, v, gpu)
+    assert Hh.took_tile_first(t)
+    nvis, nexact = int((t["radii"] > 0).sum()), int(t["host_words"][2])
+    assert 0.05 * nvis < nexact < 0.95 * nvis, "the cloud was meant to straddle the tier: %d of %d visible on the exact path" % (nexact, nvis)
+    o = Hh.oracle_raster(oracle, c, v)
+    Hh.check_binning(t, o)
+    Hh.parity_image(oracle, o, t["color"], "both sides of item_tier")
+    dL = S.make_pixel_grad(192, 192).numpy()
+    gh = Hh.hip_raster_backward(t, c, v, dL, gpu)
+    Hh.parity_raster_grads(oracle, o, gh, c, v, dL, "both sides of item_tier")
