@@ -732,12 +732,14 @@ __device__ __forceinline__ void block_moments_lds(const float4 a, const float4 b
         const float chi = __builtin_amdgcn_exp2f(a.w), chii = __builtin_amdgcn_exp2f(-a.w);
         float rtu = __builtin_amdgcn_exp2f(fminf(k1 - a.w * dy4, 120.0f));
         float rtd = rtu * chii;
-#pragma unroll 2
+        // (all four rows unrolled: with `unroll 2` -- what the loop over eight rows used until the row recurrence -- the loop-carried
+        // recurrence state and the row's LDS address sat in the way of the scheduler: 53.9 -> 51.9 us, 137 -> 130 on the 331k cloud)
+#pragma unroll
         for (int j = 0; j < N / 2; ++j) {
             recur_row(N / 2 + j, gu, rtu);
             gu *= ru; ru *= kap; rtu *= chi;
         }
-#pragma unroll 2
+#pragma unroll
         for (int j = 0; j < N / 2; ++j) {
             recur_row(N / 2 - 1 - j, gd, rtd);
             gd *= rd; rd *= kap; rtd *= chii;
